@@ -1,0 +1,217 @@
+/*
+ * kta_hip.h — C ABI of libkta_hip.so: the MI355X (gfx950) implementation of the
+ * per-record metric-accumulation hot path of xenji/kafka-topic-analyzer.
+ *
+ * This is the drop-in boundary.  Reference interface being replaced (paths under
+ * /root/reference):
+ *
+ *   src/kafka.rs:18-20    trait MetricHandler { fn handle_message(&mut self, m: &BorrowedMessage) }
+ *   src/kafka.rs:107-109  dispatch: every handler, every polled message, registration order
+ *   src/metric.rs:206-253 impl MetricHandler for MessageMetrics
+ *   src/metric.rs:288-305 impl MetricHandler for LogCompactionInMemoryMetrics (-c)
+ *   src/metric.rs:104-195 accessors the report reads (main.rs:130-170)
+ *   src/metric.rs:282-284 sum_all_alive()
+ *
+ * A Rust `MetricHandler` shim binds these entry points over FFI (INTEGRATION.md shows
+ * the `extern "C"` block): `handle_message` becomes `kta_handle_message` (copies what
+ * the borrowed message exposes into pinned struct-of-arrays staging and launches the
+ * HIP kernels whenever a batch fills), and the accessors read a `kta_result` obtained
+ * from `kta_finish`.  Plain pointers and sizes only; every function returns a status
+ * (0 = OK, negative = error) and never throws or aborts across the boundary.
+ * There is NO CPU fallback: without a usable gfx950 device `kta_create` fails.
+ *
+ * Threading: one producer thread per context (the reference's poll loop is single
+ * threaded, kafka.rs:92-135).  Internally the context owns two HIP streams (H2D copy,
+ * compute) and a ring of pinned staging batches.
+ */
+#ifndef KTA_HIP_H
+#define KTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KTA_ABI_VERSION 1
+
+/* status codes */
+#define KTA_OK 0
+#define KTA_ERR_INVALID (-1)       /* bad argument / misuse                         */
+#define KTA_ERR_HIP (-2)           /* a HIP runtime call failed (see kta_last_error) */
+#define KTA_ERR_NOMEM (-3)         /* host or device allocation failed              */
+#define KTA_ERR_NO_DEVICE (-4)     /* no usable gfx950 device                        */
+#define KTA_ERR_BAD_PARTITION (-5) /* a record's partition id was outside [0, P)     */
+#define KTA_ERR_CAPACITY (-6)      /* batch / key-byte capacity exceeded             */
+#define KTA_ERR_DIV_BY_ZERO (-7)   /* where the reference panics (metric.rs:135,144,153) */
+
+/* Per-partition counters, in the field order of `struct MessageMetrics`
+ * (metric.rs:13-19). */
+enum {
+    KTA_C_TOTAL = 0,          /* total_messages  metric.rs:13 */
+    KTA_C_TOMBSTONES = 1,     /* tombstones      metric.rs:14 */
+    KTA_C_ALIVE = 2,          /* alive           metric.rs:15 */
+    KTA_C_KEY_NULL = 3,       /* key_null        metric.rs:16 */
+    KTA_C_KEY_NON_NULL = 4,   /* key_non_null    metric.rs:17 */
+    KTA_C_KEY_SIZE_SUM = 5,   /* key_size_sum    metric.rs:18 */
+    KTA_C_VALUE_SIZE_SUM = 6, /* value_size_sum  metric.rs:19 */
+    KTA_NCOUNTERS = 7
+};
+
+/* The device result vector ("counter vector") is u64[P*7 + KTA_NGLOBALS]:
+ * counters[p*7 + c] followed by the globals below.  It is the unit that is
+ * all-reduced across GPUs when partitions are sharded (SUM over the counters and
+ * the SUM-type globals, MAX/MIN over the extrema). */
+enum {
+    KTA_G_MIN_TS_MS = 0,  /* i64, INT64_MAX when no record seen; -1 (n/a) already mapped to 0 */
+    KTA_G_MAX_TS_MS = 1,  /* i64, INT64_MIN when no record seen                              */
+    KTA_G_SMALLEST = 2,   /* i64-ranged size of the smallest non-tombstone, INT64_MAX if none */
+    KTA_G_LARGEST = 3,    /* size of the largest non-tombstone, 0 if none (metric.rs:41)      */
+    KTA_G_BAD_PARTITION = 4, /* SUM: records whose partition id was out of range (ignored)     */
+    KTA_G_ALIVE_KEYS = 5, /* SUM: filled by kta_finish when count_alive_keys                 */
+    KTA_G_RECORDS = 6,    /* SUM: records scanned (== overall_count, metric.rs:25)           */
+    KTA_G_RESERVED = 7,
+    KTA_NGLOBALS = 8
+};
+
+typedef struct kta_ctx kta_ctx;
+
+typedef struct kta_config {
+    int32_t device_id;           /* HIP device ordinal                                        */
+    int32_t n_partitions;        /* P: partition ids are dense in [0, P) (Kafka's are)         */
+    int32_t count_alive_keys;    /* 1 == the reference's -c/--count-alive-keys (main.rs:77-80) */
+    int32_t n_staging;           /* pinned staging batches in the ring; 0 -> 2                */
+    uint64_t batch_capacity;     /* records per staging batch; 0 -> 1<<22                     */
+    uint64_t key_bytes_capacity; /* key bytes per staging batch; 0 -> 64 * batch_capacity;
+                                    must be < 4 GiB (key_off is u32, batch-local)             */
+} kta_config;
+
+/* One batch of decoded records as struct-of-arrays columns.  What the reference's
+ * handlers read from a BorrowedMessage (metric.rs:208-209, 218, 233, 291-293):
+ *   partition[i]  m.partition()                                          i32
+ *   ts_ms[i]      raw rdkafka timestamp in ms; -1 == not available       i64
+ *   key_len[i]    m.key():  -1 == None, >= 0 == Some(k).len()            i32
+ *   val_len[i]    m.payload(): -1 == None (tombstone), >= 0 == len       i32
+ *   key_off[i]    offset of the key's bytes in key_bytes (if key_len>0)  u32  (-c only)
+ *   key_bytes     concatenated key bytes                                  u8   (-c only)
+ *   seq[i]        optional global consumption index; NULL => base_seq+i  u64  (-c only)
+ * Value bytes are never read by the reference path (only their length). */
+typedef struct kta_batch {
+    int32_t *partition;
+    int32_t *key_len;
+    int32_t *val_len;
+    int64_t *ts_ms;
+    uint32_t *key_off;
+    uint8_t *key_bytes;
+    uint64_t *seq;
+    uint64_t capacity;           /* records the columns can hold   */
+    uint64_t key_bytes_capacity; /* bytes key_bytes can hold       */
+} kta_batch;
+
+/* Decoded results: everything the reference's report reads (main.rs:130-170). */
+typedef struct kta_result {
+    uint32_t n_partitions;
+    uint32_t any_records;      /* 1 if at least one record was scanned                 */
+    uint32_t any_live;         /* 1 if at least one non-tombstone was scanned           */
+    uint32_t count_alive_keys; /* 1 if alive_keys is valid                              */
+    int64_t min_ts_sec;        /* min over records of trunc(ts_ms/1000) (metric.rs:210) */
+    int64_t max_ts_sec;
+    uint64_t smallest_message; /* raw state: u64::MAX if no non-tombstone (metric.rs:42) */
+    uint64_t largest_message;  /* raw state: 0 if none (metric.rs:41)                   */
+    uint64_t overall_count;    /* metric.rs:25 */
+    uint64_t overall_size;     /* metric.rs:24 */
+    uint64_t alive_keys;       /* sum_all_alive(), metric.rs:282-284                    */
+    uint64_t bad_partition_records;
+} kta_result;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+/* MessageMetrics::new + LogCompactionInMemoryMetrics::new (metric.rs:30-46, 267-271):
+ * allocates the device counter vector, the scan workspace and — with
+ * count_alive_keys — the 2^32-slot last-writer table (32 GiB of HBM). */
+int kta_create(const kta_config *cfg, kta_ctx **out);
+void kta_destroy(kta_ctx *ctx);
+/* Message of the last failure on this context (ctx may be NULL: last kta_create failure
+ * on the calling thread).  Never NULL. */
+const char *kta_last_error(const kta_ctx *ctx);
+int kta_abi_version(void);
+/* Zero all accumulated state (counters, extrema, alive table). */
+int kta_reset(kta_ctx *ctx);
+
+/* ---- per-message entry: what MetricHandler::handle_message binds to ----------- */
+/* kafka.rs:107-109 / metric.rs:207-252 / metric.rs:289-304.  key == NULL or
+ * key_len < 0 is key None; val_len < 0 is payload None.  The call copies lengths,
+ * timestamp, partition and (with -c) the key bytes into the current pinned staging
+ * batch and submits it when full.  Records get consecutive sequence numbers. */
+int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const void *key,
+                       int64_t key_len, int64_t val_len);
+/* Submit the partially filled staging batch, if any. */
+int kta_flush(kta_ctx *ctx);
+
+/* ---- batch entry: a decoder that already produces columns --------------------- */
+/* Borrow the current pinned staging batch (blocks until the ring has a free one). */
+int kta_batch_acquire(kta_ctx *ctx, kta_batch *out);
+/* Submit the first n_records of the acquired batch: async H2D copy + kernels.
+ * base_seq = global consumption index of record 0 (ignored without -c). */
+int kta_batch_submit(kta_ctx *ctx, uint64_t n_records, uint64_t n_key_bytes, uint64_t base_seq);
+
+/* ---- device-resident batches (HBM-resident topic shards, benchmarks) ----------- */
+/* Column pointers in `cols` are device pointers (16-byte aligned).  Asynchronous on
+ * the context's compute stream. */
+int kta_submit_device(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records, uint64_t base_seq);
+/* Run only one of the two handlers over a device batch (profiling / benchmarks):
+ * which = 1 MessageMetrics, 2 LogCompactionInMemoryMetrics, 3 both. */
+int kta_submit_device_ex(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records,
+                         uint64_t base_seq, int which);
+int kta_device_batch_alloc(kta_ctx *ctx, uint64_t capacity, uint64_t key_bytes_capacity,
+                           int with_seq, kta_batch *out);
+int kta_device_batch_free(kta_ctx *ctx, kta_batch *cols);
+int kta_copy_to_device(kta_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int kta_copy_to_host(kta_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- results --------------------------------------------------------------------- */
+/* Wait for everything submitted so far. */
+int kta_sync(kta_ctx *ctx);
+/* Fold everything submitted so far, count alive keys (with -c), copy the counter vector
+ * to the host and decode it.  counters_out (may be NULL) receives P*7 u64.  Returns
+ * KTA_ERR_BAD_PARTITION (results still filled in) if any record was out of range.
+ * Non-destructive: more batches may follow and kta_finish may be called again. */
+int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out);
+/* Device pointer and length (in u64) of the counter vector, for collectives over
+ * partition-sharded GPUs.  Valid after kta_finish_device. */
+int kta_result_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
+/* As kta_finish but leaves the vector on the device (no D2H, asynchronous). */
+int kta_finish_device(kta_ctx *ctx);
+/* Host-side decode of a (possibly all-reduced) counter vector. */
+int kta_decode_vector(const uint64_t *vec, uint32_t n_partitions, int count_alive_keys,
+                      kta_result *out, uint64_t *counters_out);
+/* Host-side merge of two counter vectors (acc <- acc (+) other) with the per-field
+ * reduction operator (SUM / MIN / MAX) — the reduction a collective must implement. */
+int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t n_partitions);
+
+/* ---- alive-key table access (tests, multi-GPU merge) ------------------------------ */
+/* Export the alive set as a 2^32-bit little-endian bitmap (bit h%32 of u32 word h/32;
+ * 512 MiB) into host memory — the same layout as BitSet's storage (metric.rs:263). */
+int kta_export_alive_bitmap(kta_ctx *ctx, void *dst_host_512MiB);
+/* Device pointer of the last-writer table: u64[2^32], entry = ((seq+1)<<1)|alive, 0 = never
+ * written.  Element-wise MAX across GPUs merges shards exactly. */
+int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
+/* Hash `n` keys on the device with the reference's FNV variant (fnv32.rs:92-101). */
+int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes_host, const uint32_t *key_off_host,
+                     const int32_t *key_len_host, uint64_t n, uint64_t n_key_bytes,
+                     uint32_t *hash_out_host);
+
+/* ---- profiling hooks --------------------------------------------------------------- */
+/* Average duration (ms) of the kernels launched by the last `kta_submit_device*` call,
+ * measured with HIP events on the compute stream: [0] metrics scan, [1] partial fold,
+ * [2] alive-key update.  Requires kta_set_timing(ctx, 1); entries are -1 when not run. */
+int kta_set_timing(kta_ctx *ctx, int enable);
+int kta_last_kernel_ms(kta_ctx *ctx, float out_ms[3]);
+/* Launch-geometry knobs (0 = default): scan workgroups, LDS replication log2, alive WGs. */
+int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups,
+                   int alive_variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTA_HIP_H */

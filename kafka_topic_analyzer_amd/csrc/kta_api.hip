@@ -1,0 +1,627 @@
+// kta_api.hip — the extern "C" boundary of libkta_hip.so (include/kta_hip.h): context,
+// pinned struct-of-arrays staging ring, H2D/compute streams, result decode.
+// Host code only; the kernels are in kta_kernels.hip.  There is no CPU fallback: every
+// entry point that computes anything needs a gfx950 device.
+#include "../../include/kta_hip.h"
+#include "kta_kernels.h"
+
+#include <limits.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct Stage {
+    kta_batch host{};  // pinned
+    kta_batch dev{};   // device staging
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+} // namespace
+
+struct kta_ctx {
+    int device = 0;
+    uint32_t P = 0;
+    bool alive = false;
+    int cu_count = 256;
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    hipEvent_t ev_copied = nullptr;
+    uint64_t *d_vec = nullptr;      // u64[P*7 + KTA_NGLOBALS]
+    uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
+    uint32_t max_rows = 0;
+    uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
+    std::vector<Stage> stages;
+    uint64_t batch_capacity = 0, key_bytes_capacity = 0;
+    int cur = 0;
+    bool acquired = false;
+    uint64_t fill_n = 0, fill_kb = 0; // kta_handle_message fill state
+    uint64_t next_seq = 0;
+    // tuning / profiling
+    int scan_wgs = 0, scan_variant = 1, alive_wgs = 0, alive_variant = 0;
+    bool timing = false;
+    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[3] = {-1.f, -1.f, -1.f};
+    std::string err;
+};
+
+namespace {
+
+int fail(kta_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(kta_ctx *ctx, hipError_t e, const char *what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(ctx, e == hipErrorOutOfMemory ? KTA_ERR_NOMEM : KTA_ERR_HIP, m);
+}
+
+#define KTA_HIP(ctx, call)                                         \
+    do {                                                           \
+        hipError_t e__ = (call);                                   \
+        if (e__ != hipSuccess) return hip_fail(ctx, e__, #call);   \
+    } while (0)
+
+size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+int alloc_device_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, bool seq, kta_batch *b)
+{
+    memset(b, 0, sizeof(*b));
+    b->capacity = cap;
+    b->key_bytes_capacity = keys ? kcap : 0;
+    const size_t c4 = pad16(cap * 4 + 16), c8 = pad16(cap * 8 + 16);
+    KTA_HIP(ctx, hipMalloc((void **)&b->partition, c4));
+    KTA_HIP(ctx, hipMalloc((void **)&b->key_len, c4));
+    KTA_HIP(ctx, hipMalloc((void **)&b->val_len, c4));
+    KTA_HIP(ctx, hipMalloc((void **)&b->ts_ms, c8));
+    if (keys) {
+        KTA_HIP(ctx, hipMalloc((void **)&b->key_off, c4));
+        KTA_HIP(ctx, hipMalloc((void **)&b->key_bytes, pad16(kcap + 16)));
+    }
+    if (seq) KTA_HIP(ctx, hipMalloc((void **)&b->seq, c8));
+    return KTA_OK;
+}
+
+void free_device_batch(kta_batch *b)
+{
+    if (b->partition) (void)hipFree(b->partition);
+    if (b->key_len) (void)hipFree(b->key_len);
+    if (b->val_len) (void)hipFree(b->val_len);
+    if (b->ts_ms) (void)hipFree(b->ts_ms);
+    if (b->key_off) (void)hipFree(b->key_off);
+    if (b->key_bytes) (void)hipFree(b->key_bytes);
+    if (b->seq) (void)hipFree(b->seq);
+    memset(b, 0, sizeof(*b));
+}
+
+int alloc_host_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, kta_batch *b)
+{
+    memset(b, 0, sizeof(*b));
+    b->capacity = cap;
+    b->key_bytes_capacity = keys ? kcap : 0;
+    KTA_HIP(ctx, hipHostMalloc((void **)&b->partition, pad16(cap * 4), hipHostMallocDefault));
+    KTA_HIP(ctx, hipHostMalloc((void **)&b->key_len, pad16(cap * 4), hipHostMallocDefault));
+    KTA_HIP(ctx, hipHostMalloc((void **)&b->val_len, pad16(cap * 4), hipHostMallocDefault));
+    KTA_HIP(ctx, hipHostMalloc((void **)&b->ts_ms, pad16(cap * 8), hipHostMallocDefault));
+    if (keys) {
+        KTA_HIP(ctx, hipHostMalloc((void **)&b->key_off, pad16(cap * 4), hipHostMallocDefault));
+        KTA_HIP(ctx, hipHostMalloc((void **)&b->key_bytes, pad16(kcap + 16), hipHostMallocDefault));
+    }
+    return KTA_OK;
+}
+
+void free_host_batch(kta_batch *b)
+{
+    if (b->partition) (void)hipHostFree(b->partition);
+    if (b->key_len) (void)hipHostFree(b->key_len);
+    if (b->val_len) (void)hipHostFree(b->val_len);
+    if (b->ts_ms) (void)hipHostFree(b->ts_ms);
+    if (b->key_off) (void)hipHostFree(b->key_off);
+    if (b->key_bytes) (void)hipHostFree(b->key_bytes);
+    memset(b, 0, sizeof(*b));
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Launch the handlers over device-resident columns on the compute stream.
+int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base_seq, int which)
+{
+    if (n == 0) return KTA_OK;
+    ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = -1.f;
+    if (which & 1) {
+        if (!c->partition || !c->key_len || !c->val_len || !c->ts_ms)
+            return fail(ctx, KTA_ERR_INVALID, "metric columns missing");
+        if (!aligned16(c->partition) || !aligned16(c->key_len) || !aligned16(c->val_len) ||
+            !aligned16(c->ts_ms))
+            return fail(ctx, KTA_ERR_INVALID, "device columns must be 16-byte aligned");
+        kta::ScanColumns sc{c->partition, c->key_len, c->val_len, c->ts_ms};
+        kta::ScanPlan pl = kta::plan_scan(ctx->P, n, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant);
+        if (pl.workgroups > ctx->max_rows) pl.workgroups = ctx->max_rows;
+        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[0], ctx->s_compute));
+        KTA_HIP(ctx, kta::launch_metrics_scan(pl, sc, n, ctx->P, ctx->d_partials, ctx->s_compute));
+        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[1], ctx->s_compute));
+        KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.workgroups, ctx->P, ctx->d_vec,
+                                               ctx->s_compute));
+        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[2], ctx->s_compute));
+    }
+    if ((which & 2) && ctx->alive) {
+        if (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes)
+            return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
+        kta::AliveColumns ac{c->key_len, c->val_len, c->key_off, c->key_bytes, c->seq};
+        hipEvent_t a = ctx->ev_t[2], b = ctx->ev_t[3];
+        if (ctx->timing && !(which & 1)) KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
+        KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
+                                              ctx->alive_variant, ctx->s_compute));
+        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
+    }
+    if (ctx->timing) {
+        KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+        if (which & 1) {
+            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[0], ctx->ev_t[0], ctx->ev_t[1]));
+            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[1], ctx->ev_t[1], ctx->ev_t[2]));
+        }
+        if ((which & 2) && ctx->alive)
+            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[2], ctx->ev_t[2], ctx->ev_t[3]));
+    }
+    return KTA_OK;
+}
+
+int reset_state(kta_ctx *ctx)
+{
+    KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->s_compute));
+    if (ctx->alive)
+        KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
+    ctx->next_seq = 0;
+    return KTA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int kta_abi_version(void) { return KTA_ABI_VERSION; }
+
+const char *kta_last_error(const kta_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int kta_create(const kta_config *cfg, kta_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, KTA_ERR_INVALID, "kta_create: null argument");
+    *out = nullptr;
+    if (cfg->n_partitions <= 0 || cfg->n_partitions > 4096)
+        return fail(nullptr, KTA_ERR_INVALID, "n_partitions must be in [1, 4096]");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, KTA_ERR_NO_DEVICE, "no HIP device visible (libkta_hip has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(nullptr, KTA_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device_id);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, KTA_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", libkta_hip is built for gfx950 only");
+    e = hipSetDevice(cfg->device_id);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+
+    kta_ctx *ctx = new (std::nothrow) kta_ctx();
+    if (!ctx) return fail(nullptr, KTA_ERR_NOMEM, "out of host memory");
+    ctx->device = cfg->device_id;
+    ctx->P = (uint32_t)cfg->n_partitions;
+    ctx->alive = cfg->count_alive_keys != 0;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->batch_capacity = cfg->batch_capacity ? cfg->batch_capacity : (1ull << 22);
+    ctx->key_bytes_capacity = cfg->key_bytes_capacity ? cfg->key_bytes_capacity : 64ull * ctx->batch_capacity;
+    int rc = KTA_OK;
+    auto bail = [&](int code) {
+        g_create_error = ctx->err;
+        kta_destroy(ctx);
+        return code;
+    };
+    if (ctx->key_bytes_capacity >= (1ull << 32)) {
+        ctx->err = "key_bytes_capacity must be < 4 GiB (key_off is a batch-local u32)";
+        return bail(KTA_ERR_INVALID);
+    }
+#define KTA_TRY(call)                                                     \
+    do {                                                                  \
+        hipError_t e__ = (call);                                          \
+        if (e__ != hipSuccess) return bail(hip_fail(ctx, e__, #call));    \
+    } while (0)
+    KTA_TRY(hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
+    KTA_TRY(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    KTA_TRY(hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming));
+    for (auto &ev : ctx->ev_t) KTA_TRY(hipEventCreate(&ev));
+    const size_t vec_words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
+    KTA_TRY(hipMalloc((void **)&ctx->d_vec, vec_words * sizeof(uint64_t)));
+    ctx->max_rows = (uint32_t)ctx->cu_count * 8u;
+    KTA_TRY(hipMalloc((void **)&ctx->d_partials,
+                      (size_t)ctx->max_rows * kta::scan_row_len(ctx->P) * sizeof(uint64_t)));
+    if (ctx->alive) KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+#undef KTA_TRY
+    rc = reset_state(ctx);
+    if (rc != KTA_OK) return bail(rc);
+    // staging ring is allocated lazily (first kta_batch_acquire / kta_handle_message)
+    ctx->stages.resize(cfg->n_staging > 0 ? (size_t)cfg->n_staging : 2);
+    *out = ctx;
+    return KTA_OK;
+}
+
+void kta_destroy(kta_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->s_compute) (void)hipStreamSynchronize(ctx->s_compute);
+    if (ctx->s_copy) (void)hipStreamSynchronize(ctx->s_copy);
+    for (auto &st : ctx->stages) {
+        free_host_batch(&st.host);
+        free_device_batch(&st.dev);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
+    if (ctx->d_vec) (void)hipFree(ctx->d_vec);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
+    for (auto &ev : ctx->ev_t)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
+    if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+    delete ctx;
+}
+
+int kta_reset(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->fill_n = ctx->fill_kb = 0;
+    return reset_state(ctx);
+}
+
+static int ensure_stage(kta_ctx *ctx, Stage &st)
+{
+    if (st.host.partition) return KTA_OK;
+    int rc = alloc_host_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, &st.host);
+    if (rc != KTA_OK) return rc;
+    rc = alloc_device_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, false, &st.dev);
+    if (rc != KTA_OK) return rc;
+    KTA_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    return KTA_OK;
+}
+
+int kta_batch_acquire(kta_ctx *ctx, kta_batch *out)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage &st = ctx->stages[ctx->cur];
+    int rc = ensure_stage(ctx, st);
+    if (rc != KTA_OK) return rc;
+    if (st.busy) { // the ring wrapped: wait until the kernels that read this stage are done
+        KTA_HIP(ctx, hipEventSynchronize(st.done));
+        st.busy = false;
+    }
+    *out = st.host;
+    ctx->acquired = true;
+    return KTA_OK;
+}
+
+int kta_batch_submit(kta_ctx *ctx, uint64_t n, uint64_t n_key_bytes, uint64_t base_seq)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (!ctx->acquired) return fail(ctx, KTA_ERR_INVALID, "kta_batch_submit without kta_batch_acquire");
+    if (n > ctx->batch_capacity || (ctx->alive && n_key_bytes > ctx->key_bytes_capacity))
+        return fail(ctx, KTA_ERR_CAPACITY, "batch larger than the staging capacity");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage &st = ctx->stages[ctx->cur];
+    ctx->acquired = false;
+    if (n == 0) return KTA_OK;
+    hipStream_t cs = ctx->s_copy;
+    KTA_HIP(ctx, hipMemcpyAsync(st.dev.partition, st.host.partition, n * 4, hipMemcpyHostToDevice, cs));
+    KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_len, st.host.key_len, n * 4, hipMemcpyHostToDevice, cs));
+    KTA_HIP(ctx, hipMemcpyAsync(st.dev.val_len, st.host.val_len, n * 4, hipMemcpyHostToDevice, cs));
+    KTA_HIP(ctx, hipMemcpyAsync(st.dev.ts_ms, st.host.ts_ms, n * 8, hipMemcpyHostToDevice, cs));
+    if (ctx->alive) {
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_off, st.host.key_off, n * 4, hipMemcpyHostToDevice, cs));
+        if (n_key_bytes)
+            KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_bytes, st.host.key_bytes, n_key_bytes,
+                                        hipMemcpyHostToDevice, cs));
+    }
+    KTA_HIP(ctx, hipEventRecord(ctx->ev_copied, cs));
+    KTA_HIP(ctx, hipStreamWaitEvent(ctx->s_compute, ctx->ev_copied, 0));
+    int rc = run_device_batch(ctx, &st.dev, n, base_seq, 3);
+    if (rc != KTA_OK) return rc;
+    KTA_HIP(ctx, hipEventRecord(st.done, ctx->s_compute));
+    st.busy = true;
+    ctx->cur = (ctx->cur + 1) % (int)ctx->stages.size();
+    return KTA_OK;
+}
+
+int kta_flush(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (ctx->fill_n == 0) return KTA_OK;
+    const uint64_t n = ctx->fill_n, kb = ctx->fill_kb;
+    const uint64_t base = ctx->next_seq;
+    ctx->fill_n = ctx->fill_kb = 0;
+    ctx->next_seq += n;
+    return kta_batch_submit(ctx, n, kb, base);
+}
+
+int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const void *key, int64_t key_len,
+                       int64_t val_len)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (key_len > INT32_MAX || val_len > INT32_MAX)
+        return fail(ctx, KTA_ERR_INVALID, "key/value length above i32 range");
+    if (!key) key_len = -1; // m.key() is None iff librdkafka's key pointer is null
+    const uint64_t kb = (ctx->alive && key_len > 0) ? (uint64_t)key_len : 0;
+    if (kb > ctx->key_bytes_capacity) return fail(ctx, KTA_ERR_CAPACITY, "key larger than key_bytes_capacity");
+    if (ctx->fill_n > 0 && (ctx->fill_n == ctx->batch_capacity || ctx->fill_kb + kb > ctx->key_bytes_capacity)) {
+        int rc = kta_flush(ctx);
+        if (rc != KTA_OK) return rc;
+    }
+    if (ctx->fill_n == 0) {
+        kta_batch tmp;
+        int rc = kta_batch_acquire(ctx, &tmp);
+        if (rc != KTA_OK) return rc;
+    }
+    kta_batch &h = ctx->stages[ctx->cur].host;
+    const uint64_t i = ctx->fill_n;
+    h.partition[i] = partition;
+    h.ts_ms[i] = ts_ms;
+    h.key_len[i] = key_len < 0 ? -1 : (int32_t)key_len;
+    h.val_len[i] = val_len < 0 ? -1 : (int32_t)val_len;
+    if (ctx->alive) {
+        h.key_off[i] = (uint32_t)ctx->fill_kb;
+        if (kb) {
+            memcpy(h.key_bytes + ctx->fill_kb, key, kb);
+            ctx->fill_kb += kb;
+        }
+    }
+    ctx->fill_n = i + 1;
+    return KTA_OK;
+}
+
+int kta_submit_device_ex(kta_ctx *ctx, const kta_batch *cols, uint64_t n, uint64_t base_seq, int which)
+{
+    if (!ctx || !cols) return KTA_ERR_INVALID;
+    if (which < 1 || which > 3) return fail(ctx, KTA_ERR_INVALID, "which must be 1, 2 or 3");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    return run_device_batch(ctx, cols, n, base_seq, which);
+}
+
+int kta_submit_device(kta_ctx *ctx, const kta_batch *cols, uint64_t n, uint64_t base_seq)
+{
+    return kta_submit_device_ex(ctx, cols, n, base_seq, 3);
+}
+
+int kta_device_batch_alloc(kta_ctx *ctx, uint64_t capacity, uint64_t key_bytes_capacity, int with_seq,
+                           kta_batch *out)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    if (key_bytes_capacity >= (1ull << 32))
+        return fail(ctx, KTA_ERR_INVALID, "key_bytes_capacity must be < 4 GiB per batch");
+    int rc = alloc_device_batch(ctx, capacity, key_bytes_capacity, key_bytes_capacity > 0, with_seq != 0, out);
+    if (rc != KTA_OK) free_device_batch(out);
+    return rc;
+}
+
+int kta_device_batch_free(kta_ctx *ctx, kta_batch *cols)
+{
+    if (!ctx || !cols) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    free_device_batch(cols);
+    return KTA_OK;
+}
+
+int kta_copy_to_device(kta_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    KTA_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return KTA_OK;
+}
+
+int kta_copy_to_host(kta_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    KTA_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return KTA_OK;
+}
+
+int kta_sync(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_copy));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    return KTA_OK;
+}
+
+int kta_finish_device(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    if (ctx->alive)
+        KTA_HIP(ctx, kta::launch_alive_count(ctx->d_table, kta::kAliveSlots,
+                                             ctx->d_vec + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS,
+                                             ctx->s_compute));
+    return KTA_OK;
+}
+
+int kta_result_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
+{
+    if (!ctx || !device_ptr || !n_u64) return KTA_ERR_INVALID;
+    *device_ptr = ctx->d_vec;
+    *n_u64 = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
+    return KTA_OK;
+}
+
+int kta_decode_vector(const uint64_t *vec, uint32_t P, int count_alive_keys, kta_result *out,
+                      uint64_t *counters_out)
+{
+    if (!vec || !out || P == 0) return KTA_ERR_INVALID;
+    const uint64_t *g = vec + (size_t)P * KTA_NCOUNTERS;
+    memset(out, 0, sizeof(*out));
+    out->n_partitions = P;
+    uint64_t total = 0, live = 0, size = 0;
+    for (uint32_t p = 0; p < P; p++) {
+        const uint64_t *c = vec + (size_t)p * KTA_NCOUNTERS;
+        total += c[KTA_C_TOTAL];
+        live += c[KTA_C_ALIVE];
+        size += c[KTA_C_KEY_SIZE_SUM] + c[KTA_C_VALUE_SIZE_SUM];
+    }
+    if (counters_out) memcpy(counters_out, vec, (size_t)P * KTA_NCOUNTERS * sizeof(uint64_t));
+    out->any_records = total > 0;
+    out->any_live = live > 0;
+    out->count_alive_keys = count_alive_keys ? 1u : 0u;
+    // metric.rs:210: timestamp / 1000 truncates toward zero, and is monotone, so applying it
+    // to the extrema of the millisecond values equals the extrema of the per-record seconds.
+    out->min_ts_sec = out->any_records ? (int64_t)g[KTA_G_MIN_TS_MS] / 1000 : 0;
+    out->max_ts_sec = out->any_records ? (int64_t)g[KTA_G_MAX_TS_MS] / 1000 : 0;
+    out->smallest_message = out->any_live ? g[KTA_G_SMALLEST] : UINT64_MAX; // metric.rs:42
+    out->largest_message = g[KTA_G_LARGEST];
+    out->overall_count = total;
+    out->overall_size = size;
+    out->alive_keys = count_alive_keys ? g[KTA_G_ALIVE_KEYS] : 0;
+    out->bad_partition_records = g[KTA_G_BAD_PARTITION];
+    return out->bad_partition_records ? KTA_ERR_BAD_PARTITION : KTA_OK;
+}
+
+int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t P)
+{
+    if (!acc || !other || P == 0) return KTA_ERR_INVALID;
+    const size_t nc = (size_t)P * KTA_NCOUNTERS;
+    for (size_t i = 0; i < nc; i++) acc[i] += other[i];
+    uint64_t *g = acc + nc;
+    const uint64_t *h = other + nc;
+    if ((int64_t)h[KTA_G_MIN_TS_MS] < (int64_t)g[KTA_G_MIN_TS_MS]) g[KTA_G_MIN_TS_MS] = h[KTA_G_MIN_TS_MS];
+    if ((int64_t)h[KTA_G_MAX_TS_MS] > (int64_t)g[KTA_G_MAX_TS_MS]) g[KTA_G_MAX_TS_MS] = h[KTA_G_MAX_TS_MS];
+    if ((int64_t)h[KTA_G_SMALLEST] < (int64_t)g[KTA_G_SMALLEST]) g[KTA_G_SMALLEST] = h[KTA_G_SMALLEST];
+    if ((int64_t)h[KTA_G_LARGEST] > (int64_t)g[KTA_G_LARGEST]) g[KTA_G_LARGEST] = h[KTA_G_LARGEST];
+    g[KTA_G_BAD_PARTITION] += h[KTA_G_BAD_PARTITION];
+    g[KTA_G_ALIVE_KEYS] += h[KTA_G_ALIVE_KEYS];
+    g[KTA_G_RECORDS] += h[KTA_G_RECORDS];
+    return KTA_OK;
+}
+
+int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    int rc = kta_finish_device(ctx);
+    if (rc != KTA_OK) return rc;
+    const size_t words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
+    std::vector<uint64_t> host(words);
+    KTA_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                ctx->s_compute));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    rc = kta_decode_vector(host.data(), ctx->P, ctx->alive ? 1 : 0, out, counters_out);
+    if (rc == KTA_ERR_BAD_PARTITION) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "%llu record(s) had a partition id outside [0, %u)",
+                 (unsigned long long)out->bad_partition_records, ctx->P);
+        ctx->err = buf;
+    }
+    return rc;
+}
+
+int kta_export_alive_bitmap(kta_ctx *ctx, void *dst)
+{
+    if (!ctx || !dst) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    uint32_t *d_bm = nullptr;
+    const size_t bytes = (size_t)(kta::kAliveSlots / 8);
+    KTA_HIP(ctx, hipMalloc((void **)&d_bm, bytes));
+    hipError_t e = kta::launch_alive_bitmap(ctx->d_table, kta::kAliveSlots, d_bm, ctx->s_compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_bm, bytes, hipMemcpyDeviceToHost, ctx->s_compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_compute);
+    (void)hipFree(d_bm);
+    if (e != hipSuccess) return hip_fail(ctx, e, "alive bitmap export");
+    return KTA_OK;
+}
+
+int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
+{
+    if (!ctx || !device_ptr || !n_u64) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    *device_ptr = ctx->d_table;
+    *n_u64 = (size_t)kta::kAliveSlots;
+    return KTA_OK;
+}
+
+int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes, const uint32_t *key_off, const int32_t *key_len,
+                     uint64_t n, uint64_t n_key_bytes, uint32_t *hash_out)
+{
+    if (!ctx || !key_off || !key_len || !hash_out) return KTA_ERR_INVALID;
+    if (n == 0) return KTA_OK;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_kb = nullptr;
+    uint32_t *d_off = nullptr, *d_out = nullptr;
+    int32_t *d_len = nullptr;
+    hipError_t e = hipMalloc((void **)&d_kb, pad16(n_key_bytes + 16));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_len, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 4);
+    hipStream_t s = ctx->s_compute;
+    if (e == hipSuccess && n_key_bytes) e = hipMemcpyAsync(d_kb, key_bytes, n_key_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, key_off, n * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_len, key_len, n * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = kta::launch_fnv32(d_kb, d_off, d_len, n, d_out, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(hash_out, d_out, n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_kb) (void)hipFree(d_kb);
+    if (d_off) (void)hipFree(d_off);
+    if (d_len) (void)hipFree(d_len);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(ctx, e, "kta_fnv32_device");
+    return KTA_OK;
+}
+
+int kta_set_timing(kta_ctx *ctx, int enable)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    ctx->timing = enable != 0;
+    return KTA_OK;
+}
+
+int kta_last_kernel_ms(kta_ctx *ctx, float out_ms[3])
+{
+    if (!ctx || !out_ms) return KTA_ERR_INVALID;
+    for (int i = 0; i < 3; i++) out_ms[i] = ctx->last_ms[i];
+    return KTA_OK;
+}
+
+int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups, int alive_variant)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (scan_workgroups < 0 || alive_workgroups < 0) return fail(ctx, KTA_ERR_INVALID, "negative workgroup count");
+    ctx->scan_wgs = scan_workgroups;
+    ctx->scan_variant = scan_variant;
+    ctx->alive_wgs = alive_workgroups;
+    ctx->alive_variant = alive_variant;
+    return KTA_OK;
+}
+
+} // extern "C"
+
+// exported for kta_synth.hip (same shared object)
+hipStream_t kta_internal_stream(kta_ctx *ctx) { return ctx->s_compute; }
+int kta_internal_device(kta_ctx *ctx) { return ctx->device; }
+void kta_internal_set_error(kta_ctx *ctx, const char *msg) { ctx->err = msg; }

@@ -1,0 +1,67 @@
+// kta_kernels.h — internal launch interface between the C-ABI layer (kta_api.hip) and the
+// gfx950 kernels (kta_kernels.hip).  Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kta {
+
+constexpr int kWG = 256;                    // threads per workgroup (4 wave64)
+constexpr uint32_t kScanCols = 5;           // per-partition partial columns written by the scan:
+                                            //   count, tombstones, key_null, key_size_sum, value_size_sum
+constexpr uint32_t kScanGlobals = 8;        // per-workgroup partial globals (see ScanGlobal)
+constexpr uint64_t kAliveSlots = 1ull << 32; // the reference hashes into a usize from a u32 (metric.rs:259)
+
+enum ScanGlobal : uint32_t {
+    SG_TMIN = 0, SG_TMAX = 1, SG_SMIN = 2, SG_SMAX = 3, SG_BAD = 4, SG_NREC = 5
+};
+
+struct ScanColumns {
+    const int32_t *partition;
+    const int32_t *key_len;
+    const int32_t *val_len;
+    const int64_t *ts_ms;
+};
+
+struct AliveColumns {
+    const int32_t *key_len;
+    const int32_t *val_len;
+    const uint32_t *key_off;
+    const uint8_t *key_bytes;
+    const uint64_t *seq; // may be null
+};
+
+struct ScanPlan {
+    uint32_t workgroups;   // grid size
+    uint32_t rep_log2;     // LDS replication of each partition's slots
+    uint32_t lds_bytes;    // dynamic LDS per workgroup
+    uint32_t variant;      // 0 = three 64-bit LDS atomics/record, 1 = packed (two), 9 = loads only (diagnostic)
+};
+
+// u64 words one workgroup writes into the partial workspace
+inline uint32_t scan_row_len(uint32_t P) { return P * kScanCols + kScanGlobals; }
+
+ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant);
+
+// K1: per-record metric accumulation (metric.rs:207-252) over one struct-of-arrays batch.
+hipError_t launch_metrics_scan(const ScanPlan &plan, const ScanColumns &c, uint64_t n, uint32_t P,
+                               uint64_t *partials, hipStream_t s);
+// K5: fold the per-workgroup partial rows into the persistent counter vector.
+hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_t P, uint64_t *vec,
+                                hipStream_t s);
+// reset the counter vector to the MessageMetrics::new state (metric.rs:30-46)
+hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s);
+
+// K2+K3: FNV (fnv32.rs:92-101) + last-writer-wins table update (metric.rs:289-304)
+hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
+                               int workgroups, int variant, hipStream_t s);
+// K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
+hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
+// table -> 2^32-bit bitmap (u32 words)
+hipError_t launch_alive_bitmap(const uint64_t *table, uint64_t n_slots, uint32_t *bitmap, hipStream_t s);
+// hash only (tests)
+hipError_t launch_fnv32(const uint8_t *key_bytes, const uint32_t *key_off, const int32_t *key_len,
+                        uint64_t n, uint32_t *out, hipStream_t s);
+
+} // namespace kta

@@ -1,0 +1,560 @@
+// kta_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels for the per-record
+// metric-accumulation hot path of kafka-topic-analyzer.  Integer/byte work, HBM-bound:
+// no MFMA.  wave = 64 lanes, 256-thread workgroups, 16 B/lane coalesced loads,
+// LDS-staged per-workgroup partial counters, deterministic integer reductions.
+//
+// Reference semantics (paths under /root/reference):
+//   kta_metrics_scan   src/metric.rs:207-252  MessageMetrics::handle_message
+//   kta_alive_update   src/metric.rs:289-304  LogCompactionInMemoryMetrics::handle_message
+//                      src/metric.rs:256-260  fnv1a        src/fnv32.rs:92-101  FnvHasher::write
+//   kta_alive_count    src/metric.rs:282-284  sum_all_alive
+#include "kta_kernels.h"
+
+#include <limits.h>
+
+namespace kta {
+
+// ---------------------------------------------------------------------------------------
+// K1  metrics scan
+// ---------------------------------------------------------------------------------------
+//
+// Input: four columns, 20 B/record (partition i32, key_len i32, val_len i32, ts_ms i64).
+// Each lane owns 4 consecutive records per tile (one int4 from each i32 column, two
+// longlong2 from the timestamp column: 5 x 16 B loads, fully coalesced: a wave reads
+// 3 x 1 KiB + 2 KiB contiguous).  A tile is 256 lanes x 4 records; tiles are dealt
+// round-robin to workgroups, and the next tile's loads are issued before the current
+// tile is accumulated (register double buffer) to keep HBM requests in flight.
+//
+// Accumulation: per-partition partial counters live in LDS, replicated 2^rep_log2 times
+// (replica = lane & (R-1)) so records of one partition that sit in the same wave do not
+// serialise on one LDS address (a Kafka consumer delivers per-partition runs, and small
+// P is common).  Three non-returning 64-bit LDS atomics per record:
+//     A += 1 | tombstone << 21 | key_null << 42      (three 21-bit counts in one word)
+//     K += key_len (Some)      V += val_len (Some)
+// or, in the packed variant, two when every lane's sizes fit 13 bits (wave-uniform test):
+//     B += key_len | val_len << 32
+// LDS partials are flushed to this workgroup's row of the partial workspace every 2^18
+// records (so the packed fields cannot overflow) and at the end; a second tiny kernel
+// folds the rows.  No floating point anywhere; integer adds commute, so results are
+// independent of scheduling.
+//
+// Globals: min/max of ts_ms (-1 => 0 first, metric.rs:209) — the division by 1000
+// (metric.rs:210) is monotone, so it is applied once to the extrema on the host — and
+// min/max of key+value size over non-tombstones (metric.rs:249-251), both carried in
+// registers and reduced with wave shuffles at the end.
+
+constexpr uint32_t kCntBits = 21;
+constexpr uint64_t kCntMask = (1ull << kCntBits) - 1;
+constexpr uint32_t kFlushTiles = 256;          // 256 tiles x 1024 records = 2^18 records
+constexpr uint32_t kPackedSizeLimit = 1u << 13; // 2^18 records x 2^13 B < 2^32
+
+struct Quad {
+    int4 p, k, v;
+    longlong2 t0, t1;
+};
+
+__device__ __forceinline__ void load_quad(Quad &q, const ScanColumns &c, uint64_t qi)
+{
+    q.p = reinterpret_cast<const int4 *>(c.partition)[qi];
+    q.k = reinterpret_cast<const int4 *>(c.key_len)[qi];
+    q.v = reinterpret_cast<const int4 *>(c.val_len)[qi];
+    q.t0 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi];
+    q.t1 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi + 1];
+}
+
+struct LaneState {
+    long long tmin, tmax;
+    uint32_t smin, smax;
+    uint32_t bad;
+};
+
+template <int VARIANT>
+__device__ __forceinline__ void accumulate(uint32_t part, int32_t kl, int32_t vl, long long ts,
+                                           uint32_t P, uint32_t rep_log2, uint32_t rep,
+                                           unsigned long long *sA, unsigned long long *sK,
+                                           unsigned long long *sV, unsigned long long *sB,
+                                           LaneState &st, bool valid)
+{
+    const bool ok = valid && (part < P); // unsigned compare also rejects negative ids
+    const uint32_t tomb = (uint32_t)vl >> 31;  // payload None  (metric.rs:241-244)
+    const uint32_t knull = (uint32_t)kl >> 31; // key None      (metric.rs:227-230)
+    const uint32_t ks = knull ? 0u : (uint32_t)kl;
+    const uint32_t vs = tomb ? 0u : (uint32_t)vl;
+    st.bad += (valid && !ok) ? 1u : 0u;
+    if (VARIANT == 9) { // diagnostic: loads + register work only
+        if (ok) {
+            const long long t = (ts == -1ll) ? 0ll : ts;
+            st.tmin = t < st.tmin ? t : st.tmin;
+            st.tmax = t > st.tmax ? t : st.tmax;
+            st.smax = max(st.smax, ks + vs + part);
+        }
+        return;
+    }
+    const uint32_t slot = (part << rep_log2) | rep;
+    const unsigned long long a = 1ull | ((unsigned long long)tomb << kCntBits) |
+                                 ((unsigned long long)knull << (2 * kCntBits));
+    if (VARIANT == 1) {
+        // wave-uniform choice: all active lanes small -> one packed add for both sizes
+        const bool small = (ks | vs) < kPackedSizeLimit;
+        if (__all(small || !ok)) {
+            if (ok) {
+                atomicAdd(&sA[slot], a);
+                atomicAdd(&sB[slot], (unsigned long long)ks | ((unsigned long long)vs << 32));
+            }
+        } else if (ok) {
+            atomicAdd(&sA[slot], a);
+            atomicAdd(&sK[slot], (unsigned long long)ks);
+            atomicAdd(&sV[slot], (unsigned long long)vs);
+        }
+    } else if (ok) {
+        atomicAdd(&sA[slot], a);
+        atomicAdd(&sK[slot], (unsigned long long)ks);
+        atomicAdd(&sV[slot], (unsigned long long)vs);
+    }
+    if (ok) {
+        const long long t = (ts == -1ll) ? 0ll : ts; // to_millis() None -> unwrap_or(0)
+        st.tmin = t < st.tmin ? t : st.tmin;          // metric.rs:65-72
+        st.tmax = t > st.tmax ? t : st.tmax;
+        if (!tomb) {                                  // metric.rs:249-251
+            const uint32_t sz = ks + vs;              // < 2^32: both < 2^31
+            st.smin = min(st.smin, sz);               // metric.rs:56-63
+            st.smax = max(st.smax, sz);
+        }
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t n, uint32_t P,
+                                                        uint32_t rep_log2,
+                                                        uint64_t *__restrict__ partials)
+{
+    extern __shared__ unsigned long long lds[];
+    __shared__ long long s_red[kWG / 64][6];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slots = P << rep_log2;
+    const uint32_t n_arrays = (VARIANT == 1) ? 4u : 3u;
+    unsigned long long *sA = lds;
+    unsigned long long *sK = lds + slots;
+    unsigned long long *sV = lds + 2 * slots;
+    unsigned long long *sB = lds + 3 * slots; // VARIANT 1 only
+
+    for (uint32_t i = tid; i < n_arrays * slots; i += kWG) lds[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t rep = tid & ((1u << rep_log2) - 1u);
+    LaneState st;
+    st.tmin = LLONG_MAX;
+    st.tmax = LLONG_MIN;
+    st.smin = 0xFFFFFFFFu; // never a real size (max real size is 2^32-2)
+    st.smax = 0u;
+    st.bad = 0u;
+
+    uint64_t *row = partials + (uint64_t)blockIdx.x * (P * kScanCols + kScanGlobals);
+    bool first_flush = true;
+
+    auto flush = [&]() {
+        __syncthreads();
+        for (uint32_t p = tid; p < P; p += kWG) {
+            unsigned long long a = 0, k = 0, v = 0, b = 0;
+            for (uint32_t r = 0; r < (1u << rep_log2); r++) {
+                const uint32_t s = (p << rep_log2) | r;
+                a += sA[s];
+                k += sK[s];
+                v += sV[s];
+                sA[s] = 0ull;
+                sK[s] = 0ull;
+                sV[s] = 0ull;
+                if (VARIANT == 1) {
+                    b += sB[s];
+                    sB[s] = 0ull;
+                }
+            }
+            if (VARIANT == 1) {
+                k += b & 0xFFFFFFFFull;
+                v += b >> 32;
+            }
+            uint64_t *o = row + (uint64_t)p * kScanCols;
+            const uint64_t c0 = a & kCntMask, c1 = (a >> kCntBits) & kCntMask,
+                           c2 = (a >> (2 * kCntBits)) & kCntMask;
+            if (first_flush) {
+                o[0] = c0; o[1] = c1; o[2] = c2; o[3] = k; o[4] = v;
+            } else {
+                o[0] += c0; o[1] += c1; o[2] += c2; o[3] += k; o[4] += v;
+            }
+        }
+        first_flush = false;
+        __syncthreads();
+    };
+
+    const uint64_t nquads = n >> 2;
+    const uint64_t ntiles = (nquads + kWG - 1) / kWG;
+    uint64_t tile = blockIdx.x;
+    uint32_t since_flush = 0;
+
+    Quad cur, nxt;
+    uint64_t qi = tile * kWG + tid;
+    bool cur_valid = (tile < ntiles) && (qi < nquads);
+    if (cur_valid) load_quad(cur, c, qi);
+
+    while (tile < ntiles) { // uniform per workgroup
+        const uint64_t ntile = tile + gridDim.x;
+        const uint64_t nqi = ntile * kWG + tid;
+        const bool nxt_valid = (ntile < ntiles) && (nqi < nquads);
+        if (nxt_valid) load_quad(nxt, c, nqi);
+
+        accumulate<VARIANT>((uint32_t)cur.p.x, cur.k.x, cur.v.x, cur.t0.x, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
+        accumulate<VARIANT>((uint32_t)cur.p.y, cur.k.y, cur.v.y, cur.t0.y, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
+        accumulate<VARIANT>((uint32_t)cur.p.z, cur.k.z, cur.v.z, cur.t1.x, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
+        accumulate<VARIANT>((uint32_t)cur.p.w, cur.k.w, cur.v.w, cur.t1.y, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
+
+        if (++since_flush == kFlushTiles) {
+            flush();
+            since_flush = 0;
+        }
+        cur = nxt;
+        cur_valid = nxt_valid;
+        tile = ntile;
+    }
+
+    // tail: the last n % 4 records, scalar, by the first lanes of workgroup 0
+    if (blockIdx.x == 0) {
+        const uint64_t i = (nquads << 2) + tid;
+        const bool v = (tid < 3) && (i < n);
+        const uint64_t ii = v ? i : 0;
+        // (lanes of one wave must all enter accumulate<1> because of its __all())
+        if (tid < 64) {
+            uint32_t p = 0; int32_t kl = 0, vl = 0; long long ts = 0;
+            if (v) { p = (uint32_t)c.partition[ii]; kl = c.key_len[ii]; vl = c.val_len[ii]; ts = c.ts_ms[ii]; }
+            accumulate<VARIANT>(p, kl, vl, ts, P, rep_log2, rep, sA, sK, sV, sB, st, v);
+        }
+    }
+
+    flush();
+
+    // per-workgroup extrema: wave shuffle tree, then 4 waves through LDS
+    long long tmin = st.tmin, tmax = st.tmax;
+    long long smin = (long long)st.smin, smax = (long long)st.smax, bad = (long long)st.bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long a = __shfl_xor(tmin, off), b = __shfl_xor(tmax, off);
+        const long long cmin = __shfl_xor(smin, off), cmax = __shfl_xor(smax, off);
+        const long long d = __shfl_xor(bad, off);
+        tmin = a < tmin ? a : tmin;
+        tmax = b > tmax ? b : tmax;
+        smin = cmin < smin ? cmin : smin;
+        smax = cmax > smax ? cmax : smax;
+        bad += d;
+    }
+    const uint32_t wave = tid >> 6;
+    if ((tid & 63u) == 0u) {
+        s_red[wave][0] = tmin; s_red[wave][1] = tmax; s_red[wave][2] = smin;
+        s_red[wave][3] = smax; s_red[wave][4] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t w = 1; w < kWG / 64; w++) {
+            tmin = s_red[w][0] < tmin ? s_red[w][0] : tmin;
+            tmax = s_red[w][1] > tmax ? s_red[w][1] : tmax;
+            smin = s_red[w][2] < smin ? s_red[w][2] : smin;
+            smax = s_red[w][3] > smax ? s_red[w][3] : smax;
+            bad += s_red[w][4];
+        }
+        uint64_t *g = row + (uint64_t)P * kScanCols;
+        g[SG_TMIN] = (uint64_t)tmin;
+        g[SG_TMAX] = (uint64_t)tmax;
+        g[SG_SMIN] = (smin == 0xFFFFFFFFll) ? (uint64_t)LLONG_MAX : (uint64_t)smin;
+        g[SG_SMAX] = (uint64_t)smax;
+        g[SG_BAD] = (uint64_t)bad;
+        g[SG_NREC] = 0;
+        g[6] = 0;
+        g[7] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5  fold partial rows into the persistent counter vector
+// ---------------------------------------------------------------------------------------
+// Layout of vec: u64[P*7] (reference field order) followed by KTA_NGLOBALS globals
+// (include/kta_hip.h).  grid = (column blocks, row slices); each thread sums one column of
+// the partial workspace over its row slice (consecutive threads read consecutive words), then
+// one device-scope integer atomic per (thread, output).  Integer atomics commute => exact.
+__global__ __launch_bounds__(kWG) void kta_fold_partials(const uint64_t *__restrict__ partials,
+                                                         uint32_t rows, uint32_t P,
+                                                         uint64_t *__restrict__ vec)
+{
+    const uint32_t row_len = P * kScanCols + kScanGlobals;
+    const uint32_t col = blockIdx.x * kWG + threadIdx.x;
+    if (col >= row_len) return;
+    const uint32_t r0 = (uint32_t)(((uint64_t)rows * blockIdx.y) / gridDim.y);
+    const uint32_t r1 = (uint32_t)(((uint64_t)rows * (blockIdx.y + 1)) / gridDim.y);
+    if (r0 == r1) return;
+    unsigned long long *v = reinterpret_cast<unsigned long long *>(vec);
+    unsigned long long *g = v + (uint64_t)P * 7;
+    if (col < P * kScanCols) {
+        const uint32_t p = col / kScanCols, f = col % kScanCols;
+        unsigned long long s = 0;
+        for (uint32_t r = r0; r < r1; r++) s += partials[(uint64_t)r * row_len + col];
+        if (s == 0) return;
+        unsigned long long *o = v + (uint64_t)p * 7;
+        switch (f) {
+        case 0: // record count: total += s, alive += s, key_non_null += s, records += s
+            atomicAdd(&o[0], s);
+            atomicAdd(&o[2], s);
+            atomicAdd(&o[4], s);
+            atomicAdd(&g[6], s);
+            break;
+        case 1: // tombstones: tombstones += s, alive -= s   (alive = total - tombstones)
+            atomicAdd(&o[1], s);
+            atomicAdd(&o[2], 0ull - s);
+            break;
+        case 2: // key None: key_null += s, key_non_null -= s
+            atomicAdd(&o[3], s);
+            atomicAdd(&o[4], 0ull - s);
+            break;
+        case 3: atomicAdd(&o[5], s); break; // key_size_sum
+        default: atomicAdd(&o[6], s); break; // value_size_sum
+        }
+    } else {
+        const uint32_t gi = col - P * kScanCols;
+        if (gi == SG_TMIN || gi == SG_SMIN) {
+            long long m = LLONG_MAX;
+            for (uint32_t r = r0; r < r1; r++) {
+                const long long x = (long long)partials[(uint64_t)r * row_len + col];
+                m = x < m ? x : m;
+            }
+            atomicMin(reinterpret_cast<long long *>(&g[gi == SG_TMIN ? 0 : 2]), m);
+        } else if (gi == SG_TMAX || gi == SG_SMAX) {
+            long long m = LLONG_MIN;
+            for (uint32_t r = r0; r < r1; r++) {
+                const long long x = (long long)partials[(uint64_t)r * row_len + col];
+                m = x > m ? x : m;
+            }
+            atomicMax(reinterpret_cast<long long *>(&g[gi == SG_TMAX ? 1 : 3]), m);
+        } else if (gi == SG_BAD) {
+            unsigned long long s = 0;
+            for (uint32_t r = r0; r < r1; r++) s += partials[(uint64_t)r * row_len + col];
+            if (s) atomicAdd(&g[4], s);
+        }
+    }
+}
+
+__global__ void kta_init_vector(uint64_t *vec, uint32_t P)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nc = P * 7;
+    if (i < nc) vec[i] = 0;
+    if (i == 0) {
+        uint64_t *g = vec + nc;
+        g[0] = (uint64_t)LLONG_MAX; // min ts: nothing seen
+        g[1] = (uint64_t)LLONG_MIN; // max ts
+        g[2] = (uint64_t)LLONG_MAX; // smallest: u64::MAX in the reference (metric.rs:42)
+        g[3] = 0;                   // largest (metric.rs:41)
+        g[4] = 0; g[5] = 0; g[6] = 0; g[7] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 + K3  FNV + last-writer-wins alive table
+// ---------------------------------------------------------------------------------------
+// fnv32.rs:92-101: h = 0x811c9dc5; for each byte: h ^= byte; h *= 0x811c9dc5 (wrapping).
+// The multiplier is the offset basis, not the FNV prime.
+
+constexpr uint32_t kFnvInit = 0x811c9dc5u;
+constexpr uint32_t kFnvMul = 0x811c9dc5u;
+
+__device__ __forceinline__ uint32_t fnv_step(uint32_t h, uint32_t byte) { return (h ^ byte) * kFnvMul; }
+
+// Hash `len` bytes starting at byte pointer k (any alignment) with aligned 4-byte loads.
+// Reads only whole dwords that overlap the key, so it may touch up to 3 bytes before and
+// after the key inside the same 4-byte words (the key blob is allocated padded to 16 B).
+__device__ __forceinline__ uint32_t fnv32_global(const uint8_t *k, uint32_t len)
+{
+    uint32_t h = kFnvInit;
+    if (len == 0) return h;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(k);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    uint32_t skip = (uint32_t)(a & 3u);
+    uint32_t word = *w++;
+    word >>= 8u * skip;
+    uint32_t avail = 4u - skip;
+    while (true) {
+        const uint32_t take = len < avail ? len : avail;
+        if (take == 4u) {
+            h = fnv_step(h, word & 0xFFu);
+            h = fnv_step(h, (word >> 8) & 0xFFu);
+            h = fnv_step(h, (word >> 16) & 0xFFu);
+            h = fnv_step(h, word >> 24);
+        } else {
+            for (uint32_t j = 0; j < take; j++) {
+                h = fnv_step(h, word & 0xFFu);
+                word >>= 8;
+            }
+        }
+        len -= take;
+        if (len == 0) break;
+        word = *w++;
+        avail = 4u;
+    }
+    return h;
+}
+
+// table[h] = max(table[h], ((seq+1) << 1) | alive): the entry with the largest sequence
+// number is the last writer in consumption order, which is exactly what sequential
+// BitSet insert/remove leaves behind (metric.rs:273-280, 291-303).  0 == never written.
+__global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t n, uint64_t base_seq,
+                                                        unsigned long long *__restrict__ table)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
+        const int32_t kl = c.key_len[i];
+        if (kl < 0) continue; // key None: ignored (metric.rs:302)
+        const uint32_t h = fnv32_global(c.key_bytes + c.key_off[i], (uint32_t)kl);
+        const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
+        const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
+        atomicMax(&table[h], v);
+    }
+}
+
+__global__ __launch_bounds__(kWG) void kta_fnv32(const uint8_t *key_bytes, const uint32_t *key_off,
+                                                 const int32_t *key_len, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    const int32_t kl = key_len[i];
+    out[i] = kl < 0 ? 0u : fnv32_global(key_bytes + key_off[i], (uint32_t)kl);
+}
+
+// K4: popcount of the alive bits.  16 B/lane streaming read of the u64 table.
+__global__ __launch_bounds__(kWG) void kta_alive_count(const ulonglong2 *__restrict__ table2,
+                                                       uint64_t n_pairs, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    unsigned long long cnt = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n_pairs; i += stride) {
+        const ulonglong2 e = table2[i];
+        cnt += (e.x & 1ull) + (e.y & 1ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+// table -> bitmap: one wave turns 64 consecutive entries into one u64 of bits via ballot.
+__global__ __launch_bounds__(kWG) void kta_alive_bitmap(const unsigned long long *__restrict__ table,
+                                                        uint64_t n_slots,
+                                                        unsigned long long *__restrict__ bitmap64)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n_slots; i += stride) {
+        const unsigned long long m = __ballot((table[i] & 1ull) != 0ull);
+        if ((threadIdx.x & 63u) == 0u) bitmap64[i >> 6] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------
+
+ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant)
+{
+    ScanPlan pl;
+    pl.variant = (req_variant == 1 || req_variant == 9) ? (uint32_t)req_variant : 0u;
+    const uint32_t arrays = pl.variant == 1 ? 4u : 3u;
+    // LDS budget per workgroup: 32 KiB keeps 5 workgroups (20 waves) per CU resident.
+    const uint32_t budget_slots = (32u * 1024u) / (8u * arrays);
+    uint32_t rep_log2 = 0;
+    while (rep_log2 < 6 && (P << (rep_log2 + 1)) <= budget_slots) rep_log2++;
+    pl.rep_log2 = rep_log2;
+    pl.lds_bytes = (P << rep_log2) * 8u * arrays;
+    const uint64_t ntiles = ((n >> 2) + kWG - 1) / kWG;
+    uint64_t wgs = req_workgroups > 0 ? (uint64_t)req_workgroups : (uint64_t)cu_count * 5u;
+    if (wgs > ntiles) wgs = ntiles;
+    if (wgs < 1) wgs = 1;
+    pl.workgroups = (uint32_t)wgs;
+    return pl;
+}
+
+hipError_t launch_metrics_scan(const ScanPlan &pl, const ScanColumns &c, uint64_t n, uint32_t P,
+                               uint64_t *partials, hipStream_t s)
+{
+    dim3 grid(pl.workgroups), block(kWG);
+    switch (pl.variant) {
+    case 1:
+        hipLaunchKernelGGL(kta_metrics_scan<1>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
+        break;
+    case 9:
+        hipLaunchKernelGGL(kta_metrics_scan<9>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
+        break;
+    default:
+        hipLaunchKernelGGL(kta_metrics_scan<0>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_t P, uint64_t *vec,
+                                hipStream_t s)
+{
+    const uint32_t row_len = P * kScanCols + kScanGlobals;
+    uint32_t slices = rows < 32 ? rows : 32;
+    dim3 grid((row_len + kWG - 1) / kWG, slices), block(kWG);
+    hipLaunchKernelGGL(kta_fold_partials, grid, block, 0, s, partials, rows, P, vec);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s)
+{
+    const uint32_t n = P * 7 + 1;
+    hipLaunchKernelGGL(kta_init_vector, dim3((n + 255) / 256), dim3(256), 0, s, vec, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
+                               int workgroups, int variant, hipStream_t s)
+{
+    (void)variant;
+    uint64_t wgs = (n + kWG - 1) / kWG;
+    const uint64_t cap = workgroups > 0 ? (uint64_t)workgroups : 256ull * 8ull;
+    if (wgs > cap) wgs = cap;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq,
+                       reinterpret_cast<unsigned long long *>(table));
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kta_alive_count, dim3(256 * 8), dim3(kWG), 0, s,
+                       reinterpret_cast<const ulonglong2 *>(table), n_slots / 2,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_bitmap(const uint64_t *table, uint64_t n_slots, uint32_t *bitmap, hipStream_t s)
+{
+    hipLaunchKernelGGL(kta_alive_bitmap, dim3(256 * 8), dim3(kWG), 0, s,
+                       reinterpret_cast<const unsigned long long *>(table), n_slots,
+                       reinterpret_cast<unsigned long long *>(bitmap));
+    return hipGetLastError();
+}
+
+hipError_t launch_fnv32(const uint8_t *key_bytes, const uint32_t *key_off, const int32_t *key_len,
+                        uint64_t n, uint32_t *out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kta_fnv32, dim3((uint32_t)((n + kWG - 1) / kWG)), dim3(kWG), 0, s, key_bytes,
+                       key_off, key_len, n, out);
+    return hipGetLastError();
+}
+
+} // namespace kta

@@ -1,0 +1,129 @@
+"""ctypes binding of the C oracle (oracle/libkta_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "libkta_oracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+        L = C.CDLL(path)
+        L.kto_fnv32.restype = C.c_uint32
+        L.kto_fnv32.argtypes = [C.c_char_p, C.c_size_t]
+        L.kto_metrics_new.restype = C.c_void_p
+        L.kto_metrics_new.argtypes = [C.c_int64, C.c_uint32]
+        L.kto_metrics_free.argtypes = [C.c_void_p]
+        L.kto_metrics_handle_message.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int64, C.c_int64]
+        for f in ("total", "tombstones", "alive", "key_null", "key_non_null", "key_size_sum", "value_size_sum"):
+            fn = getattr(L, "kto_" + f)
+            fn.restype = C.c_uint64
+            fn.argtypes = [C.c_void_p, C.c_int32]
+        for f in ("key_size_avg", "value_size_avg", "message_size_avg"):
+            fn = getattr(L, "kto_" + f)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
+        L.kto_dirty_ratio.restype = C.c_float
+        L.kto_dirty_ratio.argtypes = [C.c_void_p, C.c_int32]
+        for f in ("latest_message", "earliest_message"):
+            fn = getattr(L, "kto_" + f)
+            fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]
+        for f in ("smallest_message", "largest_message", "overall_count", "overall_size"):
+            fn = getattr(L, "kto_" + f)
+            fn.restype = C.c_uint64
+            fn.argtypes = [C.c_void_p]
+        L.kto_lc_new.restype = C.c_void_p
+        L.kto_lc_free.argtypes = [C.c_void_p]
+        L.kto_lc_handle_message.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64]
+        L.kto_lc_sum_all_alive.restype = C.c_uint64
+        L.kto_lc_sum_all_alive.argtypes = [C.c_void_p]
+        L.kto_lc_contains.restype = C.c_int
+        L.kto_lc_contains.argtypes = [C.c_void_p, C.c_uint32]
+        L.kto_lc_nbits.restype = C.c_uint64
+        L.kto_lc_nbits.argtypes = [C.c_void_p]
+        L.kto_lc_export_words.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.kto_run_soa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        L.kto_export_counters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def fnv32(b: bytes) -> int:
+    return lib().kto_fnv32(b, len(b))
+
+
+class Oracle:
+    """MessageMetrics (+ optional LogCompactionInMemoryMetrics) of the C oracle."""
+
+    def __init__(self, now=(4102444800, 123456789), count_alive_keys=False):
+        self.L = lib()
+        self.m = self.L.kto_metrics_new(now[0], now[1])
+        self.lc = self.L.kto_lc_new() if count_alive_keys else None
+
+    def close(self):
+        if self.m:
+            self.L.kto_metrics_free(self.m)
+            self.m = None
+        if self.lc:
+            self.L.kto_lc_free(self.lc)
+            self.lc = None
+
+    def __del__(self):
+        self.close()
+
+    def handle(self, part, ts, key, vlen):
+        """ts None == timestamp not available; key None == key None; vlen None == payload None."""
+        self.L.kto_metrics_handle_message(self.m, part, 0 if ts is None else ts, 0 if ts is None else 1,
+                                          -1 if key is None else len(key), -1 if vlen is None else vlen)
+        if self.lc:
+            self.L.kto_lc_handle_message(self.lc, key, -1 if key is None else len(key), -1 if vlen is None else vlen)
+
+    def run_soa(self, cols):
+        n = len(cols["partition"])
+        a = {k: np.ascontiguousarray(v) for k, v in cols.items() if isinstance(v, np.ndarray)}
+        assert a["partition"].dtype == np.int32 and a["ts_ms"].dtype == np.int64
+        koff = a["key_off"].ctypes.data if "key_off" in a else None
+        kb = a["key_bytes"].ctypes.data if "key_bytes" in a and len(a["key_bytes"]) else None
+        if self.lc and kb is None and "key_bytes" in a:
+            kb = np.zeros(16, np.uint8).ctypes.data
+        self.L.kto_run_soa(self.m, self.lc, n, a["partition"].ctypes.data, a["key_len"].ctypes.data,
+                           a["val_len"].ctypes.data, a["ts_ms"].ctypes.data, koff, kb)
+
+    def counters(self, P):
+        out = np.zeros((P, 7), dtype=np.uint64)
+        self.L.kto_export_counters(self.m, P, out.ctypes.data)
+        return out
+
+    def get(self, name, p=None):
+        fn = getattr(self.L, "kto_" + name)
+        return fn(self.m) if p is None else fn(self.m, p)
+
+    def avg(self, name, p):
+        out = C.c_uint64()
+        rc = getattr(self.L, "kto_" + name)(self.m, p, C.byref(out))
+        return None if rc != 0 else out.value
+
+    def earliest(self):
+        s, ns = C.c_int64(), C.c_uint32()
+        self.L.kto_earliest_message(self.m, C.byref(s), C.byref(ns))
+        return (s.value, ns.value)
+
+    def latest(self):
+        s, ns = C.c_int64(), C.c_uint32()
+        self.L.kto_latest_message(self.m, C.byref(s), C.byref(ns))
+        return (s.value, ns.value)
+
+    def alive_keys(self):
+        return self.L.kto_lc_sum_all_alive(self.lc)
+
+    def alive_words(self, n_words=1 << 27):
+        out = np.zeros(n_words, dtype=np.uint32)
+        self.L.kto_lc_export_words(self.lc, out.ctypes.data, n_words)
+        return out
