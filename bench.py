@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — the headline benchmark of the MI355X metric-accumulation path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): records/sec whole-node + achieved HBM GB/s on the 256-partition,
+256 B-mean-record synthetic topic (config "c4").  One process per GPU; partition p lives on
+rank p % N; every rank holds `--records-per-gpu` records (default 2^30: config 4's 1 B-record topic
+on ONE GPU) of its partitions in HBM — weak scaling: per-GPU work is fixed as N grows.
+
+A step = one pass of the metric-accumulation hot path (MessageMetrics::handle_message for every
+record, src/metric.rs:207-252) over the rank's HBM-resident batch: metrics-scan kernel + partial
+fold, then — for N > 1 — the exchange step: ONE all-reduce SUM of the counter vector prefix and
+ONE all-reduce MAX of the four extrema (RCCL over xGMI).  Inputs are resident in HBM before the
+timed region; nothing is skipped inside it.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (kta_metrics_scan):
+achieved = 20 algorithmic bytes/record x records per launch / mean kernel duration measured with
+HIP events on the library's compute stream during the timed steps.  `cpu_baseline` is the C oracle
+(oracle/kta_oracle.c, 1 thread — the reference is single threaded) on a bounded sample of the same
+records; `alive_pass` reports the --count-alive-keys pass (config "c3" shape) the same way.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+METRIC = "records/sec whole-node + achieved HBM GB/s, 256-part 256B-mean synthetic topic"
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
+BYTES_PER_RECORD = 20        # partition i32 + key_len i32 + val_len i32 + ts_ms i64
+
+
+class _DevVec:
+    """Zero-copy torch view of the library's device counter vector (as int64)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
+    """Time the C oracle (1 thread) over the first n_sample records of the resident batch."""
+    from oracle_c import Oracle
+    cols = h.download_batch(batch, n_sample)
+    passes, t_total = 0, 0.0
+    while t_total < min_seconds and passes < 64:
+        o = Oracle()
+        t0 = time.perf_counter()
+        o.run_soa(cols)
+        t_total += time.perf_counter() - t0
+        passes += 1
+        o.close()
+    return {"value": n_sample * passes / t_total, "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} records of the resident c4 shard x {passes} passes "
+                      f"({t_total:.1f} s), oracle/kta_oracle.c MessageMetrics::handle_message loop, "
+                      f"host has {os.cpu_count()} cores"}
+
+
+def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
+    """The --count-alive-keys pass (FNV + last-writer table) on the config-3 shape."""
+    from oracle_c import Oracle
+    spec, _ = kta.synth_preset("c3")
+    h = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
+    b = h.device_batch_alloc(n_records, n_records * 16)
+    kb = h.synth_fill_device(spec, 0, n_records, b)
+    for _ in range(warmup):
+        h.submit_device(b, n_records, 0, which=2)
+    h.sync()
+    h.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.submit_device(b, n_records, 0, which=2)
+    h.sync()
+    wall = time.perf_counter() - t0
+    avg_ms, cnt = h.kernel_time_stats()
+    h.set_timing(False)
+    res, _ = h.finish()
+    # this kernel reads key_len, val_len, key_off and the key bytes (partition and timestamp belong
+    # to the metrics scan): 12 B + len(key) per record
+    algo_bytes = (4 + 4 + 4) * n_records + kb
+    out = {"workload": f"c3 shape: 64 partitions, {n_records} records, 16 B keys, 10M distinct, 10% tombstones",
+           "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
+           "alive_keys": int(res.alive_keys),
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_update",
+                        "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
+                        "traffic": None,
+                        "note": "random 8-byte atomicMax RMWs into the 32 GiB last-writer table dominate; "
+                                "their traffic is not part of the algorithmic bytes"}}
+    m = min(n_records, 1 << 24)
+    cols = h.download_batch(b, m, m * 16)
+    passes, t_total = 0, 0.0
+    while t_total < cpu_seconds and passes < 64:
+        o = Oracle(count_alive_keys=True)
+        t0 = time.perf_counter()
+        o.L.kto_run_soa(None, o.lc, m, cols["partition"].ctypes.data, cols["key_len"].ctypes.data,
+                        cols["val_len"].ctypes.data, cols["ts_ms"].ctypes.data, cols["key_off"].ctypes.data,
+                        cols["key_bytes"].ctypes.data)
+        t_total += time.perf_counter() - t0
+        passes += 1
+        o.close()
+    out["cpu_baseline"] = {"value": m * passes / t_total, "unit": "records/s", "cores": 1, "kind": "port",
+                           "sample": f"first {m} records x {passes} passes ({t_total:.1f} s), "
+                                     "LogCompactionInMemoryMetrics::handle_message loop of oracle/kta_oracle.c"}
+    h.device_batch_free(b)
+    h.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--records-per-gpu", type=int, default=1 << 30,
+                    help="records resident per GPU (default 2^30 = 1.07 B: BASELINE config 4's 1 B-record "
+                         "256-partition topic fits one MI355X: 21.5 GB of 288 GB)")
+    ap.add_argument("--part-mode", choices=["random", "runs"], default="random",
+                    help="partition interleaving of the synthetic topic (random = worst case)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alive", action="store_true", help="skip the --count-alive-keys sub-benchmark")
+    ap.add_argument("--alive-records", type=int, default=1 << 26)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch  # first: its bundled HIP runtime must be the one this process loads
+    import torch.distributed as dist
+    import numpy as np
+    import kafka_topic_analyzer_amd as kta
+    from kafka_topic_analyzer_amd import _native as N
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libkta_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    P = 256
+    n = args.records_per_gpu
+    spec, _ = kta.synth_preset("c4")
+    spec.shard_index, spec.shard_count = rank, world      # partition p -> rank p % world
+    if args.part_mode == "runs":
+        spec.part_mode, spec.part_run_len = N.KTA_PART_RUNS, 500
+    h = kta.HipMetricHandler(P, device=local_rank)
+    batch = h.device_batch_alloc(n)
+    h.synth_fill_device(spec, rank * n, n, batch)          # rank-disjoint record index ranges
+    h.sync()
+
+    ptr, nwords = h.result_vector()
+    vec = torch.as_tensor(_DevVec(ptr, nwords), device=torch.device("cuda", local_rank))
+    n_sum = P * N.KTA_NCOUNTERS + N.KTA_NSUM_GLOBALS
+
+    def step():
+        """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
+        h.reset()                                          # MessageMetrics::new state (tiny kernel)
+        h.submit_device(batch, n, 0, which=1)              # scan + fold on the library's stream
+        if world > 1:
+            h.sync()                                       # shard result complete before the collectives
+            dist.all_reduce(vec[:n_sum], op=dist.ReduceOp.SUM)   # C1: counters (i64 wrap == u64 wrap)
+            dist.all_reduce(vec[n_sum:], op=dist.ReduceOp.MAX)   # C2: four extrema
+            torch.cuda.current_stream().synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        h.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    h.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    avg_ms, cnt = h.kernel_time_stats()
+    h.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity inside the bench: a single fresh pass must count exactly n records on this rank
+    h.reset()
+    h.submit_device(batch, n, 0, which=1)
+    res, counters = h.finish()
+    assert res.overall_count == n and int(counters[:, 0].sum()) == n, "scan lost records"
+    own = counters[rank::world, 0]
+    assert int(own.sum()) == n, "records outside this rank's partitions"
+
+    if rank == 0:
+        total_records = n * world * args.steps
+        scan_ms = avg_ms[0]
+        achieved = BYTES_PER_RECORD * n / (scan_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("records_per_launch") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": METRIC, "value": total_records / elapsed, "unit": "records/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "c4: 256-partition synthetic topic, mixed key/value sizes (mean record "
+                                   "~256 B), partitions sharded p % n_gpus", "records_per_gpu": n,
+                       "total_records_per_step": n * world, "partitions": P, "partition_order": args.part_mode,
+                       "bytes_per_record": BYTES_PER_RECORD, "parallelism": f"partition-sharded x{world}",
+                       "exchange": "none (1 GPU)" if world == 1 else
+                                   "per step: all-reduce SUM u64[%d] + all-reduce MAX i64[4] (RCCL)" % n_sum},
+            "roofline": {"bound": "hbm", "kernel": "kta_metrics_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": BYTES_PER_RECORD * n, "kernel_ms": scan_ms, "launches": int(cnt[0]),
+                         "fold_kernel_ms": avg_ms[1], "frac_of_measured_achievable_6290": achieved / 6290.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_metrics(h, batch, min(n, 1 << 26), P, args.cpu_seconds)
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    h.device_batch_free(batch)
+    h.close()
+    if rank == 0:
+        if world == 1 and not args.no_alive:
+            line["alive_pass"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
+                                                   args.alive_records, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

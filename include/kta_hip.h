@@ -60,18 +60,23 @@ enum {
 };
 
 /* The device result vector ("counter vector") is u64[P*7 + KTA_NGLOBALS]:
- * counters[p*7 + c] followed by the globals below.  It is the unit that is
- * all-reduced across GPUs when partitions are sharded (SUM over the counters and
- * the SUM-type globals, MAX/MIN over the extrema). */
+ * counters[p*7 + c], then KTA_NSUM_GLOBALS SUM-type globals, then four MAX-type
+ * globals.  It is the unit that is reduced across GPUs when partitions are sharded:
+ * ONE all-reduce SUM over the first P*7 + KTA_NSUM_GLOBALS words (u64 wrap-around ==
+ * i64 wrap-around) and ONE all-reduce MAX (signed i64) over the last four.  Minima are
+ * stored bit-complemented (~x is an order-reversing bijection on i64 without overflow),
+ * so that every extremum is a MAX. */
 enum {
-    KTA_G_MIN_TS_MS = 0,  /* i64, INT64_MAX when no record seen; -1 (n/a) already mapped to 0 */
-    KTA_G_MAX_TS_MS = 1,  /* i64, INT64_MIN when no record seen                              */
-    KTA_G_SMALLEST = 2,   /* i64-ranged size of the smallest non-tombstone, INT64_MAX if none */
-    KTA_G_LARGEST = 3,    /* size of the largest non-tombstone, 0 if none (metric.rs:41)      */
-    KTA_G_BAD_PARTITION = 4, /* SUM: records whose partition id was out of range (ignored)     */
-    KTA_G_ALIVE_KEYS = 5, /* SUM: filled by kta_finish when count_alive_keys                 */
-    KTA_G_RECORDS = 6,    /* SUM: records scanned (== overall_count, metric.rs:25)           */
-    KTA_G_RESERVED = 7,
+    KTA_G_BAD_PARTITION = 0, /* SUM: records whose partition id was out of range (ignored)      */
+    KTA_G_ALIVE_KEYS = 1,    /* SUM: filled by kta_finish when count_alive_keys                  */
+    KTA_G_RECORDS = 2,       /* SUM: records scanned (== overall_count, metric.rs:25)            */
+    KTA_G_RESERVED = 3,      /* SUM: reserved, zero                                              */
+    KTA_NSUM_GLOBALS = 4,
+    KTA_G_NOT_MIN_TS_MS = 4, /* MAX: ~min(ts_ms) (i64); ~INT64_MAX when no record seen; a raw
+                                timestamp of -1 (not available) was mapped to 0 first          */
+    KTA_G_MAX_TS_MS = 5,     /* MAX: max(ts_ms), INT64_MIN when no record seen                   */
+    KTA_G_NOT_SMALLEST = 6,  /* MAX: ~(size of the smallest non-tombstone); ~INT64_MAX if none   */
+    KTA_G_LARGEST = 7,       /* MAX: size of the largest non-tombstone, 0 if none (metric.rs:41) */
     KTA_NGLOBALS = 8
 };
 
@@ -186,7 +191,8 @@ int kta_finish_device(kta_ctx *ctx);
 int kta_decode_vector(const uint64_t *vec, uint32_t n_partitions, int count_alive_keys,
                       kta_result *out, uint64_t *counters_out);
 /* Host-side merge of two counter vectors (acc <- acc (+) other) with the per-field
- * reduction operator (SUM / MIN / MAX) — the reduction a collective must implement. */
+ * reduction operator (SUM over the prefix, signed MAX over the last four words) — exactly
+ * the reduction the two collectives implement. */
 int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t n_partitions);
 
 /* ---- alive-key table access (tests, multi-GPU merge) ------------------------------ */
@@ -202,11 +208,13 @@ int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes_host, const uint32_t
                      uint32_t *hash_out_host);
 
 /* ---- profiling hooks --------------------------------------------------------------- */
-/* Average duration (ms) of the kernels launched by the last `kta_submit_device*` call,
- * measured with HIP events on the compute stream: [0] metrics scan, [1] partial fold,
- * [2] alive-key update.  Requires kta_set_timing(ctx, 1); entries are -1 when not run. */
+/* With kta_set_timing(ctx, 1) every kernel launch is bracketed by a pair of HIP events recorded
+ * on the compute stream (no host synchronisation while recording).  kta_kernel_time_stats waits
+ * for the stream and returns, per kernel kind ([0] metrics scan, [1] partial fold, [2] alive-key
+ * update), the average duration in ms and the number of launches since the previous call
+ * (avg -1 when none). */
 int kta_set_timing(kta_ctx *ctx, int enable);
-int kta_last_kernel_ms(kta_ctx *ctx, float out_ms[3]);
+int kta_kernel_time_stats(kta_ctx *ctx, float avg_ms[3], uint64_t launches[3]);
 /* Launch-geometry knobs (0 = default): scan workgroups, LDS replication log2, alive WGs. */
 int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups,
                    int alive_variant);

@@ -277,10 +277,14 @@ class HipMetricHandler:
     def set_timing(self, on: bool) -> None:
         self._check(self._lib.kta_set_timing(self._ctx, 1 if on else 0))
 
+    def kernel_time_stats(self):
+        """-> ([avg ms scan, fold, alive], [launch counts]) since the previous call (syncs)."""
+        a, c = (C.c_float * 3)(), (C.c_uint64 * 3)()
+        self._check(self._lib.kta_kernel_time_stats(self._ctx, C.byref(a), C.byref(c)))
+        return list(a), list(c)
+
     def last_kernel_ms(self):
-        a = (C.c_float * 3)()
-        self._check(self._lib.kta_last_kernel_ms(self._ctx, C.byref(a)))
-        return list(a)
+        return self.kernel_time_stats()[0]
 
     def set_tuning(self, scan_workgroups=0, scan_variant=1, alive_workgroups=0, alive_variant=0) -> None:
         self._check(self._lib.kta_set_tuning(self._ctx, scan_workgroups, scan_variant, alive_workgroups,

@@ -25,8 +25,9 @@ KTA_NCOUNTERS = 7
 KTA_NGLOBALS = 8
 (KTA_C_TOTAL, KTA_C_TOMBSTONES, KTA_C_ALIVE, KTA_C_KEY_NULL, KTA_C_KEY_NON_NULL,
  KTA_C_KEY_SIZE_SUM, KTA_C_VALUE_SIZE_SUM) = range(7)
-(KTA_G_MIN_TS_MS, KTA_G_MAX_TS_MS, KTA_G_SMALLEST, KTA_G_LARGEST, KTA_G_BAD_PARTITION,
- KTA_G_ALIVE_KEYS, KTA_G_RECORDS, KTA_G_RESERVED) = range(8)
+(KTA_G_BAD_PARTITION, KTA_G_ALIVE_KEYS, KTA_G_RECORDS, KTA_G_RESERVED, KTA_G_NOT_MIN_TS_MS,
+ KTA_G_MAX_TS_MS, KTA_G_NOT_SMALLEST, KTA_G_LARGEST) = range(8)
+KTA_NSUM_GLOBALS = 4
 
 KTA_PART_RANDOM, KTA_PART_KEY_AFFINE, KTA_PART_RUNS = 0, 1, 2
 KTA_VAL_FIXED, KTA_VAL_EXP = 0, 1
@@ -91,7 +92,7 @@ SIGNATURES = {
     "kta_alive_table": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "kta_fnv32_device": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kta_set_timing": (C.c_int, [_P, C.c_int]),
-    "kta_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float * 3)]),
+    "kta_kernel_time_stats": (C.c_int, [_P, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint64 * 3)]),
     "kta_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kta_synth_fill_host": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.POINTER(KtaBatch),
                                       C.POINTER(C.c_uint64)]),

@@ -46,8 +46,12 @@ struct kta_ctx {
     // tuning / profiling
     int scan_wgs = 0, scan_variant = 1, alive_wgs = 0, alive_variant = 0;
     bool timing = false;
-    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
-    float last_ms[3] = {-1.f, -1.f, -1.f};
+    // HIP-event pairs recorded around each kernel on the compute stream (no host sync while
+    // recording); drained by kta_kernel_time_stats.  kind: 0 scan, 1 fold, 2 alive update.
+    std::vector<hipEvent_t> ev_pool[3];
+    size_t ev_used[3] = {0, 0, 0};
+    double ms_sum[3] = {0, 0, 0};
+    uint64_t ms_cnt[3] = {0, 0, 0};
     std::string err;
 };
 
@@ -132,11 +136,46 @@ void free_host_batch(kta_batch *b)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+constexpr size_t kMaxTimedPairs = 2048;
+
+int drain_timers(kta_ctx *ctx)
+{
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    for (int k = 0; k < 3; k++) {
+        for (size_t i = 0; i + 1 < ctx->ev_used[k]; i += 2) {
+            float ms = 0.f;
+            KTA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[k][i], ctx->ev_pool[k][i + 1]));
+            ctx->ms_sum[k] += ms;
+            ctx->ms_cnt[k] += 1;
+        }
+        ctx->ev_used[k] = 0;
+    }
+    return KTA_OK;
+}
+
+// next (start, stop) event pair of kernel kind k
+int timer_pair(kta_ctx *ctx, int k, hipEvent_t *a, hipEvent_t *b)
+{
+    if (ctx->ev_used[k] + 2 > 2 * kMaxTimedPairs) {
+        int rc = drain_timers(ctx);
+        if (rc != KTA_OK) return rc;
+    }
+    while (ctx->ev_pool[k].size() < ctx->ev_used[k] + 2) {
+        hipEvent_t e;
+        KTA_HIP(ctx, hipEventCreate(&e));
+        ctx->ev_pool[k].push_back(e);
+    }
+    *a = ctx->ev_pool[k][ctx->ev_used[k]];
+    *b = ctx->ev_pool[k][ctx->ev_used[k] + 1];
+    ctx->ev_used[k] += 2;
+    return KTA_OK;
+}
+
 // Launch the handlers over device-resident columns on the compute stream.
 int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base_seq, int which)
 {
     if (n == 0) return KTA_OK;
-    ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = -1.f;
+    hipEvent_t a = nullptr, b = nullptr;
     if (which & 1) {
         if (!c->partition || !c->key_len || !c->val_len || !c->ts_ms)
             return fail(ctx, KTA_ERR_INVALID, "metric columns missing");
@@ -146,31 +185,34 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         kta::ScanColumns sc{c->partition, c->key_len, c->val_len, c->ts_ms};
         kta::ScanPlan pl = kta::plan_scan(ctx->P, n, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant);
         if (pl.workgroups > ctx->max_rows) pl.workgroups = ctx->max_rows;
-        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[0], ctx->s_compute));
+        if (ctx->timing) {
+            int rc = timer_pair(ctx, 0, &a, &b);
+            if (rc != KTA_OK) return rc;
+            KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
+        }
         KTA_HIP(ctx, kta::launch_metrics_scan(pl, sc, n, ctx->P, ctx->d_partials, ctx->s_compute));
-        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[1], ctx->s_compute));
+        if (ctx->timing) {
+            KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
+            int rc = timer_pair(ctx, 1, &a, &b);
+            if (rc != KTA_OK) return rc;
+            KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
+        }
         KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.workgroups, ctx->P, ctx->d_vec,
                                                ctx->s_compute));
-        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(ctx->ev_t[2], ctx->s_compute));
+        if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     if ((which & 2) && ctx->alive) {
         if (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes)
             return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
         kta::AliveColumns ac{c->key_len, c->val_len, c->key_off, c->key_bytes, c->seq};
-        hipEvent_t a = ctx->ev_t[2], b = ctx->ev_t[3];
-        if (ctx->timing && !(which & 1)) KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
+        if (ctx->timing) {
+            int rc = timer_pair(ctx, 2, &a, &b);
+            if (rc != KTA_OK) return rc;
+            KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
+        }
         KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
                                               ctx->alive_variant, ctx->s_compute));
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
-    }
-    if (ctx->timing) {
-        KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
-        if (which & 1) {
-            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[0], ctx->ev_t[0], ctx->ev_t[1]));
-            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[1], ctx->ev_t[1], ctx->ev_t[2]));
-        }
-        if ((which & 2) && ctx->alive)
-            KTA_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[2], ctx->ev_t[2], ctx->ev_t[3]));
     }
     return KTA_OK;
 }
@@ -239,7 +281,6 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     KTA_TRY(hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
     KTA_TRY(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
     KTA_TRY(hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming));
-    for (auto &ev : ctx->ev_t) KTA_TRY(hipEventCreate(&ev));
     const size_t vec_words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
     KTA_TRY(hipMalloc((void **)&ctx->d_vec, vec_words * sizeof(uint64_t)));
     ctx->max_rows = (uint32_t)ctx->cu_count * 8u;
@@ -270,8 +311,8 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
-    for (auto &ev : ctx->ev_t)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &pool : ctx->ev_pool)
+        for (auto ev : pool) (void)hipEventDestroy(ev);
     if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
     delete ctx;
@@ -491,9 +532,9 @@ int kta_decode_vector(const uint64_t *vec, uint32_t P, int count_alive_keys, kta
     out->count_alive_keys = count_alive_keys ? 1u : 0u;
     // metric.rs:210: timestamp / 1000 truncates toward zero, and is monotone, so applying it
     // to the extrema of the millisecond values equals the extrema of the per-record seconds.
-    out->min_ts_sec = out->any_records ? (int64_t)g[KTA_G_MIN_TS_MS] / 1000 : 0;
+    out->min_ts_sec = out->any_records ? (int64_t)~g[KTA_G_NOT_MIN_TS_MS] / 1000 : 0;
     out->max_ts_sec = out->any_records ? (int64_t)g[KTA_G_MAX_TS_MS] / 1000 : 0;
-    out->smallest_message = out->any_live ? g[KTA_G_SMALLEST] : UINT64_MAX; // metric.rs:42
+    out->smallest_message = out->any_live ? ~g[KTA_G_NOT_SMALLEST] : UINT64_MAX; // metric.rs:42
     out->largest_message = g[KTA_G_LARGEST];
     out->overall_count = total;
     out->overall_size = size;
@@ -506,16 +547,9 @@ int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t P)
 {
     if (!acc || !other || P == 0) return KTA_ERR_INVALID;
     const size_t nc = (size_t)P * KTA_NCOUNTERS;
-    for (size_t i = 0; i < nc; i++) acc[i] += other[i];
-    uint64_t *g = acc + nc;
-    const uint64_t *h = other + nc;
-    if ((int64_t)h[KTA_G_MIN_TS_MS] < (int64_t)g[KTA_G_MIN_TS_MS]) g[KTA_G_MIN_TS_MS] = h[KTA_G_MIN_TS_MS];
-    if ((int64_t)h[KTA_G_MAX_TS_MS] > (int64_t)g[KTA_G_MAX_TS_MS]) g[KTA_G_MAX_TS_MS] = h[KTA_G_MAX_TS_MS];
-    if ((int64_t)h[KTA_G_SMALLEST] < (int64_t)g[KTA_G_SMALLEST]) g[KTA_G_SMALLEST] = h[KTA_G_SMALLEST];
-    if ((int64_t)h[KTA_G_LARGEST] > (int64_t)g[KTA_G_LARGEST]) g[KTA_G_LARGEST] = h[KTA_G_LARGEST];
-    g[KTA_G_BAD_PARTITION] += h[KTA_G_BAD_PARTITION];
-    g[KTA_G_ALIVE_KEYS] += h[KTA_G_ALIVE_KEYS];
-    g[KTA_G_RECORDS] += h[KTA_G_RECORDS];
+    for (size_t i = 0; i < nc + KTA_NSUM_GLOBALS; i++) acc[i] += other[i];
+    for (size_t i = nc + KTA_NSUM_GLOBALS; i < nc + KTA_NGLOBALS; i++)
+        if ((int64_t)other[i] > (int64_t)acc[i]) acc[i] = other[i];
     return KTA_OK;
 }
 
@@ -601,10 +635,18 @@ int kta_set_timing(kta_ctx *ctx, int enable)
     return KTA_OK;
 }
 
-int kta_last_kernel_ms(kta_ctx *ctx, float out_ms[3])
+int kta_kernel_time_stats(kta_ctx *ctx, float avg_ms[3], uint64_t launches[3])
 {
-    if (!ctx || !out_ms) return KTA_ERR_INVALID;
-    for (int i = 0; i < 3; i++) out_ms[i] = ctx->last_ms[i];
+    if (!ctx || !avg_ms || !launches) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = drain_timers(ctx);
+    if (rc != KTA_OK) return rc;
+    for (int k = 0; k < 3; k++) {
+        launches[k] = ctx->ms_cnt[k];
+        avg_ms[k] = ctx->ms_cnt[k] ? (float)(ctx->ms_sum[k] / (double)ctx->ms_cnt[k]) : -1.f;
+        ctx->ms_sum[k] = 0;
+        ctx->ms_cnt[k] = 0;
+    }
     return KTA_OK;
 }
 

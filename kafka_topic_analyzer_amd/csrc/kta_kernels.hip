@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kWG) void kta_fold_partials(const uint64_t *__restr
             atomicAdd(&o[0], s);
             atomicAdd(&o[2], s);
             atomicAdd(&o[4], s);
-            atomicAdd(&g[6], s);
+            atomicAdd(&g[2], s);
             break;
         case 1: // tombstones: tombstones += s, alive -= s   (alive = total - tombstones)
             atomicAdd(&o[1], s);
@@ -317,24 +317,25 @@ __global__ __launch_bounds__(kWG) void kta_fold_partials(const uint64_t *__restr
         }
     } else {
         const uint32_t gi = col - P * kScanCols;
-        if (gi == SG_TMIN || gi == SG_SMIN) {
+        long long *gs = reinterpret_cast<long long *>(g);
+        if (gi == SG_TMIN || gi == SG_SMIN) { // minima are kept bit-complemented: all four are MAX
             long long m = LLONG_MAX;
             for (uint32_t r = r0; r < r1; r++) {
                 const long long x = (long long)partials[(uint64_t)r * row_len + col];
                 m = x < m ? x : m;
             }
-            atomicMin(reinterpret_cast<long long *>(&g[gi == SG_TMIN ? 0 : 2]), m);
+            atomicMax(&gs[gi == SG_TMIN ? 4 : 6], ~m);
         } else if (gi == SG_TMAX || gi == SG_SMAX) {
             long long m = LLONG_MIN;
             for (uint32_t r = r0; r < r1; r++) {
                 const long long x = (long long)partials[(uint64_t)r * row_len + col];
                 m = x > m ? x : m;
             }
-            atomicMax(reinterpret_cast<long long *>(&g[gi == SG_TMAX ? 1 : 3]), m);
+            atomicMax(&gs[gi == SG_TMAX ? 5 : 7], m);
         } else if (gi == SG_BAD) {
             unsigned long long s = 0;
             for (uint32_t r = r0; r < r1; r++) s += partials[(uint64_t)r * row_len + col];
-            if (s) atomicAdd(&g[4], s);
+            if (s) atomicAdd(&g[0], s);
         }
     }
 }
@@ -346,11 +347,11 @@ __global__ void kta_init_vector(uint64_t *vec, uint32_t P)
     if (i < nc) vec[i] = 0;
     if (i == 0) {
         uint64_t *g = vec + nc;
-        g[0] = (uint64_t)LLONG_MAX; // min ts: nothing seen
-        g[1] = (uint64_t)LLONG_MIN; // max ts
-        g[2] = (uint64_t)LLONG_MAX; // smallest: u64::MAX in the reference (metric.rs:42)
-        g[3] = 0;                   // largest (metric.rs:41)
-        g[4] = 0; g[5] = 0; g[6] = 0; g[7] = 0;
+        g[0] = 0; g[1] = 0; g[2] = 0; g[3] = 0;  // SUM globals
+        g[4] = (uint64_t)~LLONG_MAX;             // ~min ts: nothing seen
+        g[5] = (uint64_t)LLONG_MIN;              // max ts
+        g[6] = (uint64_t)~LLONG_MAX;             // ~smallest: u64::MAX in the reference (metric.rs:42)
+        g[7] = 0;                                // largest (metric.rs:41)
     }
 }
 

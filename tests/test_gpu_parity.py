@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path (through the C ABI of libkta_hip.so) against the CPU oracle on
+the same inputs — bit-exact for every counter, extremum and for the alive-key set — plus the
+golden scenarios and size-independent properties at BASELINE.json scale."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import kafka_topic_analyzer_amd as kta
+from kafka_topic_analyzer_amd import _native as N
+from helpers import NOW, cols_to_records, load_golden, random_cols, records_to_cols, scenario_records
+from oracle_c import Oracle, fnv32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hc():
+    """One -c context (32 GiB last-writer table) shared by the module; reset between tests."""
+    h = kta.HipMetricHandler(256, count_alive_keys=True, batch_capacity=1 << 16,
+                             key_bytes_capacity=1 << 22, n_staging=3, now=NOW)
+    yield h
+    h.close()
+
+
+def _compare(h, o, P, check_bitmap=False):
+    res, c = h.finish()
+    assert np.array_equal(c[:P], o.counters(P)), "per-partition counters differ"
+    assert not c[P:].any()
+    mm = kta.MessageMetrics(res, c, h.now)
+    assert mm.earliest_message() == o.earliest()
+    assert mm.latest_message() == o.latest()
+    assert mm.smallest_message() == o.get("smallest_message")
+    assert mm.largest_message() == o.get("largest_message")
+    assert mm.overall_count() == o.get("overall_count")
+    assert mm.overall_size() == o.get("overall_size")
+    for p in range(P):
+        assert np.float32(mm.dirty_ratio(p)) == np.float32(o.get("dirty_ratio", p))
+        for name in ("key_size_avg", "value_size_avg", "message_size_avg"):
+            want = o.avg(name, p)
+            if want is None:
+                with pytest.raises(kta.DivideByZeroPanic):
+                    getattr(mm, name)(p)
+            else:
+                assert getattr(mm, name)(p) == want
+    if o.lc:
+        assert res.alive_keys == o.alive_keys()
+        if check_bitmap:
+            assert np.array_equal(h.export_alive_bitmap(), o.alive_words()), "alive-key sets differ"
+
+
+# ------------------------------------------------------------------------------------- FNV
+def test_fnv_device_golden_and_random(hc):
+    kats = [(bytes.fromhex(v["key_hex"]), v["hash"]) for v in load_golden("fnv32_kats.json")]
+    got = hc.fnv32([k for k, _ in kats])
+    assert [int(x) for x in got] == [w for _, w in kats]
+    assert [int(x) for x in hc.fnv32([k for k, _ in kta.fnv_reference_kats()])] == \
+        [w for _, w in kta.fnv_reference_kats()]
+    rng = np.random.default_rng(11)
+    keys = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes()
+            for n in rng.integers(0, 300, size=4000)]  # every alignment / length class
+    got = hc.fnv32(keys)
+    assert [int(x) for x in got] == [fnv32(k) for k in keys]
+
+
+# ------------------------------------------------------------------------------------- golden
+@pytest.mark.parametrize("name", sorted(load_golden("scenarios.json")["scenarios"].keys()))
+def test_golden_scenarios_per_message_entry(hc, name):
+    """Feed the reference-test-style scenarios through kta_handle_message (the MetricHandler binding)."""
+    g = load_golden("scenarios.json")
+    sc, P = g["scenarios"][name], g["n_partitions"]
+    hc.reset()
+    for p, ts, k, v in scenario_records(sc):
+        hc.handle_message(kta.Message(p, ts, k, v))
+    res, c = hc.finish()
+    e = sc["expect"]
+    mm = kta.MessageMetrics(res, c, tuple(g["now"]))
+    for p in range(P):
+        assert [int(x) for x in c[p]] == e["partitions"][p]["counters"]
+        for nm in ("key_size_avg", "value_size_avg", "message_size_avg"):
+            if e["partitions"][p][nm] == "panic":
+                with pytest.raises(kta.DivideByZeroPanic):
+                    getattr(mm, nm)(p)
+            else:
+                assert getattr(mm, nm)(p) == e["partitions"][p][nm]
+    assert list(mm.earliest_message()) == e["earliest"] and list(mm.latest_message()) == e["latest"]
+    assert (mm.smallest_message(), mm.largest_message()) == (e["smallest"], e["largest"])
+    assert (mm.overall_count(), mm.overall_size()) == (e["overall_count"], e["overall_size"])
+    assert res.alive_keys == e["alive_keys"]
+    if name in ("mixed_400", "hash_collision_later_wins_alive", "empty_key"):
+        bm = hc.export_alive_bitmap()
+        slots = np.nonzero(bm)[0]
+        got = sorted(int(w) * 32 + b for w in slots for b in range(32) if (int(bm[w]) >> b) & 1)
+        assert got == e["alive_slots"]
+
+
+# ------------------------------------------------------------------------------------- random streams
+@pytest.mark.parametrize("P,n,runs,variant", [
+    (1, 5000, False, 0), (1, 70001, True, 1), (3, 20000, False, 1), (8, 150000, False, 0),
+    (8, 150000, True, 1), (64, 200003, False, 1), (256, 300000, False, 0), (256, 300000, True, 1),
+])
+def test_random_stream_through_staging_ring(hc, P, n, runs, variant):
+    rng = np.random.default_rng(P * 1000 + n)
+    cols = random_cols(rng, n, P, key_space=max(10, n // 7), runs=runs)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    hc.reset()
+    hc.set_tuning(scan_variant=variant)
+    hc.submit_columns(**cols)  # 65536-record staging batches: several batches, ring wraps
+    _compare(hc, o, P, check_bitmap=(P in (3, 256)))
+    hc.set_tuning()
+
+
+def test_many_partitions_and_no_alive_context():
+    P = 1500
+    rng = np.random.default_rng(5)
+    cols = random_cols(rng, 120000, P, key_space=5000)
+    o = Oracle(NOW, False)
+    o.run_soa(cols)
+    with kta.HipMetricHandler(P, batch_capacity=50000, now=NOW) as h:
+        h.submit_columns(cols["partition"], cols["key_len"], cols["val_len"], cols["ts_ms"])
+        _compare(h, o, P)
+
+
+def test_sizes_up_to_i32_max_take_the_wide_path(hc):
+    """val_len up to 2^31-1: 64-bit sums, the packed fast path must bail out wave-uniformly."""
+    rng = np.random.default_rng(99)
+    cols = random_cols(rng, 100000, 8, key_space=100, big_sizes=True)
+    cols["val_len"][:3] = [2**31 - 1, 2**31 - 1, 0]
+    cols["key_len"][:3] = [-1, 1, -1]
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    for variant in (0, 1):
+        hc.reset()
+        hc.set_tuning(scan_variant=variant)
+        hc.submit_columns(**cols)
+        _compare(hc, o, 8)
+    hc.set_tuning()
+    assert o.get("largest_message") >= 2**31 - 1
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 255, 256, 257, 1023, 1024, 1025, 4099])
+def test_empty_and_ragged_batch_sizes(hc, n):
+    rng = np.random.default_rng(n + 1)
+    cols = random_cols(rng, n, 5, key_space=7) if n else records_to_cols([])
+    o = Oracle(NOW, True)
+    if n:
+        o.run_soa(cols)
+    hc.reset()
+    b, _ = hc.upload_batch(cols, with_keys=True)
+    hc.submit_device(b, n, 0)
+    _compare(hc, o, 5)
+    hc.device_batch_free(b)
+
+
+def test_bad_partition_is_reported_not_counted(hc):
+    cols = records_to_cols([(0, 1000, b"a", 1), (256, 2000, b"b", 2), (-1, 3000, b"c", 3), (255, 4000, b"d", 4)])
+    hc.reset()
+    hc.submit_columns(**cols)
+    with pytest.raises(kta.KtaError) as e:
+        hc.finish()
+    assert e.value.code == N.KTA_ERR_BAD_PARTITION
+    res, c = hc.finish(allow_bad_partition=True)
+    assert res.bad_partition_records == 2 and res.overall_count == 2
+    assert int(c[0, 0]) == 1 and int(c[255, 0]) == 1 and res.max_ts_sec == 4
+
+
+def test_reset_and_accumulation_across_batches(hc):
+    rng = np.random.default_rng(3)
+    a = random_cols(rng, 30000, 16, key_space=300)
+    b = random_cols(rng, 41000, 16, key_space=300)
+    o = Oracle(NOW, True)
+    o.run_soa(a)
+    o.run_soa(b)
+    hc.reset()
+    hc.submit_columns(**a)
+    r1, _ = hc.finish()  # finish is non-destructive: more batches may follow
+    assert r1.overall_count == 30000
+    hc.submit_columns(**b)
+    _compare(hc, o, 16, check_bitmap=True)
+    hc.reset()
+    res, c = hc.finish()
+    assert res.any_records == 0 and res.alive_keys == 0 and not c.any()
+
+
+# ------------------------------------------------------------------------------------- alive-key order
+def test_last_writer_wins_is_by_sequence_not_by_submission_order(hc):
+    """Two device batches with explicit seq columns, submitted in the WRONG order, must still
+    reproduce sequential BitSet semantics (what a partition-sharded multi-GPU merge relies on)."""
+    rng = np.random.default_rng(21)
+    cols = random_cols(rng, 60000, 4, key_space=500, tomb=0.5)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    n = len(cols["partition"])
+    half = n // 2
+    hc.reset()
+    parts = []
+    for lo, hi in ((half, n), (0, half)):  # second half first
+        sub = {k: v[lo:hi] for k, v in cols.items() if k != "key_bytes"}
+        base = int(cols["key_off"][lo])
+        end = int(cols["key_off"][hi - 1]) + max(int(cols["key_len"][hi - 1]), 0)
+        sub["key_bytes"] = cols["key_bytes"][base:end]
+        sub["key_off"] = (cols["key_off"][lo:hi] - base).astype(np.uint32)
+        sub["seq"] = np.arange(lo, hi, dtype=np.uint64)
+        b, m = hc.upload_batch(sub, with_keys=True)
+        hc.submit_device(b, m, 0)
+        parts.append(b)
+    _compare(hc, o, 4, check_bitmap=True)
+    for b in parts:
+        hc.device_batch_free(b)
+
+
+def test_collision_across_partitions_and_batches(hc):
+    g = load_golden("scenarios.json")["scenarios"]
+    recs = scenario_records(g["hash_collision_later_wins_dead"])
+    (p0, t0, ka, _), (p1, t1, kb, _) = recs
+    assert ka != kb and fnv32(ka) == fnv32(kb)
+    for order, want in (((ka, 1), (kb, None)), 0), (((ka, None), (kb, 3)), 1), (((kb, 3), (ka, None)), 0):
+        hc.reset()
+        for i, (k, v) in enumerate(order):  # separate batches: flush after each message
+            hc.handle_message(kta.Message(i, 1000 + i, k, v))
+            hc.flush()
+        res, _ = hc.finish()
+        assert res.alive_keys == want
+
+
+# ------------------------------------------------------------------------------------- generator
+@pytest.mark.parametrize("preset", ["c1", "c2", "c3", "c4"])
+def test_device_generator_matches_host_generator(hc, preset):
+    sp, _ = kta.synth_preset(preset)
+    n, first = 50000, 123456789
+    host = kta.synth_fill_host(sp, first, n, with_keys=True, with_seq=True)
+    b = hc.device_batch_alloc(n, max(host["n_key_bytes"], 16), with_seq=True)
+    kb = hc.synth_fill_device(sp, first, n, b)
+    assert kb == host["n_key_bytes"]
+    dev = hc.download_batch(b, n, kb)
+    for k in ("partition", "key_len", "val_len", "ts_ms", "key_off", "key_bytes", "seq"):
+        assert np.array_equal(dev[k], host[k]), k
+    hc.device_batch_free(b)
+
+
+# ------------------------------------------------------------------------------------- BASELINE-scale
+def _vector(h):
+    h.finish_device()
+    return h.result_vector_host()
+
+
+def test_full_size_properties_metrics_scan():
+    """2^27 records of the 256-partition mixed topic (BASELINE config 4's per-GPU shard size):
+    oracle on a window, then properties that do not need the oracle at full size."""
+    sp, _ = kta.synth_preset("c4")
+    n = 1 << 27
+    P = 256
+    with kta.HipMetricHandler(P, now=NOW) as h:
+        b = h.device_batch_alloc(n)
+        h.synth_fill_device(sp, 0, n, b)
+        # (a) oracle on a 2^21 window in the middle
+        w0, wn = (n // 2) + 1, 1 << 21
+        host = kta.synth_fill_host(sp, w0, wn)
+        o = Oracle(NOW)
+        o.run_soa(host)
+        win = kta.KtaBatch()
+        for f, sz in (("partition", 4), ("key_len", 4), ("val_len", 4), ("ts_ms", 8)):
+            setattr(win, f, getattr(b, f) + ((w0 + 3) // 4 * 4) * sz)  # keep 16 B alignment
+        skip = (w0 + 3) // 4 * 4 - w0
+        o2 = Oracle(NOW)
+        o2.run_soa({k: v[skip:] for k, v in host.items() if isinstance(v, np.ndarray)})
+        h.submit_device(win, wn - skip, 0, which=1)
+        _compare(h, o2, P)
+        # (b) whole batch: identities + invariance to launch geometry and kernel variant
+        vecs = []
+        for variant, wgs in ((0, 0), (1, 0), (1, 300), (0, 2048), (1, 77)):
+            h.reset()
+            h.set_tuning(scan_workgroups=wgs, scan_variant=variant)
+            h.submit_device(b, n, 0, which=1)
+            vecs.append(_vector(h))
+        for v in vecs[1:]:
+            assert np.array_equal(v, vecs[0])
+        v = vecs[0]
+        c = v[:P * 7].reshape(P, 7)
+        assert int(c[:, N.KTA_C_TOTAL].sum()) == n == int(v[P * 7 + N.KTA_G_RECORDS])
+        assert np.array_equal(c[:, N.KTA_C_TOMBSTONES] + c[:, N.KTA_C_ALIVE], c[:, N.KTA_C_TOTAL])
+        assert np.array_equal(c[:, N.KTA_C_KEY_NULL] + c[:, N.KTA_C_KEY_NON_NULL], c[:, N.KTA_C_TOTAL])
+        assert (c[:, N.KTA_C_ALIVE] > 0).all()
+        # (c) linearity: two halves accumulated into fresh state and merged == the whole
+        lib = N.load()
+        halves = []
+        for lo in (0, n // 2):
+            h.reset()
+            hb = kta.KtaBatch()
+            for f, sz in (("partition", 4), ("key_len", 4), ("val_len", 4), ("ts_ms", 8)):
+                setattr(hb, f, getattr(b, f) + lo * sz)
+            h.submit_device(hb, n // 2, 0, which=1)
+            halves.append(_vector(h))
+        assert lib.kta_merge_vectors(halves[0].ctypes.data, halves[1].ctypes.data, P) == N.KTA_OK
+        assert np.array_equal(halves[0], v)
+        h.device_batch_free(b)
+
+
+def test_full_size_properties_alive_pass(hc):
+    """2^26 records, 16 B keys, 10M distinct (BASELINE config 3 shape): oracle on a prefix, then
+    idempotence (replaying the same records with the same seq changes nothing) and the
+    A-then-all-tombstones round trip (every key dead => 0 alive)."""
+    sp, _ = kta.synth_preset("c3")
+    n = 1 << 26
+    hc.reset()
+    b = hc.device_batch_alloc(n, n * 16)
+    kb = hc.synth_fill_device(sp, 0, n, b)
+    assert kb == n * 16
+    m = 1 << 21
+    host = kta.synth_fill_host(sp, 0, m, with_keys=True)
+    o = Oracle(NOW, True)
+    o.run_soa(host)
+    hc.submit_device(b, m, 0, which=2)
+    res, _ = hc.finish()
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+    hc.reset()
+    hc.submit_device(b, n, 0, which=2)
+    r1, _ = hc.finish()
+    hc.submit_device(b, n, 0, which=2)  # idempotent under replay with identical sequence numbers
+    r2, _ = hc.finish()
+    assert r1.alive_keys == r2.alive_keys and 0 < r1.alive_keys <= 10_000_000
+    # kill everything: same keys, later sequence numbers, all tombstones
+    sp2, _ = kta.synth_preset("c3")
+    sp2.tombstone_permille = 1000
+    hc.synth_fill_device(sp2, 0, n, b)
+    hc.submit_device(b, n, n, which=2)
+    r3, _ = hc.finish()
+    assert r3.alive_keys == 0
+    hc.device_batch_free(b)
