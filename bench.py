@@ -138,6 +138,7 @@ def main():
     import numpy as np
     import kafka_topic_analyzer_amd as kta
     from kafka_topic_analyzer_amd import _native as N
+    from kafka_topic_analyzer_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +157,7 @@ def main():
     P = 256
     n = args.records_per_gpu
     spec, _ = kta.synth_preset("c4")
-    spec.shard_index, spec.shard_count = rank, world      # partition p -> rank p % world
+    spec = D.shard_spec(spec, rank, world)                 # partition p -> rank p % world
     if args.part_mode == "runs":
         spec.part_mode, spec.part_run_len = N.KTA_PART_RUNS, 500
     h = kta.HipMetricHandler(P, device=local_rank)
@@ -166,7 +167,7 @@ def main():
 
     ptr, nwords = h.result_vector()
     vec = torch.as_tensor(_DevVec(ptr, nwords), device=torch.device("cuda", local_rank))
-    n_sum = P * N.KTA_NCOUNTERS + N.KTA_NSUM_GLOBALS
+    n_sum = D.sum_prefix_len(P)
 
     def step():
         """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
@@ -174,8 +175,7 @@ def main():
         h.submit_device(batch, n, 0, which=1)              # scan + fold on the library's stream
         if world > 1:
             h.sync()                                       # shard result complete before the collectives
-            dist.all_reduce(vec[:n_sum], op=dist.ReduceOp.SUM)   # C1: counters (i64 wrap == u64 wrap)
-            dist.all_reduce(vec[n_sum:], op=dist.ReduceOp.MAX)   # C2: four extrema
+            D.allreduce_counter_vector(vec, P)             # C1 SUM (counters) + C2 MAX (four extrema)
             torch.cuda.current_stream().synchronize()
 
     def barrier():

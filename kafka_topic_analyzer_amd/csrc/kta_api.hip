@@ -37,6 +37,8 @@ struct kta_ctx {
     uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
     uint32_t max_rows = 0;
     uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
+    uint32_t *d_hash_scratch = nullptr; // ablation variants only
+    uint64_t hash_scratch_cap = 0;
     std::vector<Stage> stages;
     uint64_t batch_capacity = 0, key_bytes_capacity = 0;
     int cur = 0;
@@ -44,7 +46,7 @@ struct kta_ctx {
     uint64_t fill_n = 0, fill_kb = 0; // kta_handle_message fill state
     uint64_t next_seq = 0;
     // tuning / profiling
-    int scan_wgs = 0, scan_variant = 1, alive_wgs = 0, alive_variant = 0;
+    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 0; // 16: non-temporal loads
     bool timing = false;
     // HIP-event pairs recorded around each kernel on the compute stream (no host sync while
     // recording); drained by kta_kernel_time_stats.  kind: 0 scan, 1 fold, 2 alive update.
@@ -210,8 +212,15 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             if (rc != KTA_OK) return rc;
             KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
         }
+        if ((ctx->alive_variant == 8 || ctx->alive_variant == 9) && ctx->hash_scratch_cap < n) {
+            KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+            if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
+            ctx->d_hash_scratch = nullptr;
+            KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
+            ctx->hash_scratch_cap = n;
+        }
         KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
-                                              ctx->alive_variant, ctx->s_compute));
+                                              ctx->alive_variant, ctx->d_hash_scratch, ctx->s_compute));
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     return KTA_OK;
@@ -310,6 +319,7 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_vec) (void)hipFree(ctx->d_vec);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
     for (auto &pool : ctx->ev_pool)
         for (auto ev : pool) (void)hipEventDestroy(ev);

@@ -37,6 +37,7 @@ struct ScanPlan {
     uint32_t rep_log2;     // LDS replication of each partition's slots
     uint32_t lds_bytes;    // dynamic LDS per workgroup
     uint32_t variant;      // 0 = three 64-bit LDS atomics/record, 1 = packed (two), 9 = loads only (diagnostic)
+    bool nontemporal;      // stream the columns with non-temporal loads
 };
 
 // u64 words one workgroup writes into the partial workspace
@@ -54,8 +55,9 @@ hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_
 hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s);
 
 // K2+K3: FNV (fnv32.rs:92-101) + last-writer-wins table update (metric.rs:289-304)
+// variant 0 = fused; 8 / 9 = ablation halves (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, hipStream_t s);
+                               int workgroups, int variant, uint32_t *scratch, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)

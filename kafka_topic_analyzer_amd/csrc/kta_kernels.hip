@@ -53,13 +53,31 @@ struct Quad {
     longlong2 t0, t1;
 };
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef long long v2l __attribute__((ext_vector_type(2)));
+
+// NT: non-temporal loads (the columns are streamed exactly once; keep them out of L2/MALL)
+template <bool NT>
 __device__ __forceinline__ void load_quad(Quad &q, const ScanColumns &c, uint64_t qi)
 {
-    q.p = reinterpret_cast<const int4 *>(c.partition)[qi];
-    q.k = reinterpret_cast<const int4 *>(c.key_len)[qi];
-    q.v = reinterpret_cast<const int4 *>(c.val_len)[qi];
-    q.t0 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi];
-    q.t1 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi + 1];
+    if (NT) {
+        const v4i p = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(c.partition) + qi);
+        const v4i k = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(c.key_len) + qi);
+        const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(c.val_len) + qi);
+        const v2l t0 = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(c.ts_ms) + 2 * qi);
+        const v2l t1 = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(c.ts_ms) + 2 * qi + 1);
+        q.p = make_int4(p.x, p.y, p.z, p.w);
+        q.k = make_int4(k.x, k.y, k.z, k.w);
+        q.v = make_int4(v.x, v.y, v.z, v.w);
+        q.t0 = make_longlong2(t0.x, t0.y);
+        q.t1 = make_longlong2(t1.x, t1.y);
+    } else {
+        q.p = reinterpret_cast<const int4 *>(c.partition)[qi];
+        q.k = reinterpret_cast<const int4 *>(c.key_len)[qi];
+        q.v = reinterpret_cast<const int4 *>(c.val_len)[qi];
+        q.t0 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi];
+        q.t1 = reinterpret_cast<const longlong2 *>(c.ts_ms)[2 * qi + 1];
+    }
 }
 
 struct LaneState {
@@ -123,7 +141,7 @@ __device__ __forceinline__ void accumulate(uint32_t part, int32_t kl, int32_t vl
     }
 }
 
-template <int VARIANT>
+template <int VARIANT, bool NT>
 __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t n, uint32_t P,
                                                         uint32_t rep_log2,
                                                         uint64_t *__restrict__ partials)
@@ -195,13 +213,13 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
     Quad cur, nxt;
     uint64_t qi = tile * kWG + tid;
     bool cur_valid = (tile < ntiles) && (qi < nquads);
-    if (cur_valid) load_quad(cur, c, qi);
+    if (cur_valid) load_quad<NT>(cur, c, qi);
 
     while (tile < ntiles) { // uniform per workgroup
         const uint64_t ntile = tile + gridDim.x;
         const uint64_t nqi = ntile * kWG + tid;
         const bool nxt_valid = (ntile < ntiles) && (nqi < nquads);
-        if (nxt_valid) load_quad(nxt, c, nqi);
+        if (nxt_valid) load_quad<NT>(nxt, c, nqi);
 
         accumulate<VARIANT>((uint32_t)cur.p.x, cur.k.x, cur.v.x, cur.t0.x, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
         accumulate<VARIANT>((uint32_t)cur.p.y, cur.k.y, cur.v.y, cur.t0.y, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
@@ -417,6 +435,30 @@ __global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t
     }
 }
 
+// Ablation kernels (alive_variant 8 / 9): hash only (h -> scratch) and table update only
+// (h <- scratch).  Used to attribute time; the pair is also a valid two-phase implementation.
+__global__ __launch_bounds__(kWG) void kta_alive_hash_only(AliveColumns c, uint64_t n, uint32_t *__restrict__ hout)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
+        const int32_t kl = c.key_len[i];
+        hout[i] = kl < 0 ? 0u : fnv32_global(c.key_bytes + c.key_off[i], (uint32_t)kl);
+    }
+}
+
+__global__ __launch_bounds__(kWG) void kta_alive_apply_only(AliveColumns c, uint64_t n, uint64_t base_seq,
+                                                            const uint32_t *__restrict__ hin,
+                                                            unsigned long long *__restrict__ table)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
+        if (c.key_len[i] < 0) continue;
+        const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
+        const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
+        atomicMax(&table[hin[i]], v);
+    }
+}
+
 __global__ __launch_bounds__(kWG) void kta_fnv32(const uint8_t *key_bytes, const uint32_t *key_off,
                                                  const int32_t *key_len, uint64_t n, uint32_t *out)
 {
@@ -467,16 +509,21 @@ __global__ __launch_bounds__(kWG) void kta_alive_bitmap(const unsigned long long
 ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant)
 {
     ScanPlan pl;
-    pl.variant = (req_variant == 1 || req_variant == 9) ? (uint32_t)req_variant : 0u;
+    // req_variant: low bits 0 = three LDS atomics, 1 = packed, 9 = loads only; +16 = non-temporal loads
+    const int base = req_variant & 15;
+    pl.nontemporal = (req_variant & 16) != 0;
+    pl.variant = (base == 1 || base == 9) ? (uint32_t)base : 0u;
     const uint32_t arrays = pl.variant == 1 ? 4u : 3u;
-    // LDS budget per workgroup: 32 KiB keeps 5 workgroups (20 waves) per CU resident.
+    // LDS budget per workgroup: 32 KiB (4 workgroups = 16 waves per CU can be resident).
     const uint32_t budget_slots = (32u * 1024u) / (8u * arrays);
     uint32_t rep_log2 = 0;
     while (rep_log2 < 6 && (P << (rep_log2 + 1)) <= budget_slots) rep_log2++;
     pl.rep_log2 = rep_log2;
     pl.lds_bytes = (P << rep_log2) * 8u * arrays;
     const uint64_t ntiles = ((n >> 2) + kWG - 1) / kWG;
-    uint64_t wgs = req_workgroups > 0 ? (uint64_t)req_workgroups : (uint64_t)cu_count * 5u;
+    // 3 workgroups (12 waves) per CU saturate HBM (measured: 2-3 per CU best, more is slower), and
+    // every workgroup is resident at once, so the static round-robin tile deal stays balanced.
+    uint64_t wgs = req_workgroups > 0 ? (uint64_t)req_workgroups : (uint64_t)cu_count * 3u;
     if (wgs > ntiles) wgs = ntiles;
     if (wgs < 1) wgs = 1;
     pl.workgroups = (uint32_t)wgs;
@@ -487,17 +534,14 @@ hipError_t launch_metrics_scan(const ScanPlan &pl, const ScanColumns &c, uint64_
                                uint64_t *partials, hipStream_t s)
 {
     dim3 grid(pl.workgroups), block(kWG);
+#define KTA_SCAN(V, NT) \
+    hipLaunchKernelGGL((kta_metrics_scan<V, NT>), grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials)
     switch (pl.variant) {
-    case 1:
-        hipLaunchKernelGGL(kta_metrics_scan<1>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
-        break;
-    case 9:
-        hipLaunchKernelGGL(kta_metrics_scan<9>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
-        break;
-    default:
-        hipLaunchKernelGGL(kta_metrics_scan<0>, grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials);
-        break;
+    case 1: if (pl.nontemporal) KTA_SCAN(1, true); else KTA_SCAN(1, false); break;
+    case 9: if (pl.nontemporal) KTA_SCAN(9, true); else KTA_SCAN(9, false); break;
+    default: if (pl.nontemporal) KTA_SCAN(0, true); else KTA_SCAN(0, false); break;
     }
+#undef KTA_SCAN
     return hipGetLastError();
 }
 
@@ -519,15 +563,20 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s)
 }
 
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, hipStream_t s)
+                               int workgroups, int variant, uint32_t *scratch, hipStream_t s)
 {
-    (void)variant;
     uint64_t wgs = (n + kWG - 1) / kWG;
     const uint64_t cap = workgroups > 0 ? (uint64_t)workgroups : 256ull * 8ull;
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq,
-                       reinterpret_cast<unsigned long long *>(table));
+    unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
+    if (variant == 8 && scratch) {
+        hipLaunchKernelGGL(kta_alive_hash_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, scratch);
+    } else if (variant == 9 && scratch) {
+        hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t);
+    } else {
+        hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t);
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,146 @@
+"""world_size-2 gloo tests (CPU) of the N > 1 path: the partition->rank map and the exchange step
+(one all-reduce SUM over the counter prefix + one all-reduce MAX over the four extrema) reproduce the
+unsharded result; the alive-table MAX merge reproduces sequential last-writer-wins.  Shard-local
+results are produced by the oracle here (no GPU); the reduction code is the product's."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import kafka_topic_analyzer_amd as kta
+from kafka_topic_analyzer_amd import _native as N
+from kafka_topic_analyzer_amd import distributed as D
+from helpers import NOW, random_cols
+from oracle_c import Oracle
+
+I64_MAX, I64_MIN = np.iinfo(np.int64).max, np.iinfo(np.int64).min
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def oracle_vector(cols, P, now=NOW):
+    """Encode the oracle's result for `cols` in the device counter-vector layout (kta_hip.h)."""
+    o = Oracle(now)
+    n = len(cols["partition"])
+    if n:
+        o.run_soa(cols)
+    v = np.zeros(P * 7 + 8, dtype=np.int64)
+    v[:P * 7] = o.counters(P).astype(np.int64).ravel()
+    g = v[P * 7:]
+    ts = np.where(cols["ts_ms"] == -1, 0, cols["ts_ms"]) if n else np.zeros(0, np.int64)
+    live = cols["val_len"] >= 0 if n else np.zeros(0, bool)
+    sizes = (np.maximum(cols["key_len"], 0).astype(np.int64) + np.maximum(cols["val_len"], 0))[live] if n else []
+    g[N.KTA_G_RECORDS] = n
+    g[N.KTA_G_NOT_MIN_TS_MS] = ~(int(ts.min()) if n else I64_MAX)
+    g[N.KTA_G_MAX_TS_MS] = int(ts.max()) if n else I64_MIN
+    g[N.KTA_G_NOT_SMALLEST] = ~(int(min(sizes)) if len(sizes) else I64_MAX)
+    g[N.KTA_G_LARGEST] = int(max(sizes)) if len(sizes) else 0
+    return v, o
+
+
+def _worker(rank, world, port, P, seed, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)
+        cols = random_cols(rng, 20000, P, key_space=300)  # same global topic on every rank
+        mine = np.array([D.partition_owner(int(p), world) == rank for p in cols["partition"]])
+        shard = {k: (v[mine] if k != "key_bytes" else v) for k, v in cols.items()}
+        vec, _ = oracle_vector(shard, P)
+        t = torch.from_numpy(vec.copy())
+        D.allreduce_counter_vector(t, P)
+        # alive table merge on a 2^16-slot stand-in (slot = h & 0xffff), seq = global index
+        tbl = np.zeros(1 << 16, dtype=np.int64)
+        idx = np.nonzero(mine & (cols["key_len"] >= 0))[0]
+        kb = cols["key_bytes"].tobytes()
+        from oracle_c import fnv32
+        for i in idx:
+            k = kb[int(cols["key_off"][i]):int(cols["key_off"][i]) + int(cols["key_len"][i])]
+            slot = fnv32(k) & 0xFFFF
+            val = ((int(i) + 1) << 1) | (1 if cols["val_len"][i] >= 0 else 0)
+            tbl[slot] = max(tbl[slot], val)
+        tt = torch.from_numpy(tbl)
+        D.allreduce_alive_table(tt, chunk_elems=1 << 14)
+        q.put((rank, t.numpy().copy(), tt.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P,seed", [(8, 1), (5, 2)])
+def test_two_rank_exchange_equals_unsharded(P, seed):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, P, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(seed)
+    cols = random_cols(rng, 20000, P, key_space=300)
+    whole, o = oracle_vector(cols, P)
+    lib = N.load()
+    for _, vec, tbl in outs:  # every rank ends with the global result
+        assert np.array_equal(vec, whole)
+        res = N.KtaResult()
+        c = np.zeros((P, 7), np.uint64)
+        assert lib.kta_decode_vector(vec.ctypes.data, P, 0, C.byref(res), c.ctypes.data) == N.KTA_OK
+        assert np.array_equal(c, o.counters(P))
+        mm = kta.MessageMetrics(res, c, NOW)
+        assert mm.earliest_message() == o.earliest() and mm.latest_message() == o.latest()
+        assert mm.smallest_message() == o.get("smallest_message")
+        assert mm.largest_message() == o.get("largest_message")
+        assert mm.overall_size() == o.get("overall_size")
+    # sequential last-writer-wins on the same 2^16-slot stand-in
+    from oracle_c import fnv32
+    want = {}
+    kb = cols["key_bytes"].tobytes()
+    for i in range(len(cols["partition"])):
+        if cols["key_len"][i] >= 0:
+            k = kb[int(cols["key_off"][i]):int(cols["key_off"][i]) + int(cols["key_len"][i])]
+            want[fnv32(k) & 0xFFFF] = cols["val_len"][i] >= 0
+    for _, _, tbl in outs:
+        alive = {int(s) for s in np.nonzero(tbl & 1)[0]}
+        assert alive == {s for s, a in want.items() if a}
+        assert set(np.nonzero(tbl)[0].tolist()) == set(want.keys())
+
+
+def test_host_merge_matches_collective_semantics():
+    """kta_merge_vectors (the host statement of the reduction) == SUM prefix + MAX suffix."""
+    lib = N.load()
+    rng = np.random.default_rng(3)
+    P = 6
+    cols = random_cols(rng, 5000, P)
+    half = len(cols["partition"]) // 2
+    a, _ = oracle_vector({k: (v[:half] if k != "key_bytes" else v) for k, v in cols.items()}, P)
+    b, _ = oracle_vector({k: (v[half:] if k != "key_bytes" else v) for k, v in cols.items()}, P)
+    whole, _ = oracle_vector(cols, P)
+    k = D.sum_prefix_len(P)
+    manual = np.concatenate([a[:k] + b[:k], np.maximum(a[k:], b[k:])])
+    assert np.array_equal(manual, whole)
+    acc = a.copy()
+    assert lib.kta_merge_vectors(acc.ctypes.data, b.ctypes.data, P) == N.KTA_OK
+    assert np.array_equal(acc, whole)
+
+
+def test_shard_spec_is_rank_disjoint():
+    sp, _ = kta.synth_preset("c4")
+    a = kta.synth_fill_host(D.shard_spec(sp, 0, 2), 0, 5000)
+    b = kta.synth_fill_host(D.shard_spec(sp, 1, 2), 0, 5000)
+    assert (a["partition"] % 2 == 0).all() and (b["partition"] % 2 == 1).all()
+    assert sp.shard_count == 1  # the caller's spec is untouched
