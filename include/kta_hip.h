@@ -207,6 +207,18 @@ int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes_host, const uint32_t
                      const int32_t *key_len_host, uint64_t n, uint64_t n_key_bytes,
                      uint32_t *hash_out_host);
 
+/* ---- report -------------------------------------------------------------------------- */
+/* Render what the reference prints after the scan (src/main.rs:123-178) from a counter vector:
+ * the text block, chrono's `DateTime<Utc>` Display, `{:.4}` of the f32 dirty ratio and the
+ * prettytable.  `now_*` stands in for Utc::now() at MessageMetrics::new (metric.rs:39);
+ * start/end offsets may be NULL (0 / per-partition record count).  *out_len receives the full
+ * length; the text is truncated to out_cap-1 bytes + NUL.  Returns KTA_ERR_DIV_BY_ZERO where
+ * the reference panics (a partition with key bytes but no alive record, metric.rs:135). */
+int kta_render_report(const char *topic, uint64_t duration_secs, const uint64_t *vec,
+                      uint32_t n_partitions, int count_alive_keys, int64_t now_sec, uint32_t now_ns,
+                      const int64_t *start_offsets, const int64_t *end_offsets, char *out,
+                      size_t out_cap, size_t *out_len);
+
 /* ---- profiling hooks --------------------------------------------------------------- */
 /* With kta_set_timing(ctx, 1) every kernel launch is bracketed by a pair of HIP events recorded
  * on the compute stream (no host synchronisation while recording).  kta_kernel_time_stats waits

@@ -22,7 +22,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libkta_oracle.so")
 
 HIP_SOURCES = ["kta_kernels.hip", "kta_api.hip", "kta_synth.hip"]
-HOST_SOURCES = ["host/metric.cpp", "host/report.cpp", "host/main.cpp"]
+LIB_HOST_SOURCES = ["host/metric.cpp", "host/report.cpp"]  # C++ host mirror, inside libkta_hip.so
+HOST_SOURCES = ["host/main.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
                "-Wno-unused-result"]
 
@@ -56,16 +57,18 @@ def _deps(sources):
 
 
 def build_lib(force: bool = False) -> str:
-    deps = _deps(HIP_SOURCES)
+    deps = _deps(HIP_SOURCES + LIB_HOST_SOURCES)
     if not force and _newer(LIB, deps):
         return LIB
     hipcc = _hipcc()
     objs = []
-    for s in HIP_SOURCES:
+    for s in HIP_SOURCES + LIB_HOST_SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.splitext(src)[0] + ".o"
         if force or not _newer(obj, deps):
-            _run([hipcc, *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+            arch = ["--offload-arch=gfx950"] if s.endswith(".hip") else []
+            flags = [f for f in HIPCC_FLAGS if not f.startswith("--offload-arch")]
+            _run([hipcc, *arch, *flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj])
         objs.append(obj)
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
           "-Wl,-rpath,/opt/rocm/lib"])

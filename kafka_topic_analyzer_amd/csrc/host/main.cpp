@@ -1,0 +1,308 @@
+// main.cpp — `kta-analyzer`: the reference's command line (src/main.rs:29-180) in front of the
+// MI355X metric-accumulation path.  Flags, defaults and the printed report are the reference's:
+//
+//   -t, --topic <TOPIC>                         (required)           main.rs:37-44
+//   -b, --bootstrap-server <BOOTSTRAP_SERVER>   (required)           main.rs:45-52
+//       --librdkafka <LIBRDKAFKA>               k=v,k=v              main.rs:53-59, 84-92
+//   -c, --count-alive-keys                                           main.rs:60-66, 77-80
+//   -h/--help, -V/--version ("0.4.1", main.rs:35)
+//
+// The consume loop (src/kafka.rs) needs librdkafka and a broker, neither of which exists in this
+// build, so the record source is chosen by the scheme of --bootstrap-server:
+//     synthetic://<c1..c5>[?records=N]   the synthetic topic of include/kta_synth.h
+//     dump://<path>                      a KTADUMP1 topic dump (host/dump.hpp)
+// anything else is refused.  Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
+// kta.batch=N, kta.write_dump=<path>), so no flag is added or renamed.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dump.hpp"
+#include "kta_synth.h"
+#include "metric.hpp"
+
+namespace {
+
+const char *kAbout = "Kafka Topic Analyzer 0.4.1";
+
+void print_help()
+{
+    printf("%s\n\nUSAGE:\n    kafka-topic-analyzer [FLAGS] [OPTIONS] --bootstrap-server <BOOTSTRAP_SERVER> --topic <TOPIC>\n\n"
+           "FLAGS:\n"
+           "    -c, --count-alive-keys    Counts the effective number of alive keys in a log compacted topic by saving the "
+           "state for each key in a local file and counting the result at the end of the read operation.A key is 'alive' "
+           "when it is present and has a non-null value in it's latest-offset version\n"
+           "    -h, --help                Prints help information\n"
+           "    -V, --version             Prints version information\n\n"
+           "OPTIONS:\n"
+           "    -b, --bootstrap-server <BOOTSTRAP_SERVER>    Bootstrap server(s) to work with, comma separated\n"
+           "        --librdkafka <LIBRDKAFKA>                Options to pass into the underlying librdkafka, comma "
+           "seperated key=value pairs\n"
+           "    -t, --topic <TOPIC>                          The topic to analyze\n",
+           kAbout);
+}
+
+[[noreturn]] void usage_error(const std::string &msg)
+{
+    fprintf(stderr, "error: %s\n\nUSAGE:\n    kafka-topic-analyzer [FLAGS] [OPTIONS] --bootstrap-server "
+                    "<BOOTSTRAP_SERVER> --topic <TOPIC>\n\nFor more information try --help\n", msg.c_str());
+    exit(1);
+}
+
+[[noreturn]] void rust_panic(const std::string &msg, const std::string &loc)
+{
+    fprintf(stderr, "thread 'main' panicked at '%s', %s\n", msg.c_str(), loc.c_str());
+    exit(101);
+}
+
+struct Args {
+    std::string topic, bootstrap, librdkafka;
+    bool has_topic = false, has_bootstrap = false, has_librdkafka = false;
+    int count_alive_occurrences = 0;
+};
+
+Args parse_args(int argc, char **argv)
+{
+    Args a;
+    auto take = [&](int &i, const std::string &name, const char *inline_val) -> std::string {
+        if (inline_val) return inline_val;
+        if (i + 1 >= argc) usage_error("The argument '" + name + "' requires a value but none was supplied");
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string s = argv[i];
+        const char *eq = nullptr;
+        std::string name = s;
+        if (s.rfind("--", 0) == 0) {
+            size_t p = s.find('=');
+            if (p != std::string::npos) { name = s.substr(0, p); eq = argv[i] + p + 1; }
+        } else if (s.size() > 2 && s[0] == '-' && s[1] != '-') {
+            name = s.substr(0, 2);
+            eq = argv[i] + 2;
+            if (name == "-c" || name == "-h" || name == "-V") { eq = nullptr; name = s; }
+        }
+        if (name == "-t" || name == "--topic") { a.topic = take(i, "--topic <TOPIC>", eq); a.has_topic = true; }
+        else if (name == "-b" || name == "--bootstrap-server") { a.bootstrap = take(i, "--bootstrap-server <BOOTSTRAP_SERVER>", eq); a.has_bootstrap = true; }
+        else if (name == "--librdkafka") { a.librdkafka = take(i, "--librdkafka <LIBRDKAFKA>", eq); a.has_librdkafka = true; }
+        else if (name == "-c" || name == "--count-alive-keys") a.count_alive_occurrences++;
+        else if (name == "-h" || name == "--help") { print_help(); exit(0); }
+        else if (name == "-V" || name == "--version") { printf("%s\n", kAbout); exit(0); }
+        else usage_error("Found argument '" + s + "' which wasn't expected, or isn't valid in this context");
+    }
+    if (!a.has_topic || !a.has_bootstrap) {
+        std::string m = "The following required arguments were not provided:";
+        if (!a.has_bootstrap) m += "\n    --bootstrap-server <BOOTSTRAP_SERVER>";
+        if (!a.has_topic) m += "\n    --topic <TOPIC>";
+        usage_error(m);
+    }
+    return a;
+}
+
+// main.rs:84-92: split(",") then split('=') taking the first two pieces; a pair without '=' panics
+std::map<std::string, std::string> parse_librdkafka(const Args &a)
+{
+    std::map<std::string, std::string> m;
+    if (!a.has_librdkafka) return m;
+    size_t pos = 0;
+    const std::string &s = a.librdkafka;
+    while (true) {
+        size_t comma = s.find(',', pos);
+        std::string kv = s.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        size_t eq = kv.find('=');
+        if (eq == std::string::npos)
+            rust_panic("called `Option::unwrap()` on a `None` value", "src/main.rs:89:48");
+        size_t eq2 = kv.find('=', eq + 1);
+        m[kv.substr(0, eq)] = kv.substr(eq + 1, eq2 == std::string::npos ? std::string::npos : eq2 - eq - 1);
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+    }
+    return m;
+}
+
+void check(int rc, kta_ctx *ctx, const char *what)
+{
+    if (rc != KTA_OK) {
+        fprintf(stderr, "%s failed: %s\n", what, kta_last_error(ctx));
+        exit(2);
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Args args = parse_args(argc, argv);
+    const auto start_time = std::chrono::steady_clock::now();                       // main.rs:69
+    const bool count_alive = args.count_alive_occurrences == 1;                     // main.rs:77-80 (-c -c disables)
+    std::map<std::string, std::string> cfg = parse_librdkafka(args);                // main.rs:84-92
+    const int device = cfg.count("kta.device") ? atoi(cfg["kta.device"].c_str()) : 0;
+    const uint64_t batch = cfg.count("kta.batch") ? strtoull(cfg["kta.batch"].c_str(), nullptr, 10) : (1ull << 20);
+
+    // ---- the record source (stands in for TopicAnalyzer, src/kafka.rs) ------------------------------
+    const std::string &b = args.bootstrap;
+    bool synthetic = b.rfind("synthetic://", 0) == 0, dump = b.rfind("dump://", 0) == 0;
+    if (!synthetic && !dump) {
+        fprintf(stderr, "Consumer creation failed: this build has no librdkafka; --bootstrap-server must be "
+                        "synthetic://<c1..c5>[?records=N] or dump://<path>\n");
+        return 101;
+    }
+    kta_synth_spec spec{};
+    uint64_t n_records = 0;
+    kta::DumpHeader hdr;
+    kta::DumpReader *reader = nullptr;
+    if (synthetic) {
+        std::string rest = b.substr(strlen("synthetic://"));
+        std::string preset = rest.substr(0, rest.find('?'));
+        if (kta_synth_preset(preset.c_str(), &spec, &n_records) != KTA_OK) {
+            fprintf(stderr, "Error fetching metadata: unknown synthetic topic '%s'\n", preset.c_str());
+            return 101;
+        }
+        size_t q = rest.find("records=");
+        if (q != std::string::npos) n_records = strtoull(rest.c_str() + q + 8, nullptr, 10);
+        hdr.n_partitions = spec.n_partitions;
+        hdr.n_records = n_records;
+    } else {
+        reader = new kta::DumpReader(b.substr(strlen("dump://")));
+        if (!reader->ok() || !reader->read_header(&hdr)) {
+            fprintf(stderr, "Error fetching metadata: cannot read topic dump '%s'\n", b.c_str() + 7);
+            return 101;
+        }
+    }
+    const uint32_t P = hdr.n_partitions;
+
+    kta::HipMetricHandler *handler = nullptr;
+    try {
+        handler = new kta::HipMetricHandler((int32_t)P, count_alive, device, batch, 0);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 2;
+    }
+    kta_ctx *ctx = handler->ctx();
+
+    std::vector<int64_t> start_offsets(P, 0), end_offsets(P, 0);
+    if (dump) { start_offsets = hdr.start_offsets; end_offsets = hdr.end_offsets; }
+    else if (n_records > 0) {
+        // offsets of a synthetic topic: 0 .. per-partition record count; known only after the scan,
+        // so the emptiness test of main.rs:98-101 uses the record count
+        std::fill(end_offsets.begin(), end_offsets.end(), 1);
+    }
+    if (std::all_of(end_offsets.begin(), end_offsets.end(), [](int64_t v) { return v == 0; })) {  // main.rs:98-101
+        fprintf(stderr, "[ERROR] Given topic has no content, no analysis possible. Exiting.\n");
+        return 254;  // exit(-2)
+    }
+    std::vector<int32_t> partitions(P);                                             // main.rs:103-106
+    for (uint32_t p = 0; p < P; p++) partitions[p] = (int32_t)p;
+
+    printf("Subscribing to %s\n", args.topic.c_str());                              // kafka.rs:88
+    printf("Starting message consumption...\n");                                    // kafka.rs:91
+    fflush(stdout);
+
+    kta::DumpWriter *writer = nullptr;
+    std::vector<kta::DumpBatch> to_write;
+    const bool write_dump = cfg.count("kta.write_dump") != 0;
+
+    uint64_t seq = 0;
+    if (synthetic) {
+        while (seq < n_records) {
+            kta_batch hb;
+            check(kta_batch_acquire(ctx, &hb), ctx, "kta_batch_acquire");
+            uint64_t n = std::min<uint64_t>(hb.capacity, n_records - seq), kb = 0;
+            if (!count_alive && !write_dump) { hb.key_off = nullptr; hb.key_bytes = nullptr; }
+            int rc = kta_synth_fill_host(&spec, seq, n, &hb, &kb);
+            while (rc == KTA_ERR_CAPACITY && n > 1) {  // key bytes did not fit: shrink the batch
+                n /= 2;
+                rc = kta_synth_fill_host(&spec, seq, n, &hb, &kb);
+            }
+            check(rc, ctx, "kta_synth_fill_host");
+            if (write_dump) {
+                kta::DumpBatch db;
+                db.n = n; db.n_key_bytes = hb.key_bytes ? kb : 0;
+                db.partition.assign(hb.partition, hb.partition + n);
+                db.key_len.assign(hb.key_len, hb.key_len + n);
+                db.val_len.assign(hb.val_len, hb.val_len + n);
+                db.ts_ms.assign(hb.ts_ms, hb.ts_ms + n);
+                if (hb.key_off) db.key_off.assign(hb.key_off, hb.key_off + n); else db.key_off.assign(n, 0);
+                if (hb.key_bytes) db.key_bytes.assign(hb.key_bytes, hb.key_bytes + kb);
+                to_write.push_back(std::move(db));
+            }
+            check(kta_batch_submit(ctx, n, kb, seq), ctx, "kta_batch_submit");
+            seq += n;
+        }
+    } else {
+        kta::DumpBatch db;
+        for (uint64_t bi = 0; bi < hdr.n_batches; bi++) {
+            if (!reader->read_batch(&db)) {
+                fprintf(stderr, "[WARN] Kafka error: truncated topic dump\n");      // kafka.rs:95-97: warn and go on
+                break;
+            }
+            uint64_t done = 0;
+            while (done < db.n) {
+                kta_batch hb;
+                check(kta_batch_acquire(ctx, &hb), ctx, "kta_batch_acquire");
+                uint64_t n = std::min<uint64_t>(hb.capacity, db.n - done), kb = 0;
+                if (count_alive) {  // re-pack this chunk's keys
+                    uint64_t m = 0;
+                    for (; m < n; m++) {
+                        const uint64_t kl = db.key_len[done + m] > 0 ? (uint64_t)db.key_len[done + m] : 0;
+                        if (kb + kl > hb.key_bytes_capacity) break;
+                        hb.key_off[m] = (uint32_t)kb;
+                        if (kl) memcpy(hb.key_bytes + kb, db.key_bytes.data() + db.key_off[done + m], kl);
+                        kb += kl;
+                    }
+                    n = m;
+                    if (n == 0) { fprintf(stderr, "key larger than the staging capacity\n"); return 2; }
+                }
+                memcpy(hb.partition, db.partition.data() + done, 4 * n);
+                memcpy(hb.key_len, db.key_len.data() + done, 4 * n);
+                memcpy(hb.val_len, db.val_len.data() + done, 4 * n);
+                memcpy(hb.ts_ms, db.ts_ms.data() + done, 8 * n);
+                check(kta_batch_submit(ctx, n, kb, seq), ctx, "kta_batch_submit");
+                seq += n;
+                done += n;
+            }
+        }
+    }
+    fprintf(stderr, "done\n");                                                      // kafka.rs:136 (spinner)
+
+    try {
+        handler->finish();                       // where main.rs:121 is: the trait has no end-of-stream hook
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 2;
+    }
+    const kta::MessageMetrics &metrics = handler->metrics();
+    if (synthetic)
+        for (uint32_t p = 0; p < P; p++) end_offsets[p] = (int64_t)metrics.total((int32_t)p);
+    if (write_dump) {
+        writer = new kta::DumpWriter(cfg["kta.write_dump"]);
+        kta::DumpHeader wh = hdr;
+        wh.n_batches = to_write.size();
+        wh.start_offsets = start_offsets;
+        wh.end_offsets = end_offsets;
+        bool ok = writer->ok() && writer->write_header(wh);
+        for (auto &db : to_write)
+            ok = ok && writer->write_batch(db.n, db.n_key_bytes, db.partition.data(), db.key_len.data(),
+                                           db.val_len.data(), db.ts_ms.data(), db.key_off.data(), db.key_bytes.data());
+        delete writer;
+        if (!ok) fprintf(stderr, "[WARN] could not write topic dump %s\n", cfg["kta.write_dump"].c_str());
+    }
+
+    const uint64_t duration_secs = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(
+                                       std::chrono::steady_clock::now() - start_time).count();  // main.rs:121
+    try {
+        std::string text = kta::render_report(args.topic, duration_secs, metrics, handler->log_compaction(),
+                                              partitions, start_offsets, end_offsets);
+        fputs(text.c_str(), stdout);
+    } catch (const kta::RustPanic &p) {
+        rust_panic(p.what(), p.location);
+    }
+    delete handler;
+    delete reader;
+    return 0;
+}
