@@ -47,6 +47,16 @@ class _DevVec:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
+def _traffic(kernel, records_per_launch):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or None when the
+    file has no entry for this kernel at this launch size."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+        return e["hbm_bytes_per_launch"] if e["records_per_launch"] == records_per_launch else None
+    except Exception:
+        return None
+
+
 def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
     """Time the C oracle (1 thread) over the first n_sample records of the resident batch."""
     from oracle_c import Oracle
@@ -94,7 +104,7 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
                         "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": None,
+                        "traffic": _traffic("kta_alive_update", n_records),
                         "note": "random 8-byte atomicMax RMWs into the 32 GiB last-writer table dominate; "
                                 "their traffic is not part of the algorithmic bytes"}}
     m = min(n_records, 1 << 24)
@@ -214,15 +224,7 @@ def main():
         total_records = n * world * args.steps
         scan_ms = avg_ms[0]
         achieved = BYTES_PER_RECORD * n / (scan_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("records_per_launch") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = _traffic("kta_metrics_scan", n)
         line = {
             "metric": METRIC, "value": total_records / elapsed, "unit": "records/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
