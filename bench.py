@@ -160,7 +160,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libkta_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # KTA_BENCH_FORCE_COLLECTIVES=1: run the exchange step even with one rank (exercises the RCCL path
+    # on a 1-GPU box; the line then carries "forced_collectives": true and is not a headline number)
+    force_coll = os.environ.get("KTA_BENCH_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ
+    exchange = world > 1 or force_coll
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -183,13 +187,13 @@ def main():
         """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
         h.reset()                                          # MessageMetrics::new state (tiny kernel)
         h.submit_device(batch, n, 0, which=1)              # scan + fold on the library's stream
-        if world > 1:
+        if exchange:
             h.sync()                                       # shard result complete before the collectives
             D.allreduce_counter_vector(vec, P)             # C1 SUM (counters) + C2 MAX (four extrema)
             torch.cuda.current_stream().synchronize()
 
     def barrier():
-        if world > 1:
+        if exchange:
             dist.barrier()
         h.sync()
         torch.cuda.synchronize()
@@ -207,7 +211,7 @@ def main():
     avg_ms, cnt = h.kernel_time_stats()
     h.set_timing(False)
 
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -234,7 +238,8 @@ def main():
                                    "~256 B), partitions sharded p % n_gpus", "records_per_gpu": n,
                        "total_records_per_step": n * world, "partitions": P, "partition_order": args.part_mode,
                        "bytes_per_record": BYTES_PER_RECORD, "parallelism": f"partition-sharded x{world}",
-                       "exchange": "none (1 GPU)" if world == 1 else
+                       "forced_collectives": bool(force_coll),
+                       "exchange": "none (1 GPU)" if not exchange else
                                    "per step: all-reduce SUM u64[%d] + all-reduce MAX i64[4] (RCCL)" % n_sum},
             "roofline": {"bound": "hbm", "kernel": "kta_metrics_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -251,7 +256,7 @@ def main():
             line["alive_pass"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                    args.alive_records, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

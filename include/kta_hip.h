@@ -200,8 +200,15 @@ int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t n_partition
  * 512 MiB) into host memory — the same layout as BitSet's storage (metric.rs:263). */
 int kta_export_alive_bitmap(kta_ctx *ctx, void *dst_host_512MiB);
 /* Device pointer of the last-writer table: u64[2^32], entry = ((seq+1)<<1)|alive, 0 = never
- * written.  Element-wise MAX across GPUs merges shards exactly. */
+ * written.  Element-wise MAX across GPUs merges shards exactly (then call
+ * kta_alive_table_modified).  sum_all_alive is normally kept as a running count by the update
+ * kernel (returning atomicMax: +flag(new) - flag(old) whenever an entry is replaced), so
+ * kta_finish does not scan the table. */
 int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
+/* Tell the context that the table was changed behind its back (e.g. merged with other GPUs' tables
+ * by an all-reduce MAX): the running alive count is dropped and the next kta_finish recounts by
+ * scanning the table. */
+int kta_alive_table_modified(kta_ctx *ctx);
 /* Hash `n` keys on the device with the reference's FNV variant (fnv32.rs:92-101). */
 int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes_host, const uint32_t *key_off_host,
                      const int32_t *key_len_host, uint64_t n, uint64_t n_key_bytes,

@@ -256,6 +256,9 @@ class HipMetricHandler:
         self._check(self._lib.kta_alive_table(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def alive_table_modified(self) -> None:
+        self._check(self._lib.kta_alive_table_modified(self._ctx))
+
     def export_alive_bitmap(self) -> np.ndarray:
         """The alive set as a 2^32-bit bitmap: uint32[2^27], bit h%32 of word h//32."""
         bm = np.empty(1 << 27, dtype=np.uint32)
@@ -286,7 +289,7 @@ class HipMetricHandler:
     def last_kernel_ms(self):
         return self.kernel_time_stats()[0]
 
-    def set_tuning(self, scan_workgroups=0, scan_variant=16, alive_workgroups=0, alive_variant=0) -> None:
+    def set_tuning(self, scan_workgroups=0, scan_variant=16, alive_workgroups=0, alive_variant=1) -> None:
         self._check(self._lib.kta_set_tuning(self._ctx, scan_workgroups, scan_variant, alive_workgroups,
                                              alive_variant))
 

@@ -37,6 +37,8 @@ struct kta_ctx {
     uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
     uint32_t max_rows = 0;
     uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
+    int64_t *d_alive_running = nullptr; // running alive count (alive_variant 1)
+    bool running_valid = true;          // false once an update ran without counting
     uint32_t *d_hash_scratch = nullptr; // ablation variants only
     uint64_t hash_scratch_cap = 0;
     std::vector<Stage> stages;
@@ -46,7 +48,7 @@ struct kta_ctx {
     uint64_t fill_n = 0, fill_kb = 0; // kta_handle_message fill state
     uint64_t next_seq = 0;
     // tuning / profiling
-    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 0; // 16: non-temporal loads
+    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 1; // 16: non-temporal loads; 1: running alive count
     bool timing = false;
     // HIP-event pairs recorded around each kernel on the compute stream (no host sync while
     // recording); drained by kta_kernel_time_stats.  kind: 0 scan, 1 fold, 2 alive update.
@@ -215,12 +217,15 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         if ((ctx->alive_variant == 8 || ctx->alive_variant == 9) && ctx->hash_scratch_cap < n) {
             KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
             if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
+    if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
             ctx->d_hash_scratch = nullptr;
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;
         }
+        if (ctx->alive_variant != 1) ctx->running_valid = false;
         KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
-                                              ctx->alive_variant, ctx->d_hash_scratch, ctx->s_compute));
+                                              ctx->alive_variant, ctx->d_hash_scratch, ctx->d_alive_running,
+                                              ctx->s_compute));
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     return KTA_OK;
@@ -229,8 +234,11 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
 int reset_state(kta_ctx *ctx)
 {
     KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->s_compute));
-    if (ctx->alive)
+    if (ctx->alive) {
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
+        KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
+        ctx->running_valid = true;
+    }
     ctx->next_seq = 0;
     return KTA_OK;
 }
@@ -295,7 +303,10 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     ctx->max_rows = (uint32_t)ctx->cu_count * 8u;
     KTA_TRY(hipMalloc((void **)&ctx->d_partials,
                       (size_t)ctx->max_rows * kta::scan_row_len(ctx->P) * sizeof(uint64_t)));
-    if (ctx->alive) KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+    if (ctx->alive) {
+        KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+        KTA_TRY(hipMalloc((void **)&ctx->d_alive_running, sizeof(int64_t)));
+    }
 #undef KTA_TRY
     rc = reset_state(ctx);
     if (rc != KTA_OK) return bail(rc);
@@ -320,6 +331,7 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
+    if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
     if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
     for (auto &pool : ctx->ev_pool)
         for (auto ev : pool) (void)hipEventDestroy(ev);
@@ -507,10 +519,14 @@ int kta_finish_device(kta_ctx *ctx)
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
-    if (ctx->alive)
-        KTA_HIP(ctx, kta::launch_alive_count(ctx->d_table, kta::kAliveSlots,
-                                             ctx->d_vec + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS,
-                                             ctx->s_compute));
+    if (ctx->alive) {
+        uint64_t *dst = ctx->d_vec + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
+        if (ctx->running_valid && ctx->alive_variant == 1)  // exact running count, no table scan
+            KTA_HIP(ctx, hipMemcpyAsync(dst, ctx->d_alive_running, sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                        ctx->s_compute));
+        else
+            KTA_HIP(ctx, kta::launch_alive_count(ctx->d_table, kta::kAliveSlots, dst, ctx->s_compute));
+    }
     return KTA_OK;
 }
 
@@ -607,6 +623,14 @@ int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
     *device_ptr = ctx->d_table;
     *n_u64 = (size_t)kta::kAliveSlots;
+    return KTA_OK;
+}
+
+int kta_alive_table_modified(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    ctx->running_valid = false;  // the next kta_finish recounts from the table
     return KTA_OK;
 }
 

@@ -55,9 +55,10 @@ hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_
 hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s);
 
 // K2+K3: FNV (fnv32.rs:92-101) + last-writer-wins table update (metric.rs:289-304)
-// variant 0 = fused; 8 / 9 = ablation halves (hash -> scratch, scratch -> table)
+// variant 0 = fused; 1 = fused + running alive count (returning atomics); 8 / 9 = ablation halves
+// (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, uint32_t *scratch, hipStream_t s);
+                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)

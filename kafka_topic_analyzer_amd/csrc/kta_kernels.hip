@@ -435,6 +435,38 @@ __global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t
     }
 }
 
+// Variant with a RUNNING alive count.  atomicMax returns the previous entry; when this record
+// replaces it (v > old) the number of alive slots changes by flag(v) - flag(old).  Updates to one
+// address are serialised by the memory-side atomic unit, so over any interleaving the deltas
+// telescope to flag(final) - flag(initial): the running sum is exactly sum_all_alive()
+// (metric.rs:282-284) without scanning the 32 GiB table.
+__global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c, uint64_t n, uint64_t base_seq,
+                                                                 unsigned long long *__restrict__ table,
+                                                                 long long *__restrict__ running)
+{
+    __shared__ long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    long long delta = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
+        const int32_t kl = c.key_len[i];
+        if (kl < 0) continue;
+        const uint32_t h = fnv32_global(c.key_bytes + c.key_off[i], (uint32_t)kl);
+        const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
+        const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
+        const unsigned long long old = atomicMax(&table[h], v);
+        if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) delta += __shfl_xor(delta, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = delta;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(running), (unsigned long long)t);
+    }
+}
+
 // Ablation kernels (alive_variant 8 / 9): hash only (h -> scratch) and table update only
 // (h <- scratch).  Used to attribute time; the pair is also a valid two-phase implementation.
 __global__ __launch_bounds__(kWG) void kta_alive_hash_only(AliveColumns c, uint64_t n, uint32_t *__restrict__ hout)
@@ -534,8 +566,17 @@ hipError_t launch_metrics_scan(const ScanPlan &pl, const ScanColumns &c, uint64_
                                uint64_t *partials, hipStream_t s)
 {
     dim3 grid(pl.workgroups), block(kWG);
-#define KTA_SCAN(V, NT) \
-    hipLaunchKernelGGL((kta_metrics_scan<V, NT>), grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2, partials)
+    // > 64 KiB of dynamic LDS (P > ~2700) must be opted into per kernel
+#define KTA_SCAN(V, NT)                                                                                        \
+    do {                                                                                                       \
+        if (pl.lds_bytes > 48u * 1024u) {                                                                      \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_metrics_scan<V, NT>),      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes); \
+            if (ea != hipSuccess) return ea;                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((kta_metrics_scan<V, NT>), grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2,      \
+                           partials);                                                                          \
+    } while (0)
     switch (pl.variant) {
     case 1: if (pl.nontemporal) KTA_SCAN(1, true); else KTA_SCAN(1, false); break;
     case 9: if (pl.nontemporal) KTA_SCAN(9, true); else KTA_SCAN(9, false); break;
@@ -563,7 +604,7 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s)
 }
 
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, uint32_t *scratch, hipStream_t s)
+                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s)
 {
     uint64_t wgs = (n + kWG - 1) / kWG;
     const uint64_t cap = workgroups > 0 ? (uint64_t)workgroups : 256ull * 8ull;
@@ -574,6 +615,9 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
         hipLaunchKernelGGL(kta_alive_hash_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, scratch);
     } else if (variant == 9 && scratch) {
         hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t);
+    } else if (variant == 1 && running) {
+        hipLaunchKernelGGL(kta_alive_update_counting, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
+                           reinterpret_cast<long long *>(running));
     } else {
         hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t);
     }

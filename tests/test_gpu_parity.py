@@ -225,6 +225,41 @@ def test_collision_across_partitions_and_batches(hc):
         assert res.alive_keys == want
 
 
+def test_running_alive_count_equals_table_scan(hc):
+    """The running count kept by returning atomics (default) == popcount of the table (recount), also
+    after interleaving counting and non-counting update kernels."""
+    rng = np.random.default_rng(77)
+    cols = random_cols(rng, 200000, 16, key_space=3000, tomb=0.4)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    hc.reset()
+    hc.submit_columns(**cols)
+    r_run, _ = hc.finish()               # running count
+    hc.alive_table_modified()            # force a recount from the table
+    r_scan, _ = hc.finish()
+    assert r_run.alive_keys == r_scan.alive_keys == o.alive_keys()
+    more = random_cols(rng, 50000, 16, key_space=3000, tomb=0.6)
+    o.run_soa(more)
+    hc.set_tuning(alive_variant=0)       # non-counting kernel invalidates the running count ...
+    hc.submit_columns(**more)
+    hc.set_tuning()
+    r3, _ = hc.finish()                  # ... so this finish scans
+    assert r3.alive_keys == o.alive_keys()
+
+
+def test_max_partitions_uses_large_dynamic_lds():
+    P = 4096  # 96 KiB of LDS partials per workgroup
+    rng = np.random.default_rng(41)
+    cols = random_cols(rng, 150000, P, key_space=500)
+    o = Oracle(NOW)
+    o.run_soa(cols)
+    with kta.HipMetricHandler(P, now=NOW) as h:
+        h.submit_columns(cols["partition"], cols["key_len"], cols["val_len"], cols["ts_ms"])
+        _compare(h, o, P)
+    with pytest.raises(kta.KtaError):
+        kta.HipMetricHandler(4097)
+
+
 # ------------------------------------------------------------------------------------- generator
 @pytest.mark.parametrize("preset", ["c1", "c2", "c3", "c4"])
 def test_device_generator_matches_host_generator(hc, preset):
