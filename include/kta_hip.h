@@ -90,7 +90,20 @@ typedef struct kta_config {
     uint64_t batch_capacity;     /* records per staging batch; 0 -> 1<<22                     */
     uint64_t key_bytes_capacity; /* key bytes per staging batch; 0 -> 64 * batch_capacity;
                                     must be < 4 GiB (key_off is u32, batch-local)             */
+    uint32_t flags;              /* KTA_FLAG_*                                                */
+    uint32_t reserved;           /* 0                                                         */
 } kta_config;
+
+/* Additive analytics (NOT in the reference, never printed by the reference report): log2
+ * histograms of key and value sizes and per-partition timestamp / message-size extrema,
+ * accumulated by the same scan kernel in extra LDS arrays.  Opt-in: costs LDS, not bandwidth. */
+#define KTA_FLAG_ANALYTICS 1u
+#define KTA_HIST_BUCKETS 34 /* [0] None, [1] length 0, [2+k] 2^k <= length < 2^(k+1), k = 0..31 */
+
+typedef struct kta_analytics {
+    uint64_t key_size_hist[KTA_HIST_BUCKETS];
+    uint64_t value_size_hist[KTA_HIST_BUCKETS];
+} kta_analytics;
 
 /* One batch of decoded records as struct-of-arrays columns.  What the reference's
  * handlers read from a BorrowedMessage (metric.rs:208-209, 218, 233, 291-293):
@@ -194,6 +207,18 @@ int kta_decode_vector(const uint64_t *vec, uint32_t n_partitions, int count_aliv
  * reduction operator (SUM over the prefix, signed MAX over the last four words) — exactly
  * the reduction the two collectives implement. */
 int kta_merge_vectors(uint64_t *acc, const uint64_t *other, uint32_t n_partitions);
+
+/* Analytics of everything submitted so far (context created with KTA_FLAG_ANALYTICS).  The four
+ * per-partition arrays (length P, any may be NULL) use the reference's conventions: seconds =
+ * trunc(ms / 1000) with a raw timestamp of -1 counted as 0; a partition without records reports
+ * min_ts_sec = INT64_MAX / max_ts_sec = INT64_MIN; without non-tombstones smallest = UINT64_MAX,
+ * largest = 0. */
+int kta_get_analytics(kta_ctx *ctx, kta_analytics *out, int64_t *part_min_ts_sec, int64_t *part_max_ts_sec,
+                      uint64_t *part_smallest, uint64_t *part_largest);
+/* Device pointer / length (u64) of the analytics vector: [2 x 34 histogram (SUM)] then per
+ * partition [~min ts_ms, max ts_ms, ~smallest, largest] (signed MAX) — reducible across GPUs like
+ * the counter vector. */
+int kta_analytics_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
 
 /* ---- alive-key table access (tests, multi-GPU merge) ------------------------------ */
 /* Export the alive set as a 2^32-bit little-endian bitmap (bit h%32 of u32 word h/32;

@@ -56,13 +56,13 @@ class HipMetricHandler:
 
     def __init__(self, n_partitions: int, count_alive_keys: bool = False, device: int = 0,
                  batch_capacity: int = 0, key_bytes_capacity: int = 0, n_staging: int = 0,
-                 now: Optional[Tuple[int, int]] = None):
+                 now: Optional[Tuple[int, int]] = None, analytics: bool = False):
         self._lib = N.load()
         self._ctx = C.c_void_p()
         self.n_partitions = int(n_partitions)
         self.count_alive_keys = bool(count_alive_keys)
         cfg = KtaConfig(device, n_partitions, 1 if count_alive_keys else 0, n_staging, batch_capacity,
-                        key_bytes_capacity)
+                        key_bytes_capacity, N.KTA_FLAG_ANALYTICS if analytics else 0, 0)
         rc = self._lib.kta_create(C.byref(cfg), C.byref(self._ctx))
         if rc != N.KTA_OK:
             raise KtaError(rc, self._lib.kta_last_error(None).decode())
@@ -255,6 +255,18 @@ class HipMetricHandler:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.kta_alive_table(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def analytics(self) -> dict:
+        """Additive analytics (not in the reference): size histograms + per-partition extrema."""
+        a = N.KtaAnalytics()
+        P = self.n_partitions
+        mn, mx = np.zeros(P, np.int64), np.zeros(P, np.int64)
+        sm, lg = np.zeros(P, np.uint64), np.zeros(P, np.uint64)
+        self._check(self._lib.kta_get_analytics(self._ctx, C.byref(a), _np_ptr(mn), _np_ptr(mx), _np_ptr(sm),
+                                                _np_ptr(lg)))
+        return {"key_size_hist": np.array(a.key_size_hist[:], dtype=np.uint64),
+                "value_size_hist": np.array(a.value_size_hist[:], dtype=np.uint64),
+                "part_min_ts_sec": mn, "part_max_ts_sec": mx, "part_smallest": sm, "part_largest": lg}
 
     def alive_table_modified(self) -> None:
         self._check(self._lib.kta_alive_table_modified(self._ctx))

@@ -36,7 +36,16 @@ KTA_VAL_FIXED, KTA_VAL_EXP = 0, 1
 class KtaConfig(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("n_partitions", C.c_int32),
                 ("count_alive_keys", C.c_int32), ("n_staging", C.c_int32),
-                ("batch_capacity", C.c_uint64), ("key_bytes_capacity", C.c_uint64)]
+                ("batch_capacity", C.c_uint64), ("key_bytes_capacity", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+KTA_FLAG_ANALYTICS = 1
+KTA_HIST_BUCKETS = 34
+
+
+class KtaAnalytics(C.Structure):
+    _fields_ = [("key_size_hist", C.c_uint64 * 34), ("value_size_hist", C.c_uint64 * 34)]
 
 
 class KtaBatch(C.Structure):
@@ -88,6 +97,8 @@ SIGNATURES = {
     "kta_finish_device": (C.c_int, [_P]),
     "kta_decode_vector": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(KtaResult), C.c_void_p]),
     "kta_merge_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "kta_get_analytics": (C.c_int, [_P, C.POINTER(KtaAnalytics), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kta_analytics_vector": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "kta_export_alive_bitmap": (C.c_int, [_P, C.c_void_p]),
     "kta_alive_table": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "kta_alive_table_modified": (C.c_int, [_P]),

@@ -33,6 +33,8 @@ struct kta_ctx {
     int cu_count = 256;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     hipEvent_t ev_copied = nullptr;
+    bool analytics = false;
+    uint64_t *d_avec = nullptr;     // analytics vector u64[2*34 + 4*P] (KTA_FLAG_ANALYTICS)
     uint64_t *d_vec = nullptr;      // u64[P*7 + KTA_NGLOBALS]
     uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
     uint32_t max_rows = 0;
@@ -187,7 +189,8 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             !aligned16(c->ts_ms))
             return fail(ctx, KTA_ERR_INVALID, "device columns must be 16-byte aligned");
         kta::ScanColumns sc{c->partition, c->key_len, c->val_len, c->ts_ms};
-        kta::ScanPlan pl = kta::plan_scan(ctx->P, n, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant);
+        kta::ScanPlan pl = kta::plan_scan(ctx->P, n, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant,
+                                          ctx->analytics);
         if (pl.workgroups > ctx->max_rows) pl.workgroups = ctx->max_rows;
         if (ctx->timing) {
             int rc = timer_pair(ctx, 0, &a, &b);
@@ -201,8 +204,8 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             if (rc != KTA_OK) return rc;
             KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
         }
-        KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.workgroups, ctx->P, ctx->d_vec,
-                                               ctx->s_compute));
+        KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.workgroups, ctx->P, ctx->d_vec, pl.row_len,
+                                               ctx->d_avec, ctx->s_compute));
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     if ((which & 2) && ctx->alive) {
@@ -233,7 +236,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
 
 int reset_state(kta_ctx *ctx)
 {
-    KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->s_compute));
+    KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->d_avec, ctx->s_compute));
     if (ctx->alive) {
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
@@ -277,6 +280,7 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     ctx->device = cfg->device_id;
     ctx->P = (uint32_t)cfg->n_partitions;
     ctx->alive = cfg->count_alive_keys != 0;
+    ctx->analytics = (cfg->flags & KTA_FLAG_ANALYTICS) != 0;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->batch_capacity = cfg->batch_capacity ? cfg->batch_capacity : (1ull << 22);
     ctx->key_bytes_capacity = cfg->key_bytes_capacity ? cfg->key_bytes_capacity : 64ull * ctx->batch_capacity;
@@ -302,7 +306,9 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     KTA_TRY(hipMalloc((void **)&ctx->d_vec, vec_words * sizeof(uint64_t)));
     ctx->max_rows = (uint32_t)ctx->cu_count * 8u;
     KTA_TRY(hipMalloc((void **)&ctx->d_partials,
-                      (size_t)ctx->max_rows * kta::scan_row_len(ctx->P) * sizeof(uint64_t)));
+                      (size_t)ctx->max_rows * kta::scan_row_len(ctx->P, ctx->analytics) * sizeof(uint64_t)));
+    if (ctx->analytics)
+        KTA_TRY(hipMalloc((void **)&ctx->d_avec, (size_t)kta::analytics_len(ctx->P) * sizeof(uint64_t)));
     if (ctx->alive) {
         KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
         KTA_TRY(hipMalloc((void **)&ctx->d_alive_running, sizeof(int64_t)));
@@ -329,6 +335,7 @@ void kta_destroy(kta_ctx *ctx)
     }
     if (ctx->d_vec) (void)hipFree(ctx->d_vec);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_avec) (void)hipFree(ctx->d_avec);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
@@ -597,6 +604,43 @@ int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out)
         ctx->err = buf;
     }
     return rc;
+}
+
+int kta_analytics_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
+{
+    if (!ctx || !device_ptr || !n_u64) return KTA_ERR_INVALID;
+    if (!ctx->analytics) return fail(ctx, KTA_ERR_INVALID, "context was created without KTA_FLAG_ANALYTICS");
+    *device_ptr = ctx->d_avec;
+    *n_u64 = kta::analytics_len(ctx->P);
+    return KTA_OK;
+}
+
+int kta_get_analytics(kta_ctx *ctx, kta_analytics *out, int64_t *part_min_ts_sec, int64_t *part_max_ts_sec,
+                      uint64_t *part_smallest, uint64_t *part_largest)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    if (!ctx->analytics) return fail(ctx, KTA_ERR_INVALID, "context was created without KTA_FLAG_ANALYTICS");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    std::vector<uint64_t> host(kta::analytics_len(ctx->P));
+    KTA_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_avec, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                ctx->s_compute));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+    for (int b = 0; b < KTA_HIST_BUCKETS; b++) {
+        out->key_size_hist[b] = host[b];
+        out->value_size_hist[b] = host[KTA_HIST_BUCKETS + b];
+    }
+    for (uint32_t p = 0; p < ctx->P; p++) {
+        const int64_t *x = reinterpret_cast<const int64_t *>(host.data()) + kta::kAnalyticsHist + 4 * (size_t)p;
+        const bool seen = x[1] != INT64_MIN;     // max ts never written => no record in this partition
+        const bool live = x[3] != INT64_MIN;     // largest never written => no non-tombstone
+        if (part_min_ts_sec) part_min_ts_sec[p] = seen ? (~x[0]) / 1000 : INT64_MAX;  // metric.rs:210 (monotone)
+        if (part_max_ts_sec) part_max_ts_sec[p] = seen ? x[1] / 1000 : INT64_MIN;
+        if (part_smallest) part_smallest[p] = live ? (uint64_t)~x[2] : UINT64_MAX;
+        if (part_largest) part_largest[p] = live ? (uint64_t)x[3] : 0;
+    }
+    return KTA_OK;
 }
 
 int kta_export_alive_bitmap(kta_ctx *ctx, void *dst)

@@ -38,21 +38,30 @@ struct ScanPlan {
     uint32_t lds_bytes;    // dynamic LDS per workgroup
     uint32_t variant;      // 0 = three 64-bit LDS atomics/record, 1 = packed (two), 9 = loads only (diagnostic)
     bool nontemporal;      // stream the columns with non-temporal loads
+    bool analytics;        // additive outputs: size histograms + per-partition extrema
+    uint32_t row_len;      // u64 words per workgroup row of the partial workspace
 };
 
-// u64 words one workgroup writes into the partial workspace
-inline uint32_t scan_row_len(uint32_t P) { return P * kScanCols + kScanGlobals; }
+constexpr uint32_t kAnalyticsHist = 2 * 34; // key-size and value-size log2 histograms
+// analytics vector: u64[2*34 + 4*P] = histograms, then per partition [~min ts, max ts, ~smallest, largest]
+inline uint32_t analytics_len(uint32_t P) { return kAnalyticsHist + 4 * P; }
 
-ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant);
+// u64 words one workgroup writes into the partial workspace
+inline uint32_t scan_row_len(uint32_t P, bool analytics)
+{
+    return P * kScanCols + kScanGlobals + (analytics ? 4 * P + 2 * 34 : 0);
+}
+
+ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant, bool analytics);
 
 // K1: per-record metric accumulation (metric.rs:207-252) over one struct-of-arrays batch.
 hipError_t launch_metrics_scan(const ScanPlan &plan, const ScanColumns &c, uint64_t n, uint32_t P,
                                uint64_t *partials, hipStream_t s);
 // K5: fold the per-workgroup partial rows into the persistent counter vector.
 hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_t P, uint64_t *vec,
-                                hipStream_t s);
+                                uint32_t row_len, uint64_t *analytics_vec, hipStream_t s);
 // reset the counter vector to the MessageMetrics::new state (metric.rs:30-46)
-hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s);
+hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *analytics_vec, hipStream_t s);
 
 // K2+K3: FNV (fnv32.rs:92-101) + last-writer-wins table update (metric.rs:289-304)
 // variant 0 = fused; 1 = fused + running alive count (returning atomics); 8 / 9 = ablation halves

@@ -86,65 +86,169 @@ struct LaneState {
     uint32_t bad;
 };
 
-template <int VARIANT>
-__device__ __forceinline__ void accumulate(uint32_t part, int32_t kl, int32_t vl, long long ts,
-                                           uint32_t P, uint32_t rep_log2, uint32_t rep,
-                                           unsigned long long *sA, unsigned long long *sK,
-                                           unsigned long long *sV, unsigned long long *sB,
-                                           LaneState &st, bool valid)
+constexpr uint32_t kHistBuckets = 34; // [0] None, [1] length 0, [2+k] 2^k <= length < 2^(k+1)
+constexpr uint32_t kHistReps = 16;    // lane-replicated LDS counters per bucket
+
+__device__ __forceinline__ uint32_t size_bucket(uint32_t is_null, uint32_t len)
 {
-    const bool ok = valid && (part < P); // unsigned compare also rejects negative ids
-    const uint32_t tomb = (uint32_t)vl >> 31;  // payload None  (metric.rs:241-244)
-    const uint32_t knull = (uint32_t)kl >> 31; // key None      (metric.rs:227-230)
-    const uint32_t ks = knull ? 0u : (uint32_t)kl;
-    const uint32_t vs = tomb ? 0u : (uint32_t)vl;
-    st.bad += (valid && !ok) ? 1u : 0u;
-    if (VARIANT == 9) { // diagnostic: loads + register work only
-        if (ok) {
-            const long long t = (ts == -1ll) ? 0ll : ts;
-            st.tmin = t < st.tmin ? t : st.tmin;
-            st.tmax = t > st.tmax ? t : st.tmax;
-            st.smax = max(st.smax, ks + vs + part);
-        }
-        return;
-    }
-    const uint32_t slot = (part << rep_log2) | rep;
-    const unsigned long long a = 1ull | ((unsigned long long)tomb << kCntBits) |
-                                 ((unsigned long long)knull << (2 * kCntBits));
-    if (VARIANT == 1) {
-        // wave-uniform choice: all active lanes small -> one packed add for both sizes
-        const bool small = (ks | vs) < kPackedSizeLimit;
-        if (__all(small || !ok)) {
-            if (ok) {
-                atomicAdd(&sA[slot], a);
-                atomicAdd(&sB[slot], (unsigned long long)ks | ((unsigned long long)vs << 32));
-            }
-        } else if (ok) {
-            atomicAdd(&sA[slot], a);
-            atomicAdd(&sK[slot], (unsigned long long)ks);
-            atomicAdd(&sV[slot], (unsigned long long)vs);
-        }
-    } else if (ok) {
-        atomicAdd(&sA[slot], a);
-        atomicAdd(&sK[slot], (unsigned long long)ks);
-        atomicAdd(&sV[slot], (unsigned long long)vs);
-    }
-    if (ok) {
-        const long long t = (ts == -1ll) ? 0ll : ts; // to_millis() None -> unwrap_or(0)
-        st.tmin = t < st.tmin ? t : st.tmin;          // metric.rs:65-72
-        st.tmax = t > st.tmax ? t : st.tmax;
-        if (!tomb) {                                  // metric.rs:249-251
-            const uint32_t sz = ks + vs;              // < 2^32: both < 2^31
-            st.smin = min(st.smin, sz);               // metric.rs:56-63
+    return is_null ? 0u : (len == 0u ? 1u : 2u + (31u - (uint32_t)__clz((int)len)));
+}
+
+// What one record contributes, derived in registers.
+struct Rec {
+    uint32_t part, tomb, knull, ks, vs;
+    long long t;
+    bool ok;
+};
+
+__device__ __forceinline__ Rec make_rec(uint32_t part, int32_t kl, int32_t vl, long long ts, uint32_t P, bool valid)
+{
+    Rec r;
+    r.part = part;
+    r.ok = valid && (part < P);           // unsigned compare also rejects negative ids
+    r.tomb = (uint32_t)vl >> 31;          // payload None  (metric.rs:241-244)
+    r.knull = (uint32_t)kl >> 31;         // key None      (metric.rs:227-230)
+    r.ks = r.knull ? 0u : (uint32_t)kl;
+    r.vs = r.tomb ? 0u : (uint32_t)vl;
+    r.t = (ts == -1ll) ? 0ll : ts;        // to_millis() None -> unwrap_or(0)  (metric.rs:209)
+    return r;
+}
+
+// global extrema in registers (metric.rs:56-72) + the bad-partition count
+__device__ __forceinline__ void lane_extrema(const Rec &r, bool valid, LaneState &st)
+{
+    st.bad += (valid && !r.ok) ? 1u : 0u;
+    if (r.ok) {
+        st.tmin = r.t < st.tmin ? r.t : st.tmin;
+        st.tmax = r.t > st.tmax ? r.t : st.tmax;
+        if (!r.tomb) {                     // metric.rs:249-251
+            const uint32_t sz = r.ks + r.vs; // < 2^32: both < 2^31
+            st.smin = min(st.smin, sz);
             st.smax = max(st.smax, sz);
         }
     }
 }
 
-template <int VARIANT, bool NT>
+struct ScanLds {
+    unsigned long long *A, *K, *V, *B; // counters (B: packed variant only)
+    long long *X;                      // ANALYTICS: [4][slots] signed-max arrays [~ts, ts, ~size, size]
+    uint32_t *H;                       // ANALYTICS: [2][34][16] histogram counters
+    uint32_t slots;
+};
+
+// LDS side of ONE record.
+template <int VARIANT, bool ANALYTICS>
+__device__ __forceinline__ void lds_record(const Rec &r, const ScanLds &L, uint32_t rep_log2, uint32_t rep)
+{
+    if (VARIANT == 9) return; // diagnostic: loads + register work only
+    const uint32_t slot = (r.part << rep_log2) | rep;
+    const unsigned long long a = 1ull | ((unsigned long long)r.tomb << kCntBits) |
+                                 ((unsigned long long)r.knull << (2 * kCntBits));
+    if (VARIANT == 1) {
+        // wave-uniform choice: all active lanes small -> one packed add for both sizes
+        const bool small = (r.ks | r.vs) < kPackedSizeLimit;
+        if (__all(small || !r.ok)) {
+            if (r.ok) {
+                atomicAdd(&L.A[slot], a);
+                atomicAdd(&L.B[slot], (unsigned long long)r.ks | ((unsigned long long)r.vs << 32));
+            }
+        } else if (r.ok) {
+            atomicAdd(&L.A[slot], a);
+            atomicAdd(&L.K[slot], (unsigned long long)r.ks);
+            atomicAdd(&L.V[slot], (unsigned long long)r.vs);
+        }
+    } else if (r.ok) {
+        atomicAdd(&L.A[slot], a);
+        atomicAdd(&L.K[slot], (unsigned long long)r.ks);
+        atomicAdd(&L.V[slot], (unsigned long long)r.vs);
+    }
+    if (ANALYTICS && r.ok) {
+        atomicMax(&L.X[slot], ~r.t);
+        atomicMax(&L.X[L.slots + slot], r.t);
+        if (!r.tomb) {
+            const long long sz = (long long)(r.ks + r.vs);
+            atomicMax(&L.X[2 * L.slots + slot], ~sz);
+            atomicMax(&L.X[3 * L.slots + slot], sz);
+        }
+    }
+}
+
+template <bool ANALYTICS>
+__device__ __forceinline__ void lds_histograms(const Rec &r, const ScanLds &L)
+{
+    if (ANALYTICS && r.ok) {
+        const uint32_t hr = threadIdx.x & (kHistReps - 1u);
+        atomicAdd(&L.H[size_bucket(r.knull, r.ks) * kHistReps + hr], 1u);
+        atomicAdd(&L.H[(kHistBuckets + size_bucket(r.tomb, r.vs)) * kHistReps + hr], 1u);
+    }
+}
+
+// The lane's 4 consecutive records of a tile.  A Kafka consumer delivers per-partition runs, so the
+// four usually share a partition: then their contributions are combined in registers and cost one
+// set of LDS atomics instead of four (4x fewer same-address conflicts inside a run).
+template <int VARIANT, bool ANALYTICS>
+__device__ __forceinline__ void accumulate_quad(const Quad &q, bool valid, uint32_t P, uint32_t rep_log2,
+                                                uint32_t rep, const ScanLds &L, LaneState &st)
+{
+    Rec r[4] = {make_rec((uint32_t)q.p.x, q.k.x, q.v.x, q.t0.x, P, valid),
+                make_rec((uint32_t)q.p.y, q.k.y, q.v.y, q.t0.y, P, valid),
+                make_rec((uint32_t)q.p.z, q.k.z, q.v.z, q.t1.x, P, valid),
+                make_rec((uint32_t)q.p.w, q.k.w, q.v.w, q.t1.y, P, valid)};
+#pragma unroll
+    for (int j = 0; j < 4; j++) lane_extrema(r[j], valid, st);
+    if (VARIANT == 9) {
+        st.smax = max(st.smax, r[0].part + r[1].part + r[2].part + r[3].part); // keep the loads alive
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) lds_histograms<ANALYTICS>(r[j], L);
+    const bool uniform = r[0].ok && r[0].part == r[1].part && r[0].part == r[2].part && r[0].part == r[3].part;
+    if (VARIANT == 0 && uniform) {
+        const uint32_t slot = (r[0].part << rep_log2) | rep;
+        const uint32_t tombs = r[0].tomb + r[1].tomb + r[2].tomb + r[3].tomb;
+        const uint32_t knulls = r[0].knull + r[1].knull + r[2].knull + r[3].knull;
+        atomicAdd(&L.A[slot], 4ull | ((unsigned long long)tombs << kCntBits) |
+                                  ((unsigned long long)knulls << (2 * kCntBits)));
+        atomicAdd(&L.K[slot], (unsigned long long)r[0].ks + r[1].ks + r[2].ks + r[3].ks);
+        atomicAdd(&L.V[slot], (unsigned long long)r[0].vs + r[1].vs + r[2].vs + r[3].vs);
+        if (ANALYTICS) {
+            long long nt = LLONG_MIN, tx = LLONG_MIN, ns = LLONG_MIN, sx = LLONG_MIN;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                nt = ~r[j].t > nt ? ~r[j].t : nt;
+                tx = r[j].t > tx ? r[j].t : tx;
+                if (!r[j].tomb) {
+                    const long long sz = (long long)(r[j].ks + r[j].vs);
+                    ns = ~sz > ns ? ~sz : ns;
+                    sx = sz > sx ? sz : sx;
+                }
+            }
+            atomicMax(&L.X[slot], nt);
+            atomicMax(&L.X[L.slots + slot], tx);
+            if (tombs < 4u) {
+                atomicMax(&L.X[2 * L.slots + slot], ns);
+                atomicMax(&L.X[3 * L.slots + slot], sx);
+            }
+        }
+        return;
+    }
+    // interleaved partitions (or the packed variant, whose wave-wide vote needs every lane)
+    const bool any_scalar = VARIANT == 1 ? true : !uniform;
+    if (any_scalar) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds_record<VARIANT, ANALYTICS>(r[j], L, rep_log2, rep);
+    }
+}
+
+// ANALYTICS (opt-in, no reference counterpart — the additive outputs named by the project brief):
+// log2 histograms of key and value sizes and per-partition timestamp / message-size extrema, kept
+// in additional LDS arrays (extrema as signed-max arrays of [~ts, ts, ~size, size], histograms as
+// u32 counters replicated 16x by lane) and flushed with the counters.
+template <int VARIANT, bool NT, bool ANALYTICS>
 __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t n, uint32_t P,
                                                         uint32_t rep_log2,
-                                                        uint64_t *__restrict__ partials)
+                                                        uint64_t *__restrict__ partials,
+                                                        uint32_t row_len)
 {
     extern __shared__ unsigned long long lds[];
     __shared__ long long s_red[kWG / 64][6];
@@ -156,8 +260,15 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
     unsigned long long *sK = lds + slots;
     unsigned long long *sV = lds + 2 * slots;
     unsigned long long *sB = lds + 3 * slots; // VARIANT 1 only
+    long long *sX = reinterpret_cast<long long *>(lds + n_arrays * slots);          // ANALYTICS: [4][slots]
+    uint32_t *sH = reinterpret_cast<uint32_t *>(lds + (n_arrays + 4) * slots);      // ANALYTICS: [2][34][16]
+    const ScanLds L{sA, sK, sV, sB, sX, sH, slots};
 
     for (uint32_t i = tid; i < n_arrays * slots; i += kWG) lds[i] = 0ull;
+    if (ANALYTICS) {
+        for (uint32_t i = tid; i < 4 * slots; i += kWG) sX[i] = LLONG_MIN;
+        for (uint32_t i = tid; i < 2 * kHistBuckets * kHistReps; i += kWG) sH[i] = 0u;
+    }
     __syncthreads();
 
     const uint32_t rep = tid & ((1u << rep_log2) - 1u);
@@ -168,7 +279,7 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
     st.smax = 0u;
     st.bad = 0u;
 
-    uint64_t *row = partials + (uint64_t)blockIdx.x * (P * kScanCols + kScanGlobals);
+    uint64_t *row = partials + (uint64_t)blockIdx.x * row_len;
     bool first_flush = true;
 
     auto flush = [&]() {
@@ -200,6 +311,29 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
             } else {
                 o[0] += c0; o[1] += c1; o[2] += c2; o[3] += k; o[4] += v;
             }
+            if (ANALYTICS) {
+                long long *x = reinterpret_cast<long long *>(row + (uint64_t)P * kScanCols + kScanGlobals) + 4ull * p;
+                for (uint32_t j = 0; j < 4; j++) {
+                    long long m = LLONG_MIN;
+                    for (uint32_t r = 0; r < (1u << rep_log2); r++) {
+                        const uint32_t s = j * slots + ((p << rep_log2) | r);
+                        m = sX[s] > m ? sX[s] : m;
+                        sX[s] = LLONG_MIN;
+                    }
+                    x[j] = (first_flush || m > x[j]) ? m : x[j];
+                }
+            }
+        }
+        if (ANALYTICS) {
+            uint64_t *hrow = row + (uint64_t)P * kScanCols + kScanGlobals + 4ull * P;
+            for (uint32_t bkt = tid; bkt < 2 * kHistBuckets; bkt += kWG) {
+                uint64_t t = 0;
+                for (uint32_t r = 0; r < kHistReps; r++) {
+                    t += sH[bkt * kHistReps + r];
+                    sH[bkt * kHistReps + r] = 0u;
+                }
+                hrow[bkt] = first_flush ? t : hrow[bkt] + t;
+            }
         }
         first_flush = false;
         __syncthreads();
@@ -221,10 +355,7 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
         const bool nxt_valid = (ntile < ntiles) && (nqi < nquads);
         if (nxt_valid) load_quad<NT>(nxt, c, nqi);
 
-        accumulate<VARIANT>((uint32_t)cur.p.x, cur.k.x, cur.v.x, cur.t0.x, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
-        accumulate<VARIANT>((uint32_t)cur.p.y, cur.k.y, cur.v.y, cur.t0.y, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
-        accumulate<VARIANT>((uint32_t)cur.p.z, cur.k.z, cur.v.z, cur.t1.x, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
-        accumulate<VARIANT>((uint32_t)cur.p.w, cur.k.w, cur.v.w, cur.t1.y, P, rep_log2, rep, sA, sK, sV, sB, st, cur_valid);
+        accumulate_quad<VARIANT, ANALYTICS>(cur, cur_valid, P, rep_log2, rep, L, st);
 
         if (++since_flush == kFlushTiles) {
             flush();
@@ -244,7 +375,10 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
         if (tid < 64) {
             uint32_t p = 0; int32_t kl = 0, vl = 0; long long ts = 0;
             if (v) { p = (uint32_t)c.partition[ii]; kl = c.key_len[ii]; vl = c.val_len[ii]; ts = c.ts_ms[ii]; }
-            accumulate<VARIANT>(p, kl, vl, ts, P, rep_log2, rep, sA, sK, sV, sB, st, v);
+            const Rec r = make_rec(p, kl, vl, ts, P, v);
+            lane_extrema(r, v, st);
+            lds_histograms<ANALYTICS>(r, L);
+            lds_record<VARIANT, ANALYTICS>(r, L, rep_log2, rep);
         }
     }
 
@@ -299,14 +433,33 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
 // one device-scope integer atomic per (thread, output).  Integer atomics commute => exact.
 __global__ __launch_bounds__(kWG) void kta_fold_partials(const uint64_t *__restrict__ partials,
                                                          uint32_t rows, uint32_t P,
-                                                         uint64_t *__restrict__ vec)
+                                                         uint64_t *__restrict__ vec, uint32_t row_len,
+                                                         uint64_t *__restrict__ avec)
 {
-    const uint32_t row_len = P * kScanCols + kScanGlobals;
+    const uint32_t base_len = P * kScanCols + kScanGlobals;
     const uint32_t col = blockIdx.x * kWG + threadIdx.x;
     if (col >= row_len) return;
     const uint32_t r0 = (uint32_t)(((uint64_t)rows * blockIdx.y) / gridDim.y);
     const uint32_t r1 = (uint32_t)(((uint64_t)rows * (blockIdx.y + 1)) / gridDim.y);
     if (r0 == r1) return;
+    if (col >= base_len) {
+        // analytics tail of the row: [P][4] signed-max extrema, then 2 x 34 histogram sums.
+        // avec layout: [2 x 34 histogram][P][4 extrema]
+        const uint32_t a = col - base_len;
+        if (a < 4u * P) {
+            long long m = LLONG_MIN;
+            for (uint32_t r = r0; r < r1; r++) {
+                const long long x = (long long)partials[(uint64_t)r * row_len + col];
+                m = x > m ? x : m;
+            }
+            atomicMax(reinterpret_cast<long long *>(avec) + 2 * kHistBuckets + a, m);
+        } else {
+            unsigned long long t = 0;
+            for (uint32_t r = r0; r < r1; r++) t += partials[(uint64_t)r * row_len + col];
+            if (t) atomicAdd(reinterpret_cast<unsigned long long *>(avec) + (a - 4u * P), t);
+        }
+        return;
+    }
     unsigned long long *v = reinterpret_cast<unsigned long long *>(vec);
     unsigned long long *g = v + (uint64_t)P * 7;
     if (col < P * kScanCols) {
@@ -358,11 +511,15 @@ __global__ __launch_bounds__(kWG) void kta_fold_partials(const uint64_t *__restr
     }
 }
 
-__global__ void kta_init_vector(uint64_t *vec, uint32_t P)
+__global__ void kta_init_vector(uint64_t *vec, uint32_t P, uint64_t *avec)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nc = P * 7;
     if (i < nc) vec[i] = 0;
+    if (avec) {
+        if (i < 2 * kHistBuckets) avec[i] = 0;
+        if (i < 4 * P) avec[2 * kHistBuckets + i] = (uint64_t)LLONG_MIN;
+    }
     if (i == 0) {
         uint64_t *g = vec + nc;
         g[0] = 0; g[1] = 0; g[2] = 0; g[3] = 0;  // SUM globals
@@ -538,24 +695,30 @@ __global__ __launch_bounds__(kWG) void kta_alive_bitmap(const unsigned long long
 // launch wrappers
 // ---------------------------------------------------------------------------------------
 
-ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant)
+ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant, bool analytics)
 {
     ScanPlan pl;
     // req_variant: low bits 0 = three LDS atomics, 1 = packed, 9 = loads only; +16 = non-temporal loads
     const int base = req_variant & 15;
-    pl.nontemporal = (req_variant & 16) != 0;
-    pl.variant = (base == 1 || base == 9) ? (uint32_t)base : 0u;
-    const uint32_t arrays = pl.variant == 1 ? 4u : 3u;
-    // LDS budget per workgroup: 32 KiB (4 workgroups = 16 waves per CU can be resident).
-    const uint32_t budget_slots = (32u * 1024u) / (8u * arrays);
+    pl.analytics = analytics;
+    pl.nontemporal = analytics ? true : (req_variant & 16) != 0;
+    pl.variant = analytics ? 0u : ((base == 1 || base == 9) ? (uint32_t)base : 0u);
+    const uint32_t arrays = (pl.variant == 1 ? 4u : 3u) + (analytics ? 4u : 0u);
+    const uint32_t hist_bytes = analytics ? 2u * kHistBuckets * kHistReps * 4u : 0u;
+    // LDS budget per workgroup: 32 KiB (4 workgroups = 16 waves per CU can be resident); the
+    // analytics kernel carries 7 arrays and gets 64 KiB (2 workgroups per CU) to keep the replication.
+    const uint32_t budget_slots = ((analytics ? 64u : 32u) * 1024u - hist_bytes) / (8u * arrays);
     uint32_t rep_log2 = 0;
     while (rep_log2 < 6 && (P << (rep_log2 + 1)) <= budget_slots) rep_log2++;
     pl.rep_log2 = rep_log2;
-    pl.lds_bytes = (P << rep_log2) * 8u * arrays;
+    pl.lds_bytes = (P << rep_log2) * 8u * arrays + hist_bytes;
+    pl.row_len = scan_row_len(P, analytics);
     const uint64_t ntiles = ((n >> 2) + kWG - 1) / kWG;
     // 3 workgroups (12 waves) per CU saturate HBM (measured: 2-3 per CU best, more is slower), and
     // every workgroup is resident at once, so the static round-robin tile deal stays balanced.
-    uint64_t wgs = req_workgroups > 0 ? (uint64_t)req_workgroups : (uint64_t)cu_count * 3u;
+    // (a workgroup needing more than 40 KiB of LDS only fits twice per CU: use 2 per CU then)
+    uint64_t wgs = req_workgroups > 0 ? (uint64_t)req_workgroups
+                                      : (uint64_t)cu_count * (pl.lds_bytes > 40u * 1024u ? 2u : 3u);
     if (wgs > ntiles) wgs = ntiles;
     if (wgs < 1) wgs = 1;
     pl.workgroups = (uint32_t)wgs;
@@ -567,39 +730,42 @@ hipError_t launch_metrics_scan(const ScanPlan &pl, const ScanColumns &c, uint64_
 {
     dim3 grid(pl.workgroups), block(kWG);
     // > 64 KiB of dynamic LDS (P > ~2700) must be opted into per kernel
-#define KTA_SCAN(V, NT)                                                                                        \
-    do {                                                                                                       \
-        if (pl.lds_bytes > 48u * 1024u) {                                                                      \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_metrics_scan<V, NT>),      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes); \
-            if (ea != hipSuccess) return ea;                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((kta_metrics_scan<V, NT>), grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2,      \
-                           partials);                                                                          \
+#define KTA_SCAN(V, NT, AN)                                                                                     \
+    do {                                                                                                        \
+        if (pl.lds_bytes > 48u * 1024u) {                                                                       \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_metrics_scan<V, NT, AN>),   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);  \
+            if (ea != hipSuccess) return ea;                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((kta_metrics_scan<V, NT, AN>), grid, block, pl.lds_bytes, s, c, n, P, pl.rep_log2,   \
+                           partials, pl.row_len);                                                               \
     } while (0)
+    if (pl.analytics) {
+        KTA_SCAN(0, true, true);
+        return hipGetLastError();
+    }
     switch (pl.variant) {
-    case 1: if (pl.nontemporal) KTA_SCAN(1, true); else KTA_SCAN(1, false); break;
-    case 9: if (pl.nontemporal) KTA_SCAN(9, true); else KTA_SCAN(9, false); break;
-    default: if (pl.nontemporal) KTA_SCAN(0, true); else KTA_SCAN(0, false); break;
+    case 1: if (pl.nontemporal) KTA_SCAN(1, true, false); else KTA_SCAN(1, false, false); break;
+    case 9: if (pl.nontemporal) KTA_SCAN(9, true, false); else KTA_SCAN(9, false, false); break;
+    default: if (pl.nontemporal) KTA_SCAN(0, true, false); else KTA_SCAN(0, false, false); break;
     }
 #undef KTA_SCAN
     return hipGetLastError();
 }
 
 hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_t P, uint64_t *vec,
-                                hipStream_t s)
+                                uint32_t row_len, uint64_t *avec, hipStream_t s)
 {
-    const uint32_t row_len = P * kScanCols + kScanGlobals;
     uint32_t slices = rows < 32 ? rows : 32;
     dim3 grid((row_len + kWG - 1) / kWG, slices), block(kWG);
-    hipLaunchKernelGGL(kta_fold_partials, grid, block, 0, s, partials, rows, P, vec);
+    hipLaunchKernelGGL(kta_fold_partials, grid, block, 0, s, partials, rows, P, vec, row_len, avec);
     return hipGetLastError();
 }
 
-hipError_t launch_init_vector(uint64_t *vec, uint32_t P, hipStream_t s)
+hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *avec, hipStream_t s)
 {
     const uint32_t n = P * 7 + 1;
-    hipLaunchKernelGGL(kta_init_vector, dim3((n + 255) / 256), dim3(256), 0, s, vec, P);
+    hipLaunchKernelGGL(kta_init_vector, dim3((n + 255) / 256), dim3(256), 0, s, vec, P, avec);
     return hipGetLastError();
 }
 

@@ -476,3 +476,77 @@ void kto_run_soa(kto_metrics *m, kto_logcompaction *lc, uint64_t n, const int32_
         }
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Additive analytics — NO reference counterpart (see kta_oracle.h).          */
+/* ------------------------------------------------------------------------ */
+struct kto_analytics {
+    int32_t P;
+    uint64_t key_hist[34], val_hist[34];
+    int64_t *min_ms, *max_ms;
+    uint64_t *smallest, *largest;
+    uint8_t *seen, *live;
+};
+
+static unsigned size_bucket(int64_t len)
+{
+    if (len < 0) return 0;
+    if (len == 0) return 1;
+    unsigned b = 0;
+    while ((len >> (b + 1)) != 0) b++;
+    return 2 + b;
+}
+
+kto_analytics *kto_analytics_new(int32_t P)
+{
+    kto_analytics *a = (kto_analytics *)calloc(1, sizeof(*a));
+    a->P = P;
+    a->min_ms = (int64_t *)calloc((size_t)P, 8);
+    a->max_ms = (int64_t *)calloc((size_t)P, 8);
+    a->smallest = (uint64_t *)calloc((size_t)P, 8);
+    a->largest = (uint64_t *)calloc((size_t)P, 8);
+    a->seen = (uint8_t *)calloc((size_t)P, 1);
+    a->live = (uint8_t *)calloc((size_t)P, 1);
+    return a;
+}
+
+void kto_analytics_free(kto_analytics *a)
+{
+    if (!a) return;
+    free(a->min_ms); free(a->max_ms); free(a->smallest); free(a->largest); free(a->seen); free(a->live);
+    free(a);
+}
+
+void kto_analytics_run_soa(kto_analytics *a, uint64_t n, const int32_t *part, const int32_t *key_len,
+                           const int32_t *val_len, const int64_t *ts_ms)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        const int32_t p = part[i];
+        if (p < 0 || p >= a->P) continue;
+        const int64_t ts = ts_ms[i] == -1 ? 0 : ts_ms[i]; /* as metric.rs:209 */
+        a->key_hist[size_bucket(key_len[i])]++;
+        a->val_hist[size_bucket(val_len[i])]++;
+        if (!a->seen[p] || ts < a->min_ms[p]) a->min_ms[p] = ts;
+        if (!a->seen[p] || ts > a->max_ms[p]) a->max_ms[p] = ts;
+        a->seen[p] = 1;
+        if (val_len[i] >= 0) {
+            const uint64_t sz = (uint64_t)(key_len[i] > 0 ? key_len[i] : 0) + (uint64_t)val_len[i];
+            if (!a->live[p] || sz < a->smallest[p]) a->smallest[p] = sz;
+            if (!a->live[p] || sz > a->largest[p]) a->largest[p] = sz;
+            a->live[p] = 1;
+        }
+    }
+}
+
+void kto_analytics_export(const kto_analytics *a, uint64_t *key_hist, uint64_t *val_hist, int64_t *min_ts_sec,
+                          int64_t *max_ts_sec, uint64_t *smallest, uint64_t *largest)
+{
+    memcpy(key_hist, a->key_hist, sizeof a->key_hist);
+    memcpy(val_hist, a->val_hist, sizeof a->val_hist);
+    for (int32_t p = 0; p < a->P; p++) {
+        min_ts_sec[p] = a->seen[p] ? a->min_ms[p] / 1000 : INT64_MAX;
+        max_ts_sec[p] = a->seen[p] ? a->max_ms[p] / 1000 : INT64_MIN;
+        smallest[p] = a->live[p] ? a->smallest[p] : UINT64_MAX;
+        largest[p] = a->live[p] ? a->largest[p] : 0;
+    }
+}

@@ -108,4 +108,25 @@ void kto_export_counters(const kto_metrics *m, int32_t n_partitions, uint64_t *o
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- additive analytics: NO reference counterpart ------------------------------------------
+ * The reference keeps only sums and global extrema (metric.rs:18-23).  The product can
+ * additionally report log2 size histograms and per-partition extrema (KTA_FLAG_ANALYTICS,
+ * DESIGN.md §3.6); this restates THAT definition on the CPU so the kernel can be checked.
+ * bucket(None) = 0, bucket(len 0) = 1, bucket(len) = 2 + floor(log2(len)). */
+#ifdef __cplusplus
+extern "C" {
 #endif
+typedef struct kto_analytics kto_analytics;
+kto_analytics *kto_analytics_new(int32_t n_partitions);
+void kto_analytics_free(kto_analytics *a);
+void kto_analytics_run_soa(kto_analytics *a, uint64_t n, const int32_t *part, const int32_t *key_len,
+                           const int32_t *val_len, const int64_t *ts_ms);
+/* out: key_hist[34], val_hist[34]; per partition min/max seconds (INT64_MAX / INT64_MIN if none),
+ * smallest/largest non-tombstone (UINT64_MAX / 0 if none) */
+void kto_analytics_export(const kto_analytics *a, uint64_t *key_hist, uint64_t *val_hist, int64_t *min_ts_sec,
+                          int64_t *max_ts_sec, uint64_t *smallest, uint64_t *largest);
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTA_ORACLE_H */

@@ -127,3 +127,24 @@ class Oracle:
         out = np.zeros(n_words, dtype=np.uint32)
         self.L.kto_lc_export_words(self.lc, out.ctypes.data, n_words)
         return out
+
+
+def analytics(cols, P):
+    """The oracle's restatement of the additive analytics (no reference counterpart)."""
+    L = lib()
+    L.kto_analytics_new.restype = C.c_void_p
+    L.kto_analytics_new.argtypes = [C.c_int32]
+    L.kto_analytics_free.argtypes = [C.c_void_p]
+    L.kto_analytics_run_soa.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
+    L.kto_analytics_export.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    a = L.kto_analytics_new(P)
+    c = {k: np.ascontiguousarray(v) for k, v in cols.items() if isinstance(v, np.ndarray)}
+    L.kto_analytics_run_soa(a, len(c["partition"]), c["partition"].ctypes.data, c["key_len"].ctypes.data,
+                            c["val_len"].ctypes.data, c["ts_ms"].ctypes.data)
+    out = {"key_size_hist": np.zeros(34, np.uint64), "value_size_hist": np.zeros(34, np.uint64),
+           "part_min_ts_sec": np.zeros(P, np.int64), "part_max_ts_sec": np.zeros(P, np.int64),
+           "part_smallest": np.zeros(P, np.uint64), "part_largest": np.zeros(P, np.uint64)}
+    L.kto_analytics_export(a, *[out[k].ctypes.data for k in ("key_size_hist", "value_size_hist", "part_min_ts_sec",
+                                                              "part_max_ts_sec", "part_smallest", "part_largest")])
+    L.kto_analytics_free(a)
+    return out

@@ -365,3 +365,34 @@ def test_full_size_properties_alive_pass(hc):
     r3, _ = hc.finish()
     assert r3.alive_keys == 0
     hc.device_batch_free(b)
+
+
+# ------------------------------------------------------------------------------------- additive analytics
+@pytest.mark.parametrize("P,n,runs", [(1, 30000, False), (8, 120000, True), (256, 250000, False), (1000, 90000, False)])
+def test_analytics_histograms_and_partition_extrema(P, n, runs):
+    """KTA_FLAG_ANALYTICS (no reference counterpart): the kernel's histograms / per-partition extrema
+    against the oracle's restatement of the same definition — and the reference counters unchanged."""
+    from oracle_c import analytics
+    rng = np.random.default_rng(P + n)
+    cols = random_cols(rng, n, P, key_space=500, runs=runs, big_sizes=True)
+    if P >= 8:
+        cols["val_len"][cols["partition"] == 5] = -1  # a tombstone-only partition
+        keep = cols["partition"] != 6                  # and an empty one
+        cols = {k: (v[keep] if k != "key_bytes" else v) for k, v in cols.items()}
+    want = analytics(cols, P)
+    o = Oracle(NOW)
+    o.run_soa(cols)
+    with kta.HipMetricHandler(P, now=NOW, analytics=True, batch_capacity=1 << 16) as h:
+        h.submit_columns(cols["partition"], cols["key_len"], cols["val_len"], cols["ts_ms"])
+        res, c = h.finish()
+        assert np.array_equal(c, o.counters(P))
+        got = h.analytics()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+        assert int(got["key_size_hist"].sum()) == len(cols["partition"]) == res.overall_count
+        h.reset()
+        z = h.analytics()
+        assert not z["key_size_hist"].any() and (z["part_largest"] == 0).all()
+    with kta.HipMetricHandler(4) as plain:
+        with pytest.raises(kta.KtaError):
+            plain.analytics()
