@@ -1,0 +1,101 @@
+/*
+ * kta_kafka.h — Kafka record-batch (message format v2, magic 2) decode on the GPU: raw record
+ * sets (what a Fetch response carries per partition, and byte-for-byte what a broker's
+ * `*.log` segment file contains) -> the struct-of-arrays columns of kta_hip.h.
+ *
+ * This is the step BEFORE the hot path.  In the reference it happens inside librdkafka
+ * (rdkafka-sys 3.0.0+1.6.0 -> librdkafka 1.6.0, `Cargo.lock:612-613`; C source not in the
+ * reference tree): `consumer.poll()` (src/kafka.rs:93) hands out one decoded message at a time and
+ * the handlers read partition / timestamp / key / payload from it (src/metric.rs:208-209, 218, 233).
+ * Here the host only walks the 61-byte batch headers; the varint-framed records are parsed on the
+ * device straight into the columns the metric kernels consume, so the PCIe link carries the raw
+ * log once and no per-message host work remains.
+ *
+ * Format (Apache Kafka protocol guide, "Record Batch", KIP-98):
+ *   batch : baseOffset i64 | batchLength i32 | partitionLeaderEpoch i32 | magic i8 (=2) | crc u32 |
+ *           attributes i16 | lastOffsetDelta i32 | baseTimestamp i64 | maxTimestamp i64 |
+ *           producerId i64 | producerEpoch i16 | baseSequence i32 | recordsCount i32 | records
+ *           (big endian; 61 bytes of header; the batch occupies 12 + batchLength bytes)
+ *   record: length varint | attributes i8 | timestampDelta varlong | offsetDelta varint |
+ *           keyLength varint (-1 = null) | key | valueLength varint (-1 = null) | value |
+ *           headersCount varint | headers (keyLen varint, key, valueLen varint (-1 null), value)
+ *           (varints are zig-zag base-128)
+ *   attributes: bits 0-2 compression codec, bit 3 timestamp type (1 = LogAppendTime: every record
+ *           carries maxTimestamp), bit 4 transactional, bit 5 control batch (never delivered to the
+ *           application), bit 6 delete horizon.
+ *
+ * What a consumer delivers per record (and what is written to the columns):
+ *   partition = the record set's partition, timestamp = baseTimestamp + timestampDelta (or
+ *   maxTimestamp for LogAppendTime), key/payload None iff the length is -1.
+ * Not handled (counted, never silently mis-decoded): compressed batches (codec != 0), magic 0/1
+ * message sets.  CRCs are not verified — librdkafka's `check.crcs` defaults to false and the
+ * reference does not set it (src/kafka.rs:28-36).
+ */
+#ifndef KTA_KAFKA_H
+#define KTA_KAFKA_H
+
+#include <stdint.h>
+#include "kta_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KTA_KAFKA_BATCH_HEADER 61
+
+/* flags of a batch descriptor */
+#define KTA_KB_LOG_APPEND_TIME 1u /* attributes bit 3 */
+#define KTA_KB_TRANSACTIONAL 2u   /* attributes bit 4 */
+
+typedef struct kta_kafka_batch_desc {
+    uint64_t byte_off;    /* offset of the batch (its baseOffset field) in the blob          */
+    uint64_t record_base; /* index of its first record in the output columns               */
+    uint64_t key_base;    /* offset of its first key byte in key_bytes (filled by the device) */
+    int64_t base_offset;  /* Kafka offset of the first record                                */
+    int64_t base_ts_ms;
+    int64_t max_ts_ms;
+    uint32_t batch_bytes; /* 12 + batchLength                                               */
+    int32_t partition;
+    int32_t n_records;
+    uint32_t flags;
+} kta_kafka_batch_desc;
+
+typedef struct kta_kafka_index_stats {
+    uint64_t n_batches;          /* descriptors written                                     */
+    uint64_t n_records;          /* sum of their recordsCount                               */
+    uint64_t n_control_batches;  /* skipped: never delivered to the application             */
+    uint64_t n_compressed;       /* skipped: compression codec != 0 (not decoded here)      */
+    uint64_t n_old_magic;        /* skipped: magic 0/1 message sets                         */
+    uint64_t trailing_bytes;     /* bytes after the last complete batch (partial fetch tail)*/
+    uint64_t bytes_consumed;
+} kta_kafka_index_stats;
+
+/* Host: walk the batch headers of one record set.  `record_base_start` is the output index of the
+ * set's first record (lets several sets share one output batch).  Returns KTA_ERR_CAPACITY when
+ * `cap` descriptors do not suffice (stats->n_batches then holds the number needed). */
+int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, uint64_t blob_offset,
+                         uint64_t record_base_start, kta_kafka_batch_desc *descs, uint64_t cap,
+                         kta_kafka_index_stats *stats);
+
+/* Device: parse the records of `n_batches` indexed batches out of `blob_device` into the device
+ * columns `out` (capacity >= total records; key_off/key_bytes filled only if out->key_bytes is set).
+ * `descs_host` is copied to the device.  *n_key_bytes receives the key bytes produced;
+ * *n_bad_batches the batches whose records overran the batch (their remaining records are written
+ * as unkeyed tombstones on partition -1 so that they are reported, not counted). */
+int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
+                            const kta_kafka_batch_desc *descs_host, uint64_t n_batches, uint64_t n_records,
+                            const kta_batch *out, uint64_t *n_key_bytes, uint64_t *n_bad_batches);
+
+/* Convenience for hosts that hold the raw bytes in ordinary memory: copy to the device, index,
+ * decode and run the metric handlers over the result (records get consecutive sequence numbers). */
+int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
+                      kta_kafka_index_stats *stats);
+
+/* Average duration (ms) of the decode kernels since the previous call: [0] key-size pass,
+ * [1] decode pass; launches[] their counts.  Needs kta_set_timing(ctx, 1). */
+int kta_kafka_time_stats(kta_ctx *ctx, float avg_ms[2], uint64_t launches[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTA_KAFKA_H */

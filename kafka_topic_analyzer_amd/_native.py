@@ -73,7 +73,20 @@ class KtaSynthSpec(C.Structure):
                 ("ts_jitter_ms", C.c_uint32)]
 
 
-# every symbol include/kta_hip.h and include/kta_synth.h declare: (restype, argtypes)
+class KtaKafkaBatchDesc(C.Structure):
+    _fields_ = [("byte_off", C.c_uint64), ("record_base", C.c_uint64), ("key_base", C.c_uint64),
+                ("base_offset", C.c_int64), ("base_ts_ms", C.c_int64), ("max_ts_ms", C.c_int64),
+                ("batch_bytes", C.c_uint32), ("partition", C.c_int32), ("n_records", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class KtaKafkaIndexStats(C.Structure):
+    _fields_ = [("n_batches", C.c_uint64), ("n_records", C.c_uint64), ("n_control_batches", C.c_uint64),
+                ("n_compressed", C.c_uint64), ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
+                ("bytes_consumed", C.c_uint64)]
+
+
+# every symbol include/kta_hip.h, kta_synth.h and kta_kafka.h declare: (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
     "kta_abi_version": (C.c_int, []),
@@ -113,6 +126,13 @@ SIGNATURES = {
     "kta_synth_fill_device": (C.c_int, [_P, C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64,
                                         C.POINTER(KtaBatch), C.POINTER(C.c_uint64)]),
     "kta_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(KtaSynthSpec), C.POINTER(C.c_uint64)]),
+    "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,
+                                       C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,
+                                          C.c_uint64, C.POINTER(KtaBatch), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]),
+    "kta_kafka_consume": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_kafka_time_stats": (C.c_int, [_P, C.POINTER(C.c_float * 2), C.POINTER(C.c_uint64 * 2)]),
 }
 
 _lib = None

@@ -21,7 +21,7 @@ CLI = os.path.join(HERE, "kta-analyzer")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libkta_oracle.so")
 
-HIP_SOURCES = ["kta_kernels.hip", "kta_api.hip", "kta_synth.hip"]
+HIP_SOURCES = ["kta_kernels.hip", "kta_api.hip", "kta_synth.hip", "kta_kafka.hip"]
 LIB_HOST_SOURCES = ["host/metric.cpp", "host/report.cpp"]  # C++ host mirror, inside libkta_hip.so
 HOST_SOURCES = ["host/main.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -88,7 +88,7 @@ def build_cli(force: bool = False):
 
 
 def build_oracle(force: bool = False) -> str:
-    deps = [os.path.join(ORACLE_DIR, "kta_oracle.c"), os.path.join(ORACLE_DIR, "kta_oracle.h")]
+    deps = [os.path.join(ORACLE_DIR, f) for f in ("kta_oracle.c", "kta_oracle.h", "kta_kafka_oracle.c", "Makefile")]
     if not force and _newer(ORACLE_LIB, deps):
         return ORACLE_LIB
     _run(["make", "-C", ORACLE_DIR] + (["-B"] if force else []))

@@ -58,6 +58,9 @@ struct kta_ctx {
     size_t ev_used[3] = {0, 0, 0};
     double ms_sum[3] = {0, 0, 0};
     uint64_t ms_cnt[3] = {0, 0, 0};
+    // extension state owned by another translation unit of the library (kta_kafka.hip)
+    void *ext_state = nullptr;
+    void (*ext_free)(void *) = nullptr;
     std::string err;
 };
 
@@ -328,6 +331,7 @@ void kta_destroy(kta_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->s_compute) (void)hipStreamSynchronize(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamSynchronize(ctx->s_copy);
+    if (ctx->ext_state && ctx->ext_free) ctx->ext_free(ctx->ext_state);
     for (auto &st : ctx->stages) {
         free_host_batch(&st.host);
         free_device_batch(&st.dev);
@@ -741,7 +745,20 @@ int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int aliv
 
 } // extern "C"
 
-// exported for kta_synth.hip (same shared object)
+// exported for kta_synth.hip / kta_kafka.hip (same shared object)
+void **kta_internal_ext_slot(kta_ctx *ctx, void (*free_fn)(void *))
+{
+    ctx->ext_free = free_fn;
+    return &ctx->ext_state;
+}
+uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n)
+{
+    const uint64_t base = ctx->next_seq;
+    ctx->next_seq += n;
+    return base;
+}
+bool kta_internal_timing(kta_ctx *ctx) { return ctx->timing; }
+bool kta_internal_count_alive(kta_ctx *ctx) { return ctx->alive; }
 hipStream_t kta_internal_stream(kta_ctx *ctx) { return ctx->s_compute; }
 int kta_internal_device(kta_ctx *ctx) { return ctx->device; }
 void kta_internal_set_error(kta_ctx *ctx, const char *msg) { ctx->err = msg; }

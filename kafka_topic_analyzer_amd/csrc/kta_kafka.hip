@@ -1,0 +1,462 @@
+// kta_kafka.hip — Kafka record-batch v2 decode (include/kta_kafka.h): host header index +
+// gfx950 kernels that parse the varint-framed records of every batch into the struct-of-arrays
+// columns the metric kernels consume.
+//
+// Parallelisation: batches are independent (each carries its own base timestamp and record count),
+// records inside a batch form a linked list (record length prefixes), so the unit of parallelism is
+// the batch: one lane walks one batch.  A broker segment holds tens of thousands of batches per GB
+// (producer batch.size defaults to 16 KiB), so a fetch blob keeps every SIMD busy; the walk touches
+// only the record headers and the keys — value bytes are skipped, exactly as the reference's
+// handlers never read them (src/metric.rs:233-245).
+#include "../../include/kta_kafka.h"
+
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+hipStream_t kta_internal_stream(kta_ctx *ctx);
+int kta_internal_device(kta_ctx *ctx);
+void kta_internal_set_error(kta_ctx *ctx, const char *msg);
+void **kta_internal_ext_slot(kta_ctx *ctx, void (*free_fn)(void *));
+uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n);
+bool kta_internal_timing(kta_ctx *ctx);
+bool kta_internal_count_alive(kta_ctx *ctx);
+
+namespace {
+
+constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
+
+// ---- device-side byte reader over the blob (aligned 4-byte loads, one word cached) -------------
+struct Reader {
+    const uint32_t *words;
+    uint64_t pos;
+    uint64_t cached_idx;
+    uint32_t cached;
+
+    __device__ __forceinline__ uint32_t byte()
+    {
+        const uint64_t wi = pos >> 2;
+        if (wi != cached_idx) {
+            cached = words[wi];
+            cached_idx = wi;
+        }
+        const uint32_t b = (cached >> ((uint32_t)(pos & 3u) * 8u)) & 0xFFu;
+        pos++;
+        return b;
+    }
+};
+
+// unsigned LEB128 (at most 10 groups), then zig-zag
+__device__ __forceinline__ long long read_varlong(Reader &r)
+{
+    unsigned long long v = 0;
+    for (uint32_t shift = 0; shift < 70; shift += 7) {
+        const uint32_t b = r.byte();
+        v |= (unsigned long long)(b & 0x7Fu) << (shift < 64 ? shift : 63);
+        if (!(b & 0x80u)) break;
+    }
+    return (long long)(v >> 1) ^ -(long long)(v & 1ull);
+}
+
+// Walk one batch.  WRITE = false: only total the key bytes.  Returns false if the records overrun
+// the batch (corrupt / truncated batch).
+template <bool WRITE>
+__device__ __forceinline__ bool walk_batch(const uint32_t *words, const kta_kafka_batch_desc &d, bool want_keys,
+                                           int32_t *part, int32_t *klen_out, int32_t *vlen_out, int64_t *ts_out,
+                                           uint32_t *koff_out, uint8_t *kbytes_out, uint64_t *seq_out,
+                                           uint64_t seq_base, uint64_t *key_total)
+{
+    Reader r{words, d.byte_off + KTA_KAFKA_BATCH_HEADER, ~0ull, 0u};
+    const uint64_t batch_end = d.byte_off + d.batch_bytes;
+    uint64_t kb = 0;
+    bool ok = true;
+    int32_t j = 0;
+    for (; j < d.n_records; j++) {
+        if (r.pos >= batch_end) { ok = false; break; }
+        const long long len = read_varlong(r);
+        const uint64_t rec_end = r.pos + (uint64_t)len;
+        if (len < 0 || rec_end > batch_end) { ok = false; break; }
+        (void)r.byte();                                  // record attributes (unused)
+        const long long ts_delta = read_varlong(r);
+        (void)read_varlong(r);                           // offsetDelta
+        const long long kl = read_varlong(r);            // -1 = null key
+        const uint64_t key_pos = r.pos;
+        if (kl > 0) r.pos += (uint64_t)kl;
+        if (kl < -1 || r.pos > rec_end) { ok = false; break; }
+        const long long vl = read_varlong(r);            // -1 = null value (tombstone)
+        if (vl < -1 || r.pos + (uint64_t)(vl > 0 ? vl : 0) > rec_end) { ok = false; break; }
+        if (WRITE) {
+            const uint64_t i = d.record_base + (uint64_t)j;
+            part[i] = d.partition;
+            klen_out[i] = (int32_t)kl;
+            vlen_out[i] = (int32_t)vl;
+            ts_out[i] = (d.flags & KTA_KB_LOG_APPEND_TIME) ? d.max_ts_ms : d.base_ts_ms + ts_delta;
+            if (seq_out) seq_out[i] = seq_base + i;
+            if (want_keys) {
+                koff_out[i] = (uint32_t)(d.key_base + kb);
+                if (kl > 0) {
+                    Reader kr{words, key_pos, ~0ull, 0u};
+                    uint8_t *dst = kbytes_out + d.key_base + kb;
+                    for (long long b = 0; b < kl; b++) dst[b] = (uint8_t)kr.byte();
+                }
+            }
+        }
+        kb += kl > 0 ? (uint64_t)kl : 0;
+        r.pos = rec_end;                                 // skip the value and the headers
+    }
+    if (WRITE && !ok) {
+        // make the damage visible downstream: the remaining records carry partition -1
+        for (; j < d.n_records; j++) {
+            const uint64_t i = d.record_base + (uint64_t)j;
+            part[i] = -1; klen_out[i] = -1; vlen_out[i] = -1; ts_out[i] = -1;
+            if (seq_out) seq_out[i] = seq_base + i;
+            if (want_keys) koff_out[i] = (uint32_t)(d.key_base + kb);
+        }
+    }
+    *key_total = kb;
+    return ok;
+}
+
+__global__ __launch_bounds__(kLanesPerBlock) void kafka_key_sizes(const uint32_t *words, kta_kafka_batch_desc *descs,
+                                                                  uint64_t n_batches)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    uint64_t kb = 0;
+    (void)walk_batch<false>(words, d, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &kb);
+    descs[b].key_base = kb;
+}
+
+// exclusive scan of descs[].key_base (one workgroup; each thread owns a contiguous span)
+__global__ __launch_bounds__(1024) void kafka_scan_key_bases(kta_kafka_batch_desc *descs, uint64_t n, uint64_t *total)
+{
+    __shared__ uint64_t s[1024];
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t b = (uint64_t)threadIdx.x * per;
+    const uint64_t e = b + per < n ? b + per : n;
+    uint64_t t = 0;
+    for (uint64_t i = b; i < e; i++) t += descs[i].key_base;
+    s[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const uint64_t v = s[i];
+            s[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = s[threadIdx.x];
+    for (uint64_t i = b; i < e; i++) {
+        const uint64_t v = descs[i].key_base;
+        descs[i].key_base = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint32_t *words, const kta_kafka_batch_desc *descs,
+                                                               uint64_t n_batches, int want_keys, int32_t *part,
+                                                               int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
+                                                               uint8_t *kbytes, uint64_t *seq, uint64_t seq_base,
+                                                               unsigned long long *n_bad)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    uint64_t kb = 0;
+    const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, kbytes, seq, seq_base, &kb);
+    if (!ok) atomicAdd(n_bad, 1ull);
+}
+
+// ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
+struct KafkaState {
+    uint8_t *d_blob = nullptr;
+    uint64_t blob_cap = 0;
+    kta_kafka_batch_desc *d_descs = nullptr;
+    uint64_t desc_cap = 0;
+    uint64_t *d_scalars = nullptr; // [0] key-byte total, [1] bad batches
+    kta_batch out{};
+    uint64_t out_cap = 0, out_key_cap = 0;
+    std::vector<kta_kafka_batch_desc> descs;
+    std::vector<hipEvent_t> ev[2];
+    size_t ev_used[2] = {0, 0};
+    double ms_sum[2] = {0, 0};
+    uint64_t ms_cnt[2] = {0, 0};
+};
+
+void free_state(void *p)
+{
+    KafkaState *st = static_cast<KafkaState *>(p);
+    if (!st) return;
+    if (st->d_blob) (void)hipFree(st->d_blob);
+    if (st->d_descs) (void)hipFree(st->d_descs);
+    if (st->d_scalars) (void)hipFree(st->d_scalars);
+    if (st->out.partition) (void)hipFree(st->out.partition);
+    if (st->out.key_len) (void)hipFree(st->out.key_len);
+    if (st->out.val_len) (void)hipFree(st->out.val_len);
+    if (st->out.ts_ms) (void)hipFree(st->out.ts_ms);
+    if (st->out.key_off) (void)hipFree(st->out.key_off);
+    if (st->out.key_bytes) (void)hipFree(st->out.key_bytes);
+    for (auto &v : st->ev)
+        for (auto e : v) (void)hipEventDestroy(e);
+    delete st;
+}
+
+KafkaState *state_of(kta_ctx *ctx)
+{
+    void **slot = kta_internal_ext_slot(ctx, free_state);
+    if (!*slot) *slot = new KafkaState();
+    return static_cast<KafkaState *>(*slot);
+}
+
+int hip_err(kta_ctx *ctx, hipError_t e, const char *what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    kta_internal_set_error(ctx, m.c_str());
+    return e == hipErrorOutOfMemory ? KTA_ERR_NOMEM : KTA_ERR_HIP;
+}
+
+#define KK(ctx, call)                                            \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return hip_err(ctx, e__, #call);  \
+    } while (0)
+
+inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+inline uint16_t be16(const uint8_t *p) { return (uint16_t)(((uint16_t)p[0] << 8) | p[1]); }
+
+int drain(kta_ctx *ctx, KafkaState *st)
+{
+    KK(ctx, hipStreamSynchronize(kta_internal_stream(ctx)));
+    for (int k = 0; k < 2; k++) {
+        for (size_t i = 0; i + 1 < st->ev_used[k]; i += 2) {
+            float ms = 0.f;
+            KK(ctx, hipEventElapsedTime(&ms, st->ev[k][i], st->ev[k][i + 1]));
+            st->ms_sum[k] += ms;
+            st->ms_cnt[k]++;
+        }
+        st->ev_used[k] = 0;
+    }
+    return KTA_OK;
+}
+
+int pair(kta_ctx *ctx, KafkaState *st, int k, hipEvent_t *a, hipEvent_t *b)
+{
+    if (st->ev_used[k] + 2 > 1024) {
+        int rc = drain(ctx, st);
+        if (rc != KTA_OK) return rc;
+    }
+    while (st->ev[k].size() < st->ev_used[k] + 2) {
+        hipEvent_t e;
+        KK(ctx, hipEventCreate(&e));
+        st->ev[k].push_back(e);
+    }
+    *a = st->ev[k][st->ev_used[k]];
+    *b = st->ev[k][st->ev_used[k] + 1];
+    st->ev_used[k] += 2;
+    return KTA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, uint64_t blob_offset,
+                         uint64_t record_base_start, kta_kafka_batch_desc *descs, uint64_t cap,
+                         kta_kafka_index_stats *stats)
+{
+    if (!bytes || !stats || (cap && !descs)) return KTA_ERR_INVALID;
+    memset(stats, 0, sizeof(*stats));
+    uint64_t pos = 0, rec = record_base_start, nb = 0;
+    while (pos + 12 <= len) {
+        const int32_t batch_length = (int32_t)be32(bytes + pos + 8);
+        if (batch_length < KTA_KAFKA_BATCH_HEADER - 12) break;           // not a v2 batch header: stop
+        const uint64_t total = 12ull + (uint64_t)batch_length;
+        if (pos + total > len) break;                                     // partial batch at the end of a fetch
+        const uint8_t magic = bytes[pos + 16];
+        if (magic != 2) {
+            stats->n_old_magic++;
+        } else {
+            const uint16_t attrs = be16(bytes + pos + 21);
+            const int32_t count = (int32_t)be32(bytes + pos + 57);
+            if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
+            else if (attrs & 0x07) stats->n_compressed++;                 // compressed: not decoded here
+            else if (count > 0) {
+                if (nb < cap) {
+                    kta_kafka_batch_desc &d = descs[nb];
+                    d.byte_off = blob_offset + pos;
+                    d.record_base = rec;
+                    d.key_base = 0;
+                    d.base_offset = (int64_t)be64(bytes + pos);
+                    d.base_ts_ms = (int64_t)be64(bytes + pos + 27);
+                    d.max_ts_ms = (int64_t)be64(bytes + pos + 35);
+                    d.batch_bytes = (uint32_t)total;
+                    d.partition = partition;
+                    d.n_records = count;
+                    d.flags = ((attrs & 0x08) ? KTA_KB_LOG_APPEND_TIME : 0u) | ((attrs & 0x10) ? KTA_KB_TRANSACTIONAL : 0u);
+                }
+                nb++;
+                rec += (uint64_t)count;
+            }
+        }
+        pos += total;
+    }
+    stats->n_batches = nb;
+    stats->n_records = rec - record_base_start;
+    stats->bytes_consumed = pos;
+    stats->trailing_bytes = len - pos;
+    return nb > cap ? KTA_ERR_CAPACITY : KTA_OK;
+}
+
+int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
+                            const kta_kafka_batch_desc *descs_host, uint64_t n_batches, uint64_t n_records,
+                            const kta_batch *out, uint64_t *n_key_bytes, uint64_t *n_bad_batches)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    if (n_key_bytes) *n_key_bytes = 0;
+    if (n_bad_batches) *n_bad_batches = 0;
+    if (n_batches == 0) return KTA_OK;
+    if (!blob_device || !descs_host) return KTA_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(blob_device) & 3u) != 0) {
+        kta_internal_set_error(ctx, "blob_device must be 4-byte aligned");
+        return KTA_ERR_INVALID;
+    }
+    if (n_records > out->capacity) {
+        kta_internal_set_error(ctx, "decoded records exceed the output batch capacity");
+        return KTA_ERR_CAPACITY;
+    }
+    (void)blob_len;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    hipStream_t s = kta_internal_stream(ctx);
+    KafkaState *st = state_of(ctx);
+    if (st->desc_cap < n_batches) {
+        KK(ctx, hipStreamSynchronize(s));
+        if (st->d_descs) (void)hipFree(st->d_descs);
+        st->d_descs = nullptr;
+        KK(ctx, hipMalloc((void **)&st->d_descs, n_batches * sizeof(kta_kafka_batch_desc)));
+        st->desc_cap = n_batches;
+    }
+    if (!st->d_scalars) KK(ctx, hipMalloc((void **)&st->d_scalars, 2 * sizeof(uint64_t)));
+    KK(ctx, hipMemcpyAsync(st->d_descs, descs_host, n_batches * sizeof(kta_kafka_batch_desc), hipMemcpyHostToDevice, s));
+    KK(ctx, hipMemsetAsync(st->d_scalars, 0, 2 * sizeof(uint64_t), s));
+    const bool want_keys = out->key_off && out->key_bytes;
+    const bool timing = kta_internal_timing(ctx);
+    const uint32_t grid = (uint32_t)((n_batches + kLanesPerBlock - 1) / kLanesPerBlock);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(blob_device);
+    hipEvent_t a = nullptr, b = nullptr;
+    uint64_t scal[2] = {0, 0};
+    if (want_keys) {
+        if (timing) { int rc = pair(ctx, st, 0, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
+        hipLaunchKernelGGL(kafka_key_sizes, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches);
+        hipLaunchKernelGGL(kafka_scan_key_bases, dim3(1), dim3(1024), 0, s, st->d_descs, n_batches, st->d_scalars);
+        KK(ctx, hipGetLastError());
+        if (timing) KK(ctx, hipEventRecord(b, s));
+        KK(ctx, hipMemcpyAsync(&scal[0], st->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        KK(ctx, hipStreamSynchronize(s));
+        if (scal[0] > out->key_bytes_capacity || scal[0] >= (1ull << 32)) {
+            if (n_key_bytes) *n_key_bytes = scal[0];
+            kta_internal_set_error(ctx, "decoded key bytes exceed the output batch key capacity");
+            return KTA_ERR_CAPACITY;
+        }
+    }
+    if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
+    hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
+                       want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
+                       out->key_bytes, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1));
+    KK(ctx, hipGetLastError());
+    if (timing) KK(ctx, hipEventRecord(b, s));
+    if (n_bad_batches) {
+        KK(ctx, hipMemcpyAsync(&scal[1], st->d_scalars + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        KK(ctx, hipStreamSynchronize(s));
+        *n_bad_batches = scal[1];
+    }
+    if (n_key_bytes) *n_key_bytes = scal[0];
+    return KTA_OK;
+}
+
+int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
+                      kta_kafka_index_stats *stats)
+{
+    if (!ctx || !bytes || !stats) return KTA_ERR_INVALID;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    hipStream_t s = kta_internal_stream(ctx);
+    KafkaState *st = state_of(ctx);
+    int rc = kta_flush(ctx); // keep consumption order with any per-message records staged earlier
+    if (rc != KTA_OK) return rc;
+    // index (grow the descriptor array on demand)
+    if (st->descs.size() < 1024) st->descs.resize(1024);
+    rc = kta_kafka_index_host(bytes, len, partition, 0, 0, st->descs.data(), st->descs.size(), stats);
+    if (rc == KTA_ERR_CAPACITY) {
+        st->descs.resize(stats->n_batches);
+        rc = kta_kafka_index_host(bytes, len, partition, 0, 0, st->descs.data(), st->descs.size(), stats);
+    }
+    if (rc != KTA_OK) return rc;
+    if (stats->n_batches == 0) return KTA_OK;
+    const bool keys = kta_internal_count_alive(ctx);
+    const uint64_t used = stats->bytes_consumed;
+    if (used >= (1ull << 32) && keys) {
+        kta_internal_set_error(ctx, "record set too large for one call with count_alive_keys (key offsets are u32)");
+        return KTA_ERR_CAPACITY;
+    }
+    // device buffers: the blob, and an output batch sized by the index (keys can never exceed the blob)
+    if (st->blob_cap < used + 16) {
+        KK(ctx, hipStreamSynchronize(s));
+        if (st->d_blob) (void)hipFree(st->d_blob);
+        st->d_blob = nullptr;
+        st->blob_cap = used + used / 4 + 4096;
+        KK(ctx, hipMalloc((void **)&st->d_blob, st->blob_cap));
+    }
+    const uint64_t nrec = stats->n_records;
+    if (st->out_cap < nrec || (keys && st->out_key_cap < used)) {
+        KK(ctx, hipStreamSynchronize(s));
+        kta_batch &o = st->out;
+        if (o.partition) (void)hipFree(o.partition);
+        if (o.key_len) (void)hipFree(o.key_len);
+        if (o.val_len) (void)hipFree(o.val_len);
+        if (o.ts_ms) (void)hipFree(o.ts_ms);
+        if (o.key_off) (void)hipFree(o.key_off);
+        if (o.key_bytes) (void)hipFree(o.key_bytes);
+        memset(&o, 0, sizeof(o));
+        st->out_cap = nrec + nrec / 4 + 1024;
+        st->out_key_cap = keys ? used + used / 4 + 4096 : 0;
+        KK(ctx, hipMalloc((void **)&o.partition, st->out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&o.key_len, st->out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&o.val_len, st->out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&o.ts_ms, st->out_cap * 8 + 16));
+        if (keys) {
+            KK(ctx, hipMalloc((void **)&o.key_off, st->out_cap * 4 + 16));
+            KK(ctx, hipMalloc((void **)&o.key_bytes, st->out_key_cap + 16));
+        }
+        o.capacity = st->out_cap;
+        o.key_bytes_capacity = st->out_key_cap < (1ull << 32) ? st->out_key_cap : (1ull << 32) - 1;
+    }
+    KK(ctx, hipMemcpyAsync(st->d_blob, bytes, used, hipMemcpyHostToDevice, s));
+    uint64_t kb = 0;
+    rc = kta_kafka_decode_device(ctx, st->d_blob, used, st->descs.data(), stats->n_batches, nrec, &st->out, &kb, nullptr);
+    if (rc != KTA_OK) return rc;
+    const uint64_t base = kta_internal_take_seq(ctx, nrec);
+    return kta_submit_device(ctx, &st->out, nrec, base);
+}
+
+int kta_kafka_time_stats(kta_ctx *ctx, float avg_ms[2], uint64_t launches[2])
+{
+    if (!ctx || !avg_ms || !launches) return KTA_ERR_INVALID;
+    KafkaState *st = state_of(ctx);
+    int rc = drain(ctx, st);
+    if (rc != KTA_OK) return rc;
+    for (int k = 0; k < 2; k++) {
+        launches[k] = st->ms_cnt[k];
+        avg_ms[k] = st->ms_cnt[k] ? (float)(st->ms_sum[k] / (double)st->ms_cnt[k]) : -1.f;
+        st->ms_sum[k] = 0;
+        st->ms_cnt[k] = 0;
+    }
+    return KTA_OK;
+}
+
+} // extern "C"

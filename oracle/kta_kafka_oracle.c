@@ -1,0 +1,111 @@
+/*
+ * kta_kafka_oracle.c — CPU ORACLE for the Kafka record-batch v2 decode (TEST INFRASTRUCTURE).
+ *
+ * In the reference this step is not in the tree: `consumer.poll()` (src/kafka.rs:93) returns
+ * messages already decoded by librdkafka (rdkafka-sys 3.0.0+1.6.0 => librdkafka 1.6.0,
+ * Cargo.lock:612-613; the C file there is rdkafka_msgset_reader.c, v2 path).  This file restates the
+ * PUBLISHED wire format (Apache Kafka protocol guide, "Record Batch"; KIP-98) and what a consumer
+ * delivers per record, as a plain sequential decoder.  Pinned by: round trips against an independent
+ * Python ENCODER (tests/kafka_format.py) whose inputs are the expected outputs, and a committed
+ * byte-level fixture (tests/golden/kafka_v2_recordset.*).  Parity with librdkafka itself is
+ * unpinned (not installed in the image).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+typedef struct {
+    uint64_t control_batches, compressed_batches, old_magic_batches, trailing_bytes, bad_batches, batches;
+} kto_kafka_stats;
+
+static uint64_t rd_be(const uint8_t *p, int n)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < n; i++) v = (v << 8) | p[i];
+    return v;
+}
+
+/* zig-zag varint; returns bytes consumed (0 on overrun) */
+static size_t rd_varint(const uint8_t *p, const uint8_t *end, int64_t *out)
+{
+    uint64_t v = 0;
+    size_t i = 0;
+    for (;;) {
+        if (p + i >= end || i >= 10) return 0;
+        uint8_t b = p[i];
+        v |= (uint64_t)(b & 0x7f) << (7 * i);
+        i++;
+        if (!(b & 0x80)) break;
+    }
+    *out = (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+    return i;
+}
+
+/* Decode one record set.  Output arrays may be NULL (count only).  Returns the number of records. */
+int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, int32_t *part, int32_t *klen,
+                         int32_t *vlen, int64_t *ts_ms, int64_t *offsets, uint32_t *koff, uint8_t *kbytes,
+                         uint64_t *n_key_bytes, kto_kafka_stats *st)
+{
+    uint64_t pos = 0, n = 0, kb = 0;
+    memset(st, 0, sizeof *st);
+    while (pos + 12 <= len) {
+        int32_t batch_length = (int32_t)rd_be(bytes + pos + 8, 4);
+        if (batch_length < 49) break;
+        uint64_t total = 12 + (uint64_t)batch_length;
+        if (pos + total > len) break;
+        const uint8_t *b = bytes + pos, *bend = b + total;
+        if (b[16] != 2) { st->old_magic_batches++; pos += total; continue; }
+        uint16_t attrs = (uint16_t)rd_be(b + 21, 2);
+        if (attrs & 0x20) { st->control_batches++; pos += total; continue; }
+        if (attrs & 0x07) { st->compressed_batches++; pos += total; continue; }
+        int64_t base_offset = (int64_t)rd_be(b, 8);
+        int64_t base_ts = (int64_t)rd_be(b + 27, 8), max_ts = (int64_t)rd_be(b + 35, 8);
+        int32_t count = (int32_t)rd_be(b + 57, 4);
+        if (count <= 0) { pos += total; continue; }
+        st->batches++;
+        const uint8_t *p = b + 61;
+        int bad = 0;
+        for (int32_t j = 0; j < count; j++) {
+            int64_t rlen, tsd, offd, kl, vl;
+            size_t c;
+            if (bad || p >= bend || !(c = rd_varint(p, bend, &rlen)) || rlen < 0 || p + c + rlen > bend) bad = 1;
+            if (!bad) {
+                const uint8_t *q = p + c, *rend = q + rlen;
+                q += 1; /* record attributes */
+                size_t c1 = rd_varint(q, rend, &tsd); q += c1;
+                size_t c2 = c1 ? rd_varint(q, rend, &offd) : 0; q += c2;
+                size_t c3 = c2 ? rd_varint(q, rend, &kl) : 0; q += c3;
+                if (!c3 || kl < -1 || (kl > 0 && q + kl > rend)) bad = 1;
+                const uint8_t *kp = q;
+                if (!bad && kl > 0) q += kl;
+                size_t c4 = bad ? 0 : rd_varint(q, rend, &vl);
+                if (!bad && (!c4 || vl < -1 || q + c4 + (vl > 0 ? vl : 0) > rend)) bad = 1;
+                if (!bad) {
+                    if (part) {
+                        part[n] = partition; klen[n] = (int32_t)kl; vlen[n] = (int32_t)vl;
+                        ts_ms[n] = (attrs & 0x08) ? max_ts : base_ts + tsd;
+                        if (offsets) offsets[n] = base_offset + offd;
+                        if (koff) koff[n] = (uint32_t)kb;
+                        if (kbytes && kl > 0) memcpy(kbytes + kb, kp, (size_t)kl);
+                    }
+                    if (kl > 0) kb += (uint64_t)kl;
+                    p = rend; /* headers are skipped */
+                    n++;
+                    continue;
+                }
+            }
+            /* corrupt batch: the product marks the remaining records with partition -1 */
+            if (part) {
+                part[n] = -1; klen[n] = -1; vlen[n] = -1; ts_ms[n] = -1;
+                if (offsets) offsets[n] = -1;
+                if (koff) koff[n] = (uint32_t)kb;
+            }
+            n++;
+        }
+        if (bad) st->bad_batches++;
+        pos += total;
+    }
+    st->trailing_bytes = len - pos;
+    if (n_key_bytes) *n_key_bytes = kb;
+    return (int64_t)n;
+}

@@ -117,7 +117,29 @@ def report_golden():
     return out
 
 
+def kafka_fixture():
+    """A small byte-level Kafka v2 record set with every feature the decoder distinguishes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kafka_format as K
+    b1 = [(0, b"k", b"v"), (5, None, None), (-3, b"", b""), (70000, b"key-\xff", b"x" * 200, [(b"h", b"1"), (b"n", None)])]
+    b2 = [(1, b"second-batch", None)]
+    blob = K.encode_batch(100, b1, 1600000000000)
+    blob += K.encode_batch(104, [(0, b"ctl", b"ctl")], 1600000000100, attributes=0x30)          # control batch
+    blob += K.encode_batch(105, b2, 1600000001000, attributes=0x08, max_ts=1600000009999)       # LogAppendTime
+    blob += K.encode_batch(106, [(0, b"z", b"z")], 1600000002000, attributes=0x02)              # "snappy": skipped
+    blob += K.encode_batch(107, [(0, b"old", b"old")], 1600000003000, magic=1)                  # magic 1: skipped
+    blob += K.encode_batch(108, [(0, b"tail", b"tail")], 1600000004000)[:30]                    # partial tail
+    keys = [b"k", b"", b"key-\xff", b"second-batch"]
+    expect = {"partition": [9] * 5, "key_len": [1, -1, 0, 5, 12], "val_len": [1, -1, 0, 200, -1],
+              "ts_ms": [1600000000000, 1600000000005, 1599999999997, 1600000070000, 1600000009999],
+              "offset": [100, 101, 102, 103, 105], "key_bytes_hex": b"".join(keys).hex(),
+              "control_batches": 1, "compressed_batches": 1, "old_magic_batches": 1, "trailing_bytes": 30}
+    return {"partition": 9, "blob_hex": blob.hex(), "expect": expect}
+
+
 def main():
+    with open(os.path.join(HERE, "kafka_v2_recordset.json"), "w") as f:
+        json.dump(kafka_fixture(), f, indent=0)
     with open(os.path.join(HERE, "fnv32_kats.json"), "w") as f:
         json.dump(fnv_vectors(), f, indent=0)
     S = scenarios()

@@ -148,3 +148,27 @@ def analytics(cols, P):
                                                               "part_max_ts_sec", "part_smallest", "part_largest")])
     L.kto_analytics_free(a)
     return out
+
+
+class KafkaStats(C.Structure):
+    _fields_ = [("control_batches", C.c_uint64), ("compressed_batches", C.c_uint64), ("old_magic_batches", C.c_uint64),
+                ("trailing_bytes", C.c_uint64), ("bad_batches", C.c_uint64), ("batches", C.c_uint64)]
+
+
+def kafka_decode(blob: bytes, partition: int):
+    """The oracle's sequential decode of one Kafka v2 record set -> (columns dict, stats)."""
+    L = lib()
+    L.kto_kafka_decode.restype = C.c_int64
+    L.kto_kafka_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_int32] + [C.c_void_p] * 7 + [C.POINTER(C.c_uint64),
+                                                                                          C.POINTER(KafkaStats)]
+    st, kb = KafkaStats(), C.c_uint64()
+    n = L.kto_kafka_decode(blob, len(blob), partition, None, None, None, None, None, None, None, C.byref(kb), C.byref(st))
+    cols = {"partition": np.zeros(n, np.int32), "key_len": np.zeros(n, np.int32), "val_len": np.zeros(n, np.int32),
+            "ts_ms": np.zeros(n, np.int64), "offset": np.zeros(n, np.int64), "key_off": np.zeros(n, np.uint32),
+            "key_bytes": np.zeros(max(kb.value, 1), np.uint8)}
+    n2 = L.kto_kafka_decode(blob, len(blob), partition, cols["partition"].ctypes.data, cols["key_len"].ctypes.data,
+                            cols["val_len"].ctypes.data, cols["ts_ms"].ctypes.data, cols["offset"].ctypes.data,
+                            cols["key_off"].ctypes.data, cols["key_bytes"].ctypes.data, C.byref(kb), C.byref(st))
+    assert n2 == n
+    cols["key_bytes"] = cols["key_bytes"][:kb.value]
+    return cols, st

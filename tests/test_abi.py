@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("kta_hip.h", "kta_synth.h"):
+    for h in ("kta_hip.h", "kta_synth.h", "kta_kafka.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         # prototypes only (skip the static inline generator definitions)

@@ -1,0 +1,171 @@
+"""Kafka record-batch v2 decode.  CPU: the oracle decoder and the product's host
+header index against record sets built by the independent encoder (expected output = encoder input)
+and against a committed byte-level fixture.  GPU: the device decode and the end-to-end
+`kta_kafka_consume` against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kafka_topic_analyzer_amd as kta
+from kafka_topic_analyzer_amd import _native as N
+import kafka_format as K
+from helpers import GOLDEN, NOW
+from kafka_cases import assert_columns, random_record_set
+from oracle_c import Oracle, kafka_decode
+
+
+def index_host(blob, partition, cap=None):
+    lib = N.load()
+    st = N.KtaKafkaIndexStats()
+    n = cap if cap is not None else 1 << 16
+    descs = (N.KtaKafkaBatchDesc * n)()
+    rc = lib.kta_kafka_index_host(blob, len(blob), partition, 0, 0, descs, n, C.byref(st))
+    return rc, descs, st
+
+
+def test_encoder_primitives():
+    assert K.crc32c(b"123456789") == 0xE3069283  # the CRC-32C check value
+    assert [K.varint(v) for v in (0, -1, 1, 63, 64, 300)] == [b"\x00", b"\x01", b"\x02", b"\x7e", b"\x80\x01", b"\xd8\x04"]
+
+
+def test_golden_fixture_bytes_and_decode():
+    fx = json.load(open(os.path.join(GOLDEN, "kafka_v2_recordset.json")))
+    blob = bytes.fromhex(fx["blob_hex"])
+    cols, st = kafka_decode(blob, fx["partition"])
+    e = fx["expect"]
+    assert list(cols["partition"]) == e["partition"] and list(cols["key_len"]) == e["key_len"]
+    assert list(cols["val_len"]) == e["val_len"] and list(cols["ts_ms"]) == e["ts_ms"]
+    assert list(cols["offset"]) == e["offset"]
+    assert cols["key_bytes"].tobytes().hex() == e["key_bytes_hex"]
+    assert (st.control_batches, st.compressed_batches, st.old_magic_batches, st.trailing_bytes) == \
+        (e["control_batches"], e["compressed_batches"], e["old_magic_batches"], e["trailing_bytes"])
+    # every batch in the fixture carries a valid CRC-32C (the encoder is a faithful producer)
+    pos = 0
+    while pos + 12 <= len(blob) - e["trailing_bytes"]:
+        total = 12 + int.from_bytes(blob[pos + 8:pos + 12], "big")
+        if blob[pos + 16] == 2:
+            assert int.from_bytes(blob[pos + 17:pos + 21], "big") == K.crc32c(blob[pos + 21:pos + total])
+        pos += total
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_oracle_decodes_what_the_encoder_built(seed):
+    rng = np.random.default_rng(seed)
+    blob, expected, info = random_record_set(rng, 40, big=(seed == 5))
+    cols, st = kafka_decode(blob, 3)
+    assert_columns(cols, expected)
+    assert (st.control_batches, st.compressed_batches, st.old_magic_batches) == \
+        (info["control"], info["compressed"], info["old_magic"])
+    assert st.trailing_bytes == 0 and st.bad_batches == 0
+
+
+def test_host_index_matches_oracle_and_handles_partial_tail():
+    rng = np.random.default_rng(11)
+    blob, expected, info = random_record_set(rng, 60)
+    tail = K.encode_batch(1, [(0, b"k", b"v" * 100)], 1)[:40]  # a fetch response may end mid-batch
+    rc, descs, st = index_host(blob + tail, 7)
+    assert rc == N.KTA_OK
+    cols, ost = kafka_decode(blob + tail, 7)
+    assert st.n_records == len(cols["partition"]) == len(expected[0])
+    assert st.n_batches == ost.batches
+    assert (st.n_control_batches, st.n_compressed, st.n_old_magic) == (info["control"], info["compressed"], info["old_magic"])
+    assert st.trailing_bytes == len(tail) == ost.trailing_bytes and st.bytes_consumed == len(blob)
+    run = 0
+    for i in range(st.n_batches):
+        d = descs[i]
+        assert d.record_base == run and d.partition == 7 and d.n_records > 0
+        assert int.from_bytes(blob[d.byte_off + 57:d.byte_off + 61], "big") == d.n_records
+        assert d.batch_bytes == 12 + int.from_bytes(blob[d.byte_off + 8:d.byte_off + 12], "big")
+        run += d.n_records
+    # too few descriptors: reports how many are needed
+    rc, _, st2 = index_host(blob, 7, cap=3)
+    assert rc == N.KTA_ERR_CAPACITY and st2.n_batches == st.n_batches
+    # garbage / empty input
+    rc, _, st3 = index_host(b"\x00" * 7, 0)
+    assert rc == N.KTA_OK and st3.n_batches == 0 and st3.trailing_bytes == 7
+
+
+def test_oracle_marks_corrupt_batches():
+    good = K.encode_batch(0, [(0, b"a", b"b"), (1, b"c", None)], 1000)
+    # recordsCount says 3 but only 2 records are present
+    bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
+    cols, st = kafka_decode(good + bad, 0)
+    assert st.bad_batches == 1 and list(cols["partition"]) == [0, 0, 0, 0, -1]
+
+
+# --------------------------------------------------------------------------------------------- GPU
+def _decode_on_device(h, blob, partition, with_keys):
+    lib = N.load()
+    rc, descs, st = index_host(blob, partition)
+    assert rc == N.KTA_OK
+    n = st.n_records
+    d_blob = C.c_void_p()
+    out = h.device_batch_alloc(max(n, 1), max(len(blob), 16) if with_keys else 0)
+    blob_dev = h.device_batch_alloc((len(blob) + 3) // 4 + 4)  # reuse a column as the raw byte buffer
+    arr = np.frombuffer(blob + b"\0" * ((-len(blob)) % 4), dtype=np.uint8).copy()
+    h._check(lib.kta_copy_to_device(h._ctx, blob_dev.partition, arr.ctypes.data, arr.nbytes))
+    kb, bad = C.c_uint64(), C.c_uint64()
+    h._check(lib.kta_kafka_decode_device(h._ctx, blob_dev.partition, len(blob), descs, st.n_batches, n, C.byref(out),
+                                         C.byref(kb), C.byref(bad)))
+    cols = h.download_batch(out, n, kb.value)
+    h.device_batch_free(out)
+    h.device_batch_free(blob_dev)
+    return cols, st, bad.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,with_keys", [(1, True), (2, False), (3, True), (5, True)])
+def test_device_decode_matches_encoder_and_oracle(seed, with_keys):
+    rng = np.random.default_rng(seed)
+    blob, expected, _ = random_record_set(rng, 300, big=(seed == 5))
+    want, _ = kafka_decode(blob, 3)
+    with kta.HipMetricHandler(8, now=NOW) as h:
+        cols, st, bad = _decode_on_device(h, blob, 3, with_keys)
+    assert bad == 0
+    assert_columns(cols, expected, key_check=with_keys)
+    for k in ("partition", "key_len", "val_len", "ts_ms") + (("key_off", "key_bytes") if with_keys else ()):
+        assert np.array_equal(cols[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_device_decode_reports_corrupt_batches():
+    good = K.encode_batch(0, [(0, b"a", b"b"), (1, b"c", None)], 1000)
+    bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
+    blob = good + bad + good
+    want, ost = kafka_decode(blob, 0)
+    with kta.HipMetricHandler(2, now=NOW) as h:
+        cols, st, nbad = _decode_on_device(h, blob, 0, True)
+        assert nbad == 1 == ost.bad_batches
+        assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count_alive", [False, True])
+def test_consume_raw_record_sets_end_to_end(count_alive):
+    """Raw record sets of several partitions -> kta_kafka_consume -> the same metrics (and alive-key
+    set) as the oracle handlers run over the oracle's decode, in the same consumption order."""
+    lib = N.load()
+    rng = np.random.default_rng(42)
+    P = 4
+    o = Oracle(NOW, count_alive)
+    with kta.HipMetricHandler(P, count_alive_keys=count_alive, now=NOW) as h:
+        for fetch in range(6):
+            part = fetch % P
+            blob, expected, _ = random_record_set(rng, 50, partition=part, key_space=80)
+            st = N.KtaKafkaIndexStats()
+            h._check(lib.kta_kafka_consume(h._ctx, blob, len(blob), part, C.byref(st)))
+            cols, _ = kafka_decode(blob, part)
+            assert st.n_records == len(cols["partition"])
+            o.run_soa({k: v for k, v in cols.items() if k != "offset"})
+        res, c = h.finish()
+        assert np.array_equal(c, o.counters(P))
+        mm = kta.MessageMetrics(res, c, NOW)
+        assert mm.earliest_message() == o.earliest() and mm.latest_message() == o.latest()
+        assert mm.smallest_message() == o.get("smallest_message") and mm.largest_message() == o.get("largest_message")
+        assert mm.overall_size() == o.get("overall_size")
+        if count_alive:
+            assert res.alive_keys == o.alive_keys()
+            assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
