@@ -37,6 +37,8 @@
 #include <stdint.h>
 #include "kta_hip.h"
 
+struct kta_synth_spec;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -50,7 +52,7 @@ extern "C" {
 typedef struct kta_kafka_batch_desc {
     uint64_t byte_off;    /* offset of the batch (its baseOffset field) in the blob          */
     uint64_t record_base; /* index of its first record in the output columns               */
-    uint64_t key_base;    /* offset of its first key byte in key_bytes (filled by the device) */
+    uint64_t key_base;    /* reserved (the batch's position in the blob)                            */
     int64_t base_offset;  /* Kafka offset of the first record                                */
     int64_t base_ts_ms;
     int64_t max_ts_ms;
@@ -77,9 +79,12 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                          uint64_t record_base_start, kta_kafka_batch_desc *descs, uint64_t cap,
                          kta_kafka_index_stats *stats);
 
-/* Device: parse the records of `n_batches` indexed batches out of `blob_device` into the device
- * columns `out` (capacity >= total records; key_off/key_bytes filled only if out->key_bytes is set).
- * `descs_host` is copied to the device.  *n_key_bytes receives the key bytes produced;
+/* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
+ * readable up to the next multiple of 16) into the device columns `out` (capacity >= total records).
+ * Keys are ZERO-COPY: when out->key_off is set, key_off[i] is the offset of record i's key inside the
+ * blob, so the caller passes `blob_device` itself as `key_bytes` when submitting the columns
+ * (out->key_bytes is ignored; the blob must then be < 4 GiB and stay alive until the kernels ran).
+ * `descs_host` is copied to the device.  *n_key_bytes receives the total key bytes seen;
  * *n_bad_batches the batches whose records overran the batch (their remaining records are written
  * as unkeyed tombstones on partition -1 so that they are reported, not counted). */
 int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
@@ -91,8 +96,16 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
 int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
                       kta_kafka_index_stats *stats);
 
-/* Average duration (ms) of the decode kernels since the previous call: [0] key-size pass,
- * [1] decode pass; launches[] their counts.  Needs kta_set_timing(ctx, 1). */
+/* Producer side, for benchmarks and fixtures: encode records [first, first+n) of the synthetic
+ * topic (include/kta_synth.h) as v2 record batches of `records_per_batch` records, exactly as a
+ * broker segment would hold them (valid CRC-32C, zero-filled values of the right length, the
+ * spec's partition ignored: a record set belongs to ONE partition, chosen at consume time).
+ * `out` may be NULL to size the buffer; *len receives the bytes written / needed. */
+int kta_kafka_encode_synth_host(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
+                                uint32_t records_per_batch, uint8_t *out, uint64_t cap, uint64_t *len);
+
+/* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);
+ * launches[] the counts.  Needs kta_set_timing(ctx, 1). */
 int kta_kafka_time_stats(kta_ctx *ctx, float avg_ms[2], uint64_t launches[2]);
 
 #ifdef __cplusplus

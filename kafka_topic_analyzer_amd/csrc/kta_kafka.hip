@@ -9,6 +9,7 @@
 // only the record headers and the keys — value bytes are skipped, exactly as the reference's
 // handlers never read them (src/metric.rs:233-245).
 #include "../../include/kta_kafka.h"
+#include "../../include/kta_synth.h"
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -28,21 +29,25 @@ namespace {
 
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
 
-// ---- device-side byte reader over the blob (aligned 4-byte loads, one word cached) -------------
+// ---- device-side byte reader over the blob: aligned 16-byte loads, one block cached -------------
+// A record header (length, attributes, timestamp delta, offset delta, key length) is <= 26 bytes, so
+// it costs one or two dependent loads instead of one per varint.
 struct Reader {
-    const uint32_t *words;
+    const uint4 *blocks;
     uint64_t pos;
     uint64_t cached_idx;
-    uint32_t cached;
+    uint4 cached;
 
     __device__ __forceinline__ uint32_t byte()
     {
-        const uint64_t wi = pos >> 2;
-        if (wi != cached_idx) {
-            cached = words[wi];
-            cached_idx = wi;
+        const uint64_t bi = pos >> 4;
+        if (bi != cached_idx) {
+            cached = blocks[bi];
+            cached_idx = bi;
         }
-        const uint32_t b = (cached >> ((uint32_t)(pos & 3u) * 8u)) & 0xFFu;
+        const uint32_t w = (uint32_t)(pos >> 2) & 3u;
+        const uint32_t word = w == 0 ? cached.x : (w == 1 ? cached.y : (w == 2 ? cached.z : cached.w));
+        const uint32_t b = (word >> ((uint32_t)(pos & 3u) * 8u)) & 0xFFu;
         pos++;
         return b;
     }
@@ -63,12 +68,12 @@ __device__ __forceinline__ long long read_varlong(Reader &r)
 // Walk one batch.  WRITE = false: only total the key bytes.  Returns false if the records overrun
 // the batch (corrupt / truncated batch).
 template <bool WRITE>
-__device__ __forceinline__ bool walk_batch(const uint32_t *words, const kta_kafka_batch_desc &d, bool want_keys,
+__device__ __forceinline__ bool walk_batch(const uint4 *words, const kta_kafka_batch_desc &d, bool want_keys,
                                            int32_t *part, int32_t *klen_out, int32_t *vlen_out, int64_t *ts_out,
-                                           uint32_t *koff_out, uint8_t *kbytes_out, uint64_t *seq_out,
+                                           uint32_t *koff_out, uint64_t blob_base, uint64_t *seq_out,
                                            uint64_t seq_base, uint64_t *key_total)
 {
-    Reader r{words, d.byte_off + KTA_KAFKA_BATCH_HEADER, ~0ull, 0u};
+    Reader r{words, d.byte_off + KTA_KAFKA_BATCH_HEADER, ~0ull, make_uint4(0, 0, 0, 0)};
     const uint64_t batch_end = d.byte_off + d.batch_bytes;
     uint64_t kb = 0;
     bool ok = true;
@@ -94,14 +99,8 @@ __device__ __forceinline__ bool walk_batch(const uint32_t *words, const kta_kafk
             vlen_out[i] = (int32_t)vl;
             ts_out[i] = (d.flags & KTA_KB_LOG_APPEND_TIME) ? d.max_ts_ms : d.base_ts_ms + ts_delta;
             if (seq_out) seq_out[i] = seq_base + i;
-            if (want_keys) {
-                koff_out[i] = (uint32_t)(d.key_base + kb);
-                if (kl > 0) {
-                    Reader kr{words, key_pos, ~0ull, 0u};
-                    uint8_t *dst = kbytes_out + d.key_base + kb;
-                    for (long long b = 0; b < kl; b++) dst[b] = (uint8_t)kr.byte();
-                }
-            }
+            // zero-copy keys: key_off points at the key inside the raw blob (key_bytes == the blob)
+            if (want_keys) koff_out[i] = (uint32_t)(kl > 0 ? key_pos - blob_base : 0);
         }
         kb += kl > 0 ? (uint64_t)kl : 0;
         r.pos = rec_end;                                 // skip the value and the headers
@@ -112,65 +111,26 @@ __device__ __forceinline__ bool walk_batch(const uint32_t *words, const kta_kafk
             const uint64_t i = d.record_base + (uint64_t)j;
             part[i] = -1; klen_out[i] = -1; vlen_out[i] = -1; ts_out[i] = -1;
             if (seq_out) seq_out[i] = seq_base + i;
-            if (want_keys) koff_out[i] = (uint32_t)(d.key_base + kb);
+            if (want_keys) koff_out[i] = 0u;
         }
     }
     *key_total = kb;
     return ok;
 }
 
-__global__ __launch_bounds__(kLanesPerBlock) void kafka_key_sizes(const uint32_t *words, kta_kafka_batch_desc *descs,
-                                                                  uint64_t n_batches)
-{
-    const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
-    if (b >= n_batches) return;
-    const kta_kafka_batch_desc d = descs[b];
-    uint64_t kb = 0;
-    (void)walk_batch<false>(words, d, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &kb);
-    descs[b].key_base = kb;
-}
-
-// exclusive scan of descs[].key_base (one workgroup; each thread owns a contiguous span)
-__global__ __launch_bounds__(1024) void kafka_scan_key_bases(kta_kafka_batch_desc *descs, uint64_t n, uint64_t *total)
-{
-    __shared__ uint64_t s[1024];
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t b = (uint64_t)threadIdx.x * per;
-    const uint64_t e = b + per < n ? b + per : n;
-    uint64_t t = 0;
-    for (uint64_t i = b; i < e; i++) t += descs[i].key_base;
-    s[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) {
-            const uint64_t v = s[i];
-            s[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-    __syncthreads();
-    uint64_t run = s[threadIdx.x];
-    for (uint64_t i = b; i < e; i++) {
-        const uint64_t v = descs[i].key_base;
-        descs[i].key_base = run;
-        run += v;
-    }
-}
-
-__global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint32_t *words, const kta_kafka_batch_desc *descs,
+__global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *words, const kta_kafka_batch_desc *descs,
                                                                uint64_t n_batches, int want_keys, int32_t *part,
                                                                int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
-                                                               uint8_t *kbytes, uint64_t *seq, uint64_t seq_base,
-                                                               unsigned long long *n_bad)
+                                                               uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
+                                                               unsigned long long *n_bad, unsigned long long *n_keyb)
 {
     const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
     uint64_t kb = 0;
-    const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, kbytes, seq, seq_base, &kb);
+    const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, blob_base, seq, seq_base, &kb);
     if (!ok) atomicAdd(n_bad, 1ull);
+    if (want_keys && kb) atomicAdd(n_keyb, (unsigned long long)kb);
 }
 
 // ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
@@ -181,7 +141,7 @@ struct KafkaState {
     uint64_t desc_cap = 0;
     uint64_t *d_scalars = nullptr; // [0] key-byte total, [1] bad batches
     kta_batch out{};
-    uint64_t out_cap = 0, out_key_cap = 0;
+    uint64_t out_cap = 0;
     std::vector<kta_kafka_batch_desc> descs;
     std::vector<hipEvent_t> ev[2];
     size_t ev_used[2] = {0, 0};
@@ -201,7 +161,6 @@ void free_state(void *p)
     if (st->out.val_len) (void)hipFree(st->out.val_len);
     if (st->out.ts_ms) (void)hipFree(st->out.ts_ms);
     if (st->out.key_off) (void)hipFree(st->out.key_off);
-    if (st->out.key_bytes) (void)hipFree(st->out.key_bytes);
     for (auto &v : st->ev)
         for (auto e : v) (void)hipEventDestroy(e);
     delete st;
@@ -292,7 +251,7 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     kta_kafka_batch_desc &d = descs[nb];
                     d.byte_off = blob_offset + pos;
                     d.record_base = rec;
-                    d.key_base = 0;
+                    d.key_base = blob_offset + pos; // the batch's keys live at the batch's own blob offset
                     d.base_offset = (int64_t)be64(bytes + pos);
                     d.base_ts_ms = (int64_t)be64(bytes + pos + 27);
                     d.max_ts_ms = (int64_t)be64(bytes + pos + 35);
@@ -323,15 +282,14 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     if (n_bad_batches) *n_bad_batches = 0;
     if (n_batches == 0) return KTA_OK;
     if (!blob_device || !descs_host) return KTA_ERR_INVALID;
-    if ((reinterpret_cast<uintptr_t>(blob_device) & 3u) != 0) {
-        kta_internal_set_error(ctx, "blob_device must be 4-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(blob_device) & 15u) != 0) {
+        kta_internal_set_error(ctx, "blob_device must be 16-byte aligned (and padded to a multiple of 16 bytes)");
         return KTA_ERR_INVALID;
     }
     if (n_records > out->capacity) {
         kta_internal_set_error(ctx, "decoded records exceed the output batch capacity");
         return KTA_ERR_CAPACITY;
     }
-    (void)blob_len;
     KK(ctx, hipSetDevice(kta_internal_device(ctx)));
     hipStream_t s = kta_internal_stream(ctx);
     KafkaState *st = state_of(ctx);
@@ -345,38 +303,31 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     if (!st->d_scalars) KK(ctx, hipMalloc((void **)&st->d_scalars, 2 * sizeof(uint64_t)));
     KK(ctx, hipMemcpyAsync(st->d_descs, descs_host, n_batches * sizeof(kta_kafka_batch_desc), hipMemcpyHostToDevice, s));
     KK(ctx, hipMemsetAsync(st->d_scalars, 0, 2 * sizeof(uint64_t), s));
-    const bool want_keys = out->key_off && out->key_bytes;
+    // Zero-copy keys: key_off[i] is the key's offset inside the raw blob, so the caller passes the
+    // blob itself as `key_bytes` to kta_submit_device; nothing is copied.  out->key_bytes is ignored.
+    const bool want_keys = out->key_off != nullptr;
+    if (want_keys && blob_len >= (1ull << 32)) {
+        kta_internal_set_error(ctx, "record set must be < 4 GiB when key offsets are wanted (key_off is u32)");
+        return KTA_ERR_CAPACITY;
+    }
     const bool timing = kta_internal_timing(ctx);
     const uint32_t grid = (uint32_t)((n_batches + kLanesPerBlock - 1) / kLanesPerBlock);
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(blob_device);
+    const uint4 *words = reinterpret_cast<const uint4 *>(blob_device);
     hipEvent_t a = nullptr, b = nullptr;
     uint64_t scal[2] = {0, 0};
-    if (want_keys) {
-        if (timing) { int rc = pair(ctx, st, 0, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
-        hipLaunchKernelGGL(kafka_key_sizes, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches);
-        hipLaunchKernelGGL(kafka_scan_key_bases, dim3(1), dim3(1024), 0, s, st->d_descs, n_batches, st->d_scalars);
-        KK(ctx, hipGetLastError());
-        if (timing) KK(ctx, hipEventRecord(b, s));
-        KK(ctx, hipMemcpyAsync(&scal[0], st->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        KK(ctx, hipStreamSynchronize(s));
-        if (scal[0] > out->key_bytes_capacity || scal[0] >= (1ull << 32)) {
-            if (n_key_bytes) *n_key_bytes = scal[0];
-            kta_internal_set_error(ctx, "decoded key bytes exceed the output batch key capacity");
-            return KTA_ERR_CAPACITY;
-        }
-    }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
     hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
                        want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
-                       out->key_bytes, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1));
+                       (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
+                       reinterpret_cast<unsigned long long *>(st->d_scalars));
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
-    if (n_bad_batches) {
-        KK(ctx, hipMemcpyAsync(&scal[1], st->d_scalars + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    if (n_bad_batches || n_key_bytes) {
+        KK(ctx, hipMemcpyAsync(scal, st->d_scalars, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         KK(ctx, hipStreamSynchronize(s));
-        *n_bad_batches = scal[1];
+        if (n_bad_batches) *n_bad_batches = scal[1];
+        if (n_key_bytes) *n_key_bytes = scal[0];
     }
-    if (n_key_bytes) *n_key_bytes = scal[0];
     return KTA_OK;
 }
 
@@ -413,7 +364,7 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         KK(ctx, hipMalloc((void **)&st->d_blob, st->blob_cap));
     }
     const uint64_t nrec = stats->n_records;
-    if (st->out_cap < nrec || (keys && st->out_key_cap < used)) {
+    if (st->out_cap < nrec || (keys && !st->out.key_off)) {
         KK(ctx, hipStreamSynchronize(s));
         kta_batch &o = st->out;
         if (o.partition) (void)hipFree(o.partition);
@@ -421,27 +372,131 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         if (o.val_len) (void)hipFree(o.val_len);
         if (o.ts_ms) (void)hipFree(o.ts_ms);
         if (o.key_off) (void)hipFree(o.key_off);
-        if (o.key_bytes) (void)hipFree(o.key_bytes);
         memset(&o, 0, sizeof(o));
         st->out_cap = nrec + nrec / 4 + 1024;
-        st->out_key_cap = keys ? used + used / 4 + 4096 : 0;
         KK(ctx, hipMalloc((void **)&o.partition, st->out_cap * 4 + 16));
         KK(ctx, hipMalloc((void **)&o.key_len, st->out_cap * 4 + 16));
         KK(ctx, hipMalloc((void **)&o.val_len, st->out_cap * 4 + 16));
         KK(ctx, hipMalloc((void **)&o.ts_ms, st->out_cap * 8 + 16));
-        if (keys) {
-            KK(ctx, hipMalloc((void **)&o.key_off, st->out_cap * 4 + 16));
-            KK(ctx, hipMalloc((void **)&o.key_bytes, st->out_key_cap + 16));
-        }
+        if (keys) KK(ctx, hipMalloc((void **)&o.key_off, st->out_cap * 4 + 16));
         o.capacity = st->out_cap;
-        o.key_bytes_capacity = st->out_key_cap < (1ull << 32) ? st->out_key_cap : (1ull << 32) - 1;
     }
+    st->out.key_bytes = keys ? st->d_blob : nullptr;   // zero-copy: keys are hashed in place in the raw log
+    st->out.key_bytes_capacity = keys ? used : 0;
     KK(ctx, hipMemcpyAsync(st->d_blob, bytes, used, hipMemcpyHostToDevice, s));
-    uint64_t kb = 0;
-    rc = kta_kafka_decode_device(ctx, st->d_blob, used, st->descs.data(), stats->n_batches, nrec, &st->out, &kb, nullptr);
+    rc = kta_kafka_decode_device(ctx, st->d_blob, used, st->descs.data(), stats->n_batches, nrec, &st->out, nullptr,
+                                 nullptr);
     if (rc != KTA_OK) return rc;
     const uint64_t base = kta_internal_take_seq(ctx, nrec);
     return kta_submit_device(ctx, &st->out, nrec, base);
+}
+
+// ---- producer side (host): synthetic topic -> v2 record batches ---------------------------------
+namespace {
+
+uint32_t g_crc_table[256];
+bool g_crc_ready = false;
+
+uint32_t crc32c(const uint8_t *p, size_t n)
+{
+    if (!g_crc_ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            g_crc_table[i] = c;
+        }
+        g_crc_ready = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = g_crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+size_t put_varint(uint8_t *dst, int64_t v)
+{
+    uint64_t z = ((uint64_t)v << 1) ^ (uint64_t)(v >> 63);
+    size_t i = 0;
+    while (z >= 0x80) {
+        if (dst) dst[i] = (uint8_t)(z | 0x80);
+        z >>= 7;
+        i++;
+    }
+    if (dst) dst[i] = (uint8_t)z;
+    return i + 1;
+}
+
+void put_be(uint8_t *p, uint64_t v, int n)
+{
+    for (int i = n - 1; i >= 0; i--) { p[i] = (uint8_t)v; v >>= 8; }
+}
+
+} // namespace
+
+int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
+                                uint8_t *out, uint64_t cap, uint64_t *len)
+{
+    if (!spec || !len || records_per_batch == 0) return KTA_ERR_INVALID;
+    uint64_t pos = 0;
+    bool fits = true;
+    std::vector<uint8_t> rec; // one batch's records
+    for (uint64_t b0 = 0; b0 < n; b0 += records_per_batch) {
+        const uint32_t cnt = (uint32_t)((n - b0) < records_per_batch ? (n - b0) : records_per_batch);
+        rec.clear();
+        int64_t base_ts = 0, max_ts = INT64_MIN;
+        for (uint32_t j = 0; j < cnt; j++) {
+            int32_t p, kl, vl;
+            int64_t ts;
+            kta_synth_record(spec, first + b0 + j, &p, &kl, &vl, &ts);
+            if (j == 0) base_ts = ts;
+            if (ts > max_ts) max_ts = ts;
+            uint8_t hdr[48];
+            size_t h = 0;
+            hdr[h++] = 0;                                   // record attributes
+            h += put_varint(hdr + h, ts - base_ts);
+            h += put_varint(hdr + h, (int64_t)j);
+            h += put_varint(hdr + h, kl);
+            const size_t klb = kl > 0 ? (size_t)kl : 0, vlb = vl > 0 ? (size_t)vl : 0;
+            uint8_t vh[12];
+            const size_t vhn = put_varint(vh, vl);
+            const size_t body = h + klb + vhn + vlb + 1;    // + headersCount (0)
+            uint8_t lh[12];
+            const size_t lhn = put_varint(lh, (int64_t)body);
+            const size_t at = rec.size();
+            rec.resize(at + lhn + body, 0);                 // values stay zero-filled
+            uint8_t *q = rec.data() + at;
+            memcpy(q, lh, lhn); q += lhn;
+            memcpy(q, hdr, h); q += h;
+            if (klb) {
+                const uint64_t kid = (uint64_t)kta_synth_key_id(spec, first + b0 + j);
+                for (size_t x = 0; x < klb; x++) q[x] = kta_synth_key_byte(spec, kid, (uint32_t)x);
+                q += klb;
+            }
+            memcpy(q, vh, vhn);                             // value bytes + the 0 headersCount are already zero
+        }
+        const uint64_t total = KTA_KAFKA_BATCH_HEADER + rec.size();
+        if (out && pos + total <= cap) {
+            uint8_t *h = out + pos;
+            put_be(h, first + b0, 8);                       // baseOffset
+            put_be(h + 8, total - 12, 4);                   // batchLength
+            put_be(h + 12, 0, 4);                           // partitionLeaderEpoch
+            h[16] = 2;                                      // magic
+            put_be(h + 21, 0, 2);                           // attributes: CreateTime, no codec
+            put_be(h + 23, cnt - 1, 4);                     // lastOffsetDelta
+            put_be(h + 27, (uint64_t)base_ts, 8);
+            put_be(h + 35, (uint64_t)max_ts, 8);
+            put_be(h + 43, ~0ull, 8);                       // producerId -1
+            put_be(h + 51, 0xFFFF, 2);                      // producerEpoch -1
+            put_be(h + 53, 0xFFFFFFFFull, 4);               // baseSequence -1
+            put_be(h + 57, cnt, 4);                         // recordsCount
+            memcpy(h + KTA_KAFKA_BATCH_HEADER, rec.data(), rec.size());
+            put_be(h + 17, crc32c(h + 21, total - 21), 4);
+        } else if (out) {
+            fits = false;
+        }
+        pos += total;
+    }
+    *len = pos;
+    return (!out || fits) ? KTA_OK : KTA_ERR_CAPACITY;
 }
 
 int kta_kafka_time_stats(kta_ctx *ctx, float avg_ms[2], uint64_t launches[2])

@@ -103,14 +103,17 @@ def _decode_on_device(h, blob, partition, with_keys):
     assert rc == N.KTA_OK
     n = st.n_records
     d_blob = C.c_void_p()
-    out = h.device_batch_alloc(max(n, 1), max(len(blob), 16) if with_keys else 0)
+    out = h.device_batch_alloc(max(n, 1), 16 if with_keys else 0)  # key_off only: keys stay in the blob
     blob_dev = h.device_batch_alloc((len(blob) + 3) // 4 + 4)  # reuse a column as the raw byte buffer
     arr = np.frombuffer(blob + b"\0" * ((-len(blob)) % 4), dtype=np.uint8).copy()
     h._check(lib.kta_copy_to_device(h._ctx, blob_dev.partition, arr.ctypes.data, arr.nbytes))
     kb, bad = C.c_uint64(), C.c_uint64()
     h._check(lib.kta_kafka_decode_device(h._ctx, blob_dev.partition, len(blob), descs, st.n_batches, n, C.byref(out),
                                          C.byref(kb), C.byref(bad)))
-    cols = h.download_batch(out, n, kb.value)
+    cols = h.download_batch(out, n, 0)
+    if with_keys:
+        cols["key_bytes"] = np.frombuffer(blob, dtype=np.uint8)  # zero-copy: key_off indexes the raw blob
+    cols["n_key_bytes"] = kb.value
     h.device_batch_free(out)
     h.device_batch_free(blob_dev)
     return cols, st, bad.value
@@ -125,9 +128,11 @@ def test_device_decode_matches_encoder_and_oracle(seed, with_keys):
     with kta.HipMetricHandler(8, now=NOW) as h:
         cols, st, bad = _decode_on_device(h, blob, 3, with_keys)
     assert bad == 0
-    assert_columns(cols, expected, key_check=with_keys)
-    for k in ("partition", "key_len", "val_len", "ts_ms") + (("key_off", "key_bytes") if with_keys else ()):
+    assert_columns(cols, expected, key_check=with_keys)   # keys compared by content through key_off
+    for k in ("partition", "key_len", "val_len", "ts_ms"):
         assert np.array_equal(cols[k], want[k]), k
+    if with_keys:
+        assert cols["n_key_bytes"] == len(want["key_bytes"]) == int(np.maximum(want["key_len"], 0).sum())
 
 
 @pytest.mark.gpu
