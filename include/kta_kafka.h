@@ -80,7 +80,7 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                          kta_kafka_index_stats *stats);
 
 /* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
- * readable up to the next multiple of 16) into the device columns `out` (capacity >= total records).
+ * readable for 32 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
  * Keys are ZERO-COPY: when out->key_off is set, key_off[i] is the offset of record i's key inside the
  * blob, so the caller passes `blob_device` itself as `key_bytes` when submitting the columns
  * (out->key_bytes is ignored; the blob must then be < 4 GiB and stay alive until the kernels ran).
@@ -103,6 +103,10 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
  * `out` may be NULL to size the buffer; *len receives the bytes written / needed. */
 int kta_kafka_encode_synth_host(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
                                 uint32_t records_per_batch, uint8_t *out, uint64_t cap, uint64_t *len);
+
+/* Decode kernel choice (process wide): 0 = one wave per batch, cooperative through an LDS window
+ * (default), 1 = one lane per batch (kept for comparison). */
+int kta_kafka_set_variant(int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);
  * launches[] the counts.  Needs kta_set_timing(ctx, 1). */

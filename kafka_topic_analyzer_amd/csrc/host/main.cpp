@@ -11,6 +11,9 @@
 // build, so the record source is chosen by the scheme of --bootstrap-server:
 //     synthetic://<c1..c5>[?records=N]   the synthetic topic of include/kta_synth.h
 //     dump://<path>                      a KTADUMP1 topic dump (host/dump.hpp)
+//     segment://<f0>[,<f1>...]           raw Kafka log segments (`*.log` files of a broker, record-batch
+//                                        v2, uncompressed): file k is partition k; decoded ON THE GPU
+//                                        (include/kta_kafka.h), the host only walks batch headers
 // anything else is refused.  Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
 // kta.batch=N, kta.write_dump=<path>), so no flag is added or renamed.
 #include <stdio.h>
@@ -24,6 +27,7 @@
 #include <vector>
 
 #include "dump.hpp"
+#include "kta_kafka.h"
 #include "kta_synth.h"
 #include "metric.hpp"
 
@@ -147,10 +151,22 @@ int main(int argc, char **argv)
     // ---- the record source (stands in for TopicAnalyzer, src/kafka.rs) ------------------------------
     const std::string &b = args.bootstrap;
     bool synthetic = b.rfind("synthetic://", 0) == 0, dump = b.rfind("dump://", 0) == 0;
-    if (!synthetic && !dump) {
+    const bool segment = b.rfind("segment://", 0) == 0;
+    if (!synthetic && !dump && !segment) {
         fprintf(stderr, "Consumer creation failed: this build has no librdkafka; --bootstrap-server must be "
-                        "synthetic://<c1..c5>[?records=N] or dump://<path>\n");
+                        "synthetic://<c1..c5>[?records=N], dump://<path> or segment://<log>[,<log>...]\n");
         return 101;
+    }
+    std::vector<std::string> segment_files;
+    if (segment) {
+        std::string rest = b.substr(strlen("segment://"));
+        size_t p0 = 0;
+        while (true) {
+            size_t c = rest.find(',', p0);
+            segment_files.push_back(rest.substr(p0, c == std::string::npos ? std::string::npos : c - p0));
+            if (c == std::string::npos) break;
+            p0 = c + 1;
+        }
     }
     kta_synth_spec spec{};
     uint64_t n_records = 0;
@@ -167,6 +183,9 @@ int main(int argc, char **argv)
         if (q != std::string::npos) n_records = strtoull(rest.c_str() + q + 8, nullptr, 10);
         hdr.n_partitions = spec.n_partitions;
         hdr.n_records = n_records;
+    } else if (segment) {
+        hdr.n_partitions = (uint32_t)segment_files.size();
+        n_records = 1;  // unknown until decoded; non-zero so the emptiness test below looks at the files
     } else {
         reader = new kta::DumpReader(b.substr(strlen("dump://")));
         if (!reader->ok() || !reader->read_header(&hdr)) {
@@ -187,7 +206,37 @@ int main(int argc, char **argv)
 
     std::vector<int64_t> start_offsets(P, 0), end_offsets(P, 0);
     if (dump) { start_offsets = hdr.start_offsets; end_offsets = hdr.end_offsets; }
-    else if (n_records > 0) {
+    std::vector<std::vector<uint8_t>> segment_bytes;
+    if (segment) {  // watermarks = first / last offset found in each partition's segment (kafka.rs:60-72)
+        for (uint32_t p = 0; p < P; p++) {
+            std::vector<uint8_t> bytes;
+            FILE *f = fopen(segment_files[p].c_str(), "rb");
+            if (!f) {
+                fprintf(stderr, "Error fetching metadata: cannot read log segment '%s'\n", segment_files[p].c_str());
+                return 101;
+            }
+            fseek(f, 0, SEEK_END);
+            long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            bytes.resize((size_t)sz + 64, 0);
+            if (sz > 0 && fread(bytes.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return 101; }
+            fclose(f);
+            bytes.resize((size_t)sz);
+            kta_kafka_index_stats ist;
+            std::vector<kta_kafka_batch_desc> descs(1);
+            int rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, descs.data(), descs.size(), &ist);
+            if (rc == KTA_ERR_CAPACITY) {
+                descs.resize(ist.n_batches);
+                rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, descs.data(), descs.size(), &ist);
+            }
+            if (rc == KTA_OK && ist.n_batches > 0) {
+                start_offsets[p] = descs.front().base_offset;
+                end_offsets[p] = descs.back().base_offset + descs.back().n_records;
+            }
+            segment_bytes.push_back(std::move(bytes));
+        }
+    }
+    else if (synthetic && n_records > 0) {
         // offsets of a synthetic topic: 0 .. per-partition record count; known only after the scan,
         // so the emptiness test of main.rs:98-101 uses the record count
         std::fill(end_offsets.begin(), end_offsets.end(), 1);
@@ -233,6 +282,17 @@ int main(int argc, char **argv)
             }
             check(kta_batch_submit(ctx, n, kb, seq), ctx, "kta_batch_submit");
             seq += n;
+        }
+    } else if (segment) {
+        for (uint32_t p = 0; p < P; p++) {
+            if (segment_bytes[p].empty()) continue;
+            kta_kafka_index_stats ist;
+            check(kta_kafka_consume(ctx, segment_bytes[p].data(), segment_bytes[p].size(), (int32_t)p, &ist), ctx,
+                  "kta_kafka_consume");
+            if (ist.n_compressed || ist.n_old_magic)
+                fprintf(stderr, "[WARN] Kafka error: partition %u: %llu compressed and %llu pre-v2 batches skipped\n", p,
+                        (unsigned long long)ist.n_compressed, (unsigned long long)ist.n_old_magic);   // kafka.rs:95-97
+            seq += ist.n_records;
         }
     } else {
         kta::DumpBatch db;

@@ -28,6 +28,7 @@ bool kta_internal_count_alive(kta_ctx *ctx);
 namespace {
 
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
+int g_decode_variant = 0;          // 0 = wave per batch (cooperative), 1 = lane per batch
 
 // ---- device-side byte reader over the blob: aligned 16-byte loads, one block cached -------------
 // A record header (length, attributes, timestamp delta, offset delta, key length) is <= 26 bytes, so
@@ -131,6 +132,159 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
     const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, blob_base, seq, seq_base, &kb);
     if (!ok) atomicAdd(n_bad, 1ull);
     if (want_keys && kb) atomicAdd(n_keyb, (unsigned long long)kb);
+}
+
+// ---- wave-cooperative decode: one wave per batch -------------------------------------------------
+// The lane-per-batch walk above is latency bound (one dependent HBM round trip per varint) and has
+// only as many active lanes as there are batches.  Here one wave owns one batch:
+//   1. the wave streams a window of the batch into LDS with coalesced 16-byte loads;
+//   2. lane 0 chains the record length prefixes inside the window (LDS latency, ~100 cycles/record)
+//      and publishes the record starts;
+//   3. all lanes parse one record each from LDS and write the columns (consecutive indices:
+//      coalesced stores); keys stay where they are (key_off points into the blob);
+//   4. the next window starts at the first record that did not fit — or, after a large value, at the
+//      next record start, so value bytes beyond the window are never loaded.
+constexpr uint32_t kWinBytes = 8192;
+constexpr uint32_t kWinRecs = 256;
+
+__device__ __forceinline__ bool lds_varlong(const uint8_t *win, uint32_t &off, uint32_t limit, long long &out)
+{
+    unsigned long long v = 0;
+    for (uint32_t shift = 0; shift < 70; shift += 7) {
+        if (off >= limit) return false;
+        const uint32_t b = win[off++];
+        v |= (unsigned long long)(b & 0x7Fu) << (shift < 64 ? shift : 63);
+        if (!(b & 0x80u)) {
+            out = (long long)(v >> 1) ^ -(long long)(v & 1ull);
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
+                                                        uint64_t n_batches, int want_keys, int32_t *part,
+                                                        int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
+                                                        uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
+                                                        unsigned long long *n_bad, unsigned long long *n_keyb)
+{
+    __shared__ uint4 s_win[kWinBytes / 16];
+    __shared__ uint32_t s_start[kWinRecs];   // record start, relative to the window base
+    __shared__ uint32_t s_body[kWinRecs];    // offset of the record body (after the length varint)
+    __shared__ uint64_t s_next;              // absolute position after the last chained record
+    __shared__ uint32_t s_found, s_first_incomplete, s_bad;
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s_win);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    const uint64_t end = d.byte_off + d.batch_bytes;
+    const uint32_t total = (uint32_t)d.n_records;
+    uint64_t pos = d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    uint32_t j = 0;                          // records finished
+    unsigned long long kb = 0;               // this lane's share of the key bytes
+    bool bad = false;
+    while (j < total) {                      // every condition below is wave-uniform
+        if (pos >= end) { bad = true; break; }
+        const uint64_t wbase = pos & ~15ull;
+        const uint64_t span = ((end + 15) & ~15ull) - wbase;
+        const uint32_t wbytes = span < kWinBytes ? (uint32_t)span : kWinBytes;
+        const uint64_t wlimit_abs = wbase + wbytes < end ? wbase + wbytes : end;
+        const uint32_t limit = (uint32_t)(wlimit_abs - wbase);                 // valid bytes in the window
+        for (uint32_t o = lane * 16; o < wbytes; o += 64 * 16) s_win[o >> 4] = blocks[(wbase + o) >> 4];
+        if (lane == 0) { s_bad = 0; s_found = 0; s_first_incomplete = kWinRecs; }
+        __syncthreads();
+        if (lane == 0) {                                                       // chain the length prefixes
+            uint32_t k = 0;
+            uint64_t cur = pos;
+            const uint32_t want = total - j;
+            while (k < kWinRecs && k < want && cur < wlimit_abs) {
+                uint32_t off = (uint32_t)(cur - wbase);
+                long long len;
+                if (!lds_varlong(win, off, limit, len)) {
+                    if (wlimit_abs == end) s_bad = 1;                          // ran into the end of the batch
+                    break;                                                     // else it straddles the window: next round
+                }
+                const uint64_t rec_end = wbase + off + (uint64_t)len;
+                if (len < 0 || rec_end > end) { s_bad = 1; break; }
+                s_start[k] = (uint32_t)(cur - wbase);
+                s_body[k] = off;
+                cur = rec_end;
+                k++;
+            }
+            s_found = k;
+            s_next = cur;
+        }
+        __syncthreads();
+        const uint32_t found = s_found;
+        long long my_kl[kWinRecs / 64];
+#pragma unroll
+        for (uint32_t t = 0; t < kWinRecs / 64; t++) {                         // one record per lane and round
+            my_kl[t] = 0;
+            const uint32_t k = lane + 64 * t;
+            if (k >= found) continue;
+            uint32_t off = s_body[k] + 1;                                      // + record attributes byte
+            const uint64_t rec_end = (k + 1 < found) ? wbase + s_start[k + 1] : s_next;
+            long long ts_delta = 0, od = 0, kl = 0, vl = 0;
+            if (!(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
+                  lds_varlong(win, off, limit, kl))) {
+                atomicMin(&s_first_incomplete, k);                             // header not inside this window
+                continue;
+            }
+            const uint64_t key_pos = wbase + off;
+            const uint64_t vpos = key_pos + (kl > 0 ? (uint64_t)kl : 0);
+            bool rec_ok = kl >= -1 && vpos < rec_end;
+            if (rec_ok) {
+                bool got = false;
+                uint64_t after = 0;                                            // position after the value length
+                if (vpos < wlimit_abs) {
+                    uint32_t voff = (uint32_t)(vpos - wbase);
+                    got = lds_varlong(win, voff, limit, vl);
+                    after = wbase + voff;
+                }
+                if (!got) {                                                    // value length lies beyond the window
+                    Reader gr{blocks, vpos, ~0ull, make_uint4(0, 0, 0, 0)};
+                    vl = read_varlong(gr);
+                    after = gr.pos;
+                }
+                rec_ok = vl >= -1 && after + (uint64_t)(vl > 0 ? vl : 0) <= rec_end;
+            }
+            if (!rec_ok) { s_bad = 1; continue; }
+            const uint64_t i = d.record_base + j + k;
+            part[i] = d.partition;
+            klen[i] = (int32_t)kl;
+            vlen[i] = (int32_t)vl;
+            ts[i] = (d.flags & KTA_KB_LOG_APPEND_TIME) ? d.max_ts_ms : d.base_ts_ms + ts_delta;
+            if (seq) seq[i] = seq_base + i;
+            if (want_keys) koff[i] = (uint32_t)(kl > 0 ? key_pos - blob_base : 0);
+            my_kl[t] = kl;
+        }
+        __syncthreads();
+        if (s_bad) { bad = true; break; }
+        const uint32_t first_inc = s_first_incomplete;
+        const uint32_t done = first_inc < found ? first_inc : found;
+        if (done == 0) { bad = true; break; }                                  // no progress: truncated batch
+#pragma unroll
+        for (uint32_t t = 0; t < kWinRecs / 64; t++)
+            if (lane + 64 * t < done && my_kl[t] > 0) kb += (unsigned long long)my_kl[t];
+        j += done;
+        pos = done < found ? wbase + s_start[done] : s_next;                   // records >= done are redone
+        __syncthreads();
+    }
+    if (bad) {
+        for (uint32_t r = j + lane; r < total; r += 64) {
+            const uint64_t i = d.record_base + r;
+            part[i] = -1; klen[i] = -1; vlen[i] = -1; ts[i] = -1;
+            if (seq) seq[i] = seq_base + i;
+            if (want_keys) koff[i] = 0u;
+        }
+        if (lane == 0) atomicAdd(n_bad, 1ull);
+    }
+    if (want_keys) {                                                           // one atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kb += __shfl_xor(kb, off);
+        if (lane == 0 && kb) atomicAdd(n_keyb, kb);
+    }
 }
 
 // ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
@@ -316,10 +470,16 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipEvent_t a = nullptr, b = nullptr;
     uint64_t scal[2] = {0, 0};
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
-    hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
-                       want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
-                       (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
-                       reinterpret_cast<unsigned long long *>(st->d_scalars));
+    if (g_decode_variant == 0)   // one wave per batch (default)
+        hipLaunchKernelGGL(kafka_decode_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
+                           want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
+                           (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
+                           reinterpret_cast<unsigned long long *>(st->d_scalars));
+    else                         // one lane per batch (kept for comparison)
+        hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
+                           want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
+                           (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
+                           reinterpret_cast<unsigned long long *>(st->d_scalars));
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
     if (n_bad_batches || n_key_bytes) {
@@ -497,6 +657,13 @@ int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint
     }
     *len = pos;
     return (!out || fits) ? KTA_OK : KTA_ERR_CAPACITY;
+}
+
+int kta_kafka_set_variant(int variant)
+{
+    if (variant != 0 && variant != 1) return KTA_ERR_INVALID;
+    g_decode_variant = variant;
+    return KTA_OK;
 }
 
 int kta_kafka_time_stats(kta_ctx *ctx, float avg_ms[2], uint64_t launches[2])

@@ -21,6 +21,8 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             key = None if r < 0.1 else (b"" if r < 0.13 else (b"key-%d-" % kid) + bytes([kid % 251]) * (kid % 37))
             if big and rng.random() < 0.05:
                 key = bytes(rng.integers(0, 256, size=int(rng.integers(100, 400)), dtype=np.uint8))
+            if big and rng.random() < 0.01:  # a key larger than the decoder's 8 KiB LDS window
+                key = bytes(rng.integers(0, 256, size=int(rng.integers(9000, 20000)), dtype=np.uint8))
             r = rng.random()
             val = None if r < 0.2 else (b"" if r < 0.23 else bytes(int(rng.integers(1, 20000 if big else 600))))
             headers = [(b"h%d" % i, None if i % 3 == 0 else b"x" * i) for i in range(int(rng.integers(0, 4)))]

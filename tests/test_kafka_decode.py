@@ -120,13 +120,20 @@ def _decode_on_device(h, blob, partition, with_keys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,with_keys", [(1, True), (2, False), (3, True), (5, True)])
-def test_device_decode_matches_encoder_and_oracle(seed, with_keys):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
+                                                        (6, True, 3000)])
+def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, variant):
+    """Both decode kernels (wave-per-batch through LDS windows, lane-per-batch); batches from one
+    record up to thousands (many LDS windows), values/keys larger than a window with seed 5."""
     rng = np.random.default_rng(seed)
-    blob, expected, _ = random_record_set(rng, 300, big=(seed == 5))
+    blob, expected, _ = random_record_set(rng, 300 if max_records < 1000 else 12, max_records=max_records,
+                                          big=(seed == 5))
     want, _ = kafka_decode(blob, 3)
+    N.load().kta_kafka_set_variant(variant)
     with kta.HipMetricHandler(8, now=NOW) as h:
         cols, st, bad = _decode_on_device(h, blob, 3, with_keys)
+    N.load().kta_kafka_set_variant(0)
     assert bad == 0
     assert_columns(cols, expected, key_check=with_keys)   # keys compared by content through key_off
     for k in ("partition", "key_len", "val_len", "ts_ms"):
@@ -141,10 +148,13 @@ def test_device_decode_reports_corrupt_batches():
     bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
     blob = good + bad + good
     want, ost = kafka_decode(blob, 0)
-    with kta.HipMetricHandler(2, now=NOW) as h:
-        cols, st, nbad = _decode_on_device(h, blob, 0, True)
-        assert nbad == 1 == ost.bad_batches
-        assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
+    for variant in (0, 1):
+        N.load().kta_kafka_set_variant(variant)
+        with kta.HipMetricHandler(2, now=NOW) as h:
+            cols, st, nbad = _decode_on_device(h, blob, 0, True)
+            assert nbad == 1 == ost.bad_batches
+            assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
+    N.load().kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
