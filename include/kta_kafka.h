@@ -91,8 +91,18 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
                             const kta_kafka_batch_desc *descs_host, uint64_t n_batches, uint64_t n_records,
                             const kta_batch *out, uint64_t *n_key_bytes, uint64_t *n_bad_batches);
 
-/* Convenience for hosts that hold the raw bytes in ordinary memory: copy to the device, index,
- * decode and run the metric handlers over the result (records get consecutive sequence numbers). */
+/* ---- the raw-log pipeline -----------------------------------------------------------------
+ * The fetcher writes each Fetch response's record set (or a chunk of a `*.log` segment, cut anywhere)
+ * straight into a PINNED staging blob; submit indexes the batch headers on the host, sends the
+ * bytes over PCIe on the copy stream and decodes + accumulates on the compute stream while the next
+ * blob is being filled (ring of stages).  stats->bytes_consumed tells how many bytes were whole
+ * batches; the caller carries the remaining tail (a partial batch) into the next blob. */
+int kta_kafka_configure(kta_ctx *ctx, uint64_t blob_capacity, int n_stages);  /* before first acquire; 0 = default (256 MiB, 3) */
+int kta_kafka_blob_acquire(kta_ctx *ctx, uint8_t **host_ptr, uint64_t *capacity);
+int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kafka_index_stats *stats);
+
+/* Convenience for hosts that hold the raw bytes in ordinary memory: memcpy into the staging ring
+ * (chunked at batch boundaries) and submit (records get consecutive sequence numbers). */
 int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
                       kta_kafka_index_stats *stats);
 

@@ -758,6 +758,7 @@ uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n)
     return base;
 }
 bool kta_internal_timing(kta_ctx *ctx) { return ctx->timing; }
+hipStream_t kta_internal_copy_stream(kta_ctx *ctx) { return ctx->s_copy; }
 bool kta_internal_count_alive(kta_ctx *ctx) { return ctx->alive; }
 hipStream_t kta_internal_stream(kta_ctx *ctx) { return ctx->s_compute; }
 int kta_internal_device(kta_ctx *ctx) { return ctx->device; }

@@ -24,6 +24,7 @@ void **kta_internal_ext_slot(kta_ctx *ctx, void (*free_fn)(void *));
 uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n);
 bool kta_internal_timing(kta_ctx *ctx);
 bool kta_internal_count_alive(kta_ctx *ctx);
+hipStream_t kta_internal_copy_stream(kta_ctx *ctx);
 
 namespace {
 
@@ -288,33 +289,57 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
 }
 
 // ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
+// One stage of the raw-log pipeline: a pinned host blob the fetcher fills, its device copy, the
+// pinned batch index and the decoded columns.
+struct BlobStage {
+    uint8_t *h_blob = nullptr, *d_blob = nullptr;
+    uint64_t cap = 0;
+    kta_kafka_batch_desc *h_descs = nullptr; // pinned: the H2D copy of the index is truly asynchronous
+    uint64_t desc_cap = 0;
+    kta_batch out{};
+    uint64_t out_cap = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+};
+
 struct KafkaState {
-    uint8_t *d_blob = nullptr;
-    uint64_t blob_cap = 0;
     kta_kafka_batch_desc *d_descs = nullptr;
     uint64_t desc_cap = 0;
     uint64_t *d_scalars = nullptr; // [0] key-byte total, [1] bad batches
-    kta_batch out{};
-    uint64_t out_cap = 0;
-    std::vector<kta_kafka_batch_desc> descs;
+    std::vector<BlobStage> stages;
+    uint64_t blob_capacity = 256ull << 20;
+    int cur = 0;
+    bool acquired = false;
     std::vector<hipEvent_t> ev[2];
     size_t ev_used[2] = {0, 0};
     double ms_sum[2] = {0, 0};
     uint64_t ms_cnt[2] = {0, 0};
 };
 
+void free_out(kta_batch &o)
+{
+    if (o.partition) (void)hipFree(o.partition);
+    if (o.key_len) (void)hipFree(o.key_len);
+    if (o.val_len) (void)hipFree(o.val_len);
+    if (o.ts_ms) (void)hipFree(o.ts_ms);
+    if (o.key_off) (void)hipFree(o.key_off);
+    memset(&o, 0, sizeof(o));
+}
+
 void free_state(void *p)
 {
     KafkaState *st = static_cast<KafkaState *>(p);
     if (!st) return;
-    if (st->d_blob) (void)hipFree(st->d_blob);
     if (st->d_descs) (void)hipFree(st->d_descs);
     if (st->d_scalars) (void)hipFree(st->d_scalars);
-    if (st->out.partition) (void)hipFree(st->out.partition);
-    if (st->out.key_len) (void)hipFree(st->out.key_len);
-    if (st->out.val_len) (void)hipFree(st->out.val_len);
-    if (st->out.ts_ms) (void)hipFree(st->out.ts_ms);
-    if (st->out.key_off) (void)hipFree(st->out.key_off);
+    for (auto &g : st->stages) {
+        if (g.h_blob) (void)hipHostFree(g.h_blob);
+        if (g.d_blob) (void)hipFree(g.d_blob);
+        if (g.h_descs) (void)hipHostFree(g.h_descs);
+        free_out(g.out);
+        if (g.copied) (void)hipEventDestroy(g.copied);
+        if (g.done) (void)hipEventDestroy(g.done);
+    }
     for (auto &v : st->ev)
         for (auto e : v) (void)hipEventDestroy(e);
     delete st;
@@ -454,9 +479,13 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipMalloc((void **)&st->d_descs, n_batches * sizeof(kta_kafka_batch_desc)));
         st->desc_cap = n_batches;
     }
-    if (!st->d_scalars) KK(ctx, hipMalloc((void **)&st->d_scalars, 2 * sizeof(uint64_t)));
+    if (!st->d_scalars) {
+        KK(ctx, hipMalloc((void **)&st->d_scalars, 2 * sizeof(uint64_t)));
+        KK(ctx, hipMemsetAsync(st->d_scalars, 0, 2 * sizeof(uint64_t), s));
+    }
     KK(ctx, hipMemcpyAsync(st->d_descs, descs_host, n_batches * sizeof(kta_kafka_batch_desc), hipMemcpyHostToDevice, s));
-    KK(ctx, hipMemsetAsync(st->d_scalars, 0, 2 * sizeof(uint64_t), s));
+    if (n_bad_batches || n_key_bytes)   // per-call counts wanted: start from zero (otherwise they accumulate)
+        KK(ctx, hipMemsetAsync(st->d_scalars, 0, 2 * sizeof(uint64_t), s));
     // Zero-copy keys: key_off[i] is the key's offset inside the raw blob, so the caller passes the
     // blob itself as `key_bytes` to kta_submit_device; nothing is copied.  out->key_bytes is ignored.
     const bool want_keys = out->key_off != nullptr;
@@ -491,64 +520,148 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     return KTA_OK;
 }
 
-int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
-                      kta_kafka_index_stats *stats)
+int kta_kafka_configure(kta_ctx *ctx, uint64_t blob_capacity, int n_stages)
 {
-    if (!ctx || !bytes || !stats) return KTA_ERR_INVALID;
-    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
-    hipStream_t s = kta_internal_stream(ctx);
+    if (!ctx || n_stages < 0 || n_stages > 16) return KTA_ERR_INVALID;
     KafkaState *st = state_of(ctx);
-    int rc = kta_flush(ctx); // keep consumption order with any per-message records staged earlier
+    if (!st->stages.empty()) {
+        kta_internal_set_error(ctx, "kta_kafka_configure must precede the first kta_kafka_blob_acquire");
+        return KTA_ERR_INVALID;
+    }
+    if (blob_capacity) st->blob_capacity = blob_capacity;
+    if (st->blob_capacity >= (1ull << 32) - 64) {
+        kta_internal_set_error(ctx, "blob capacity must be < 4 GiB (key offsets are u32)");
+        return KTA_ERR_INVALID;
+    }
+    st->stages.resize(n_stages ? (size_t)n_stages : 3);
+    return KTA_OK;
+}
+
+int kta_kafka_blob_acquire(kta_ctx *ctx, uint8_t **host_ptr, uint64_t *capacity)
+{
+    if (!ctx || !host_ptr || !capacity) return KTA_ERR_INVALID;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    KafkaState *st = state_of(ctx);
+    if (st->stages.empty()) st->stages.resize(3);
+    BlobStage &g = st->stages[st->cur];
+    if (!g.h_blob) {
+        g.cap = st->blob_capacity;
+        KK(ctx, hipHostMalloc((void **)&g.h_blob, g.cap + 64, hipHostMallocDefault));
+        KK(ctx, hipMalloc((void **)&g.d_blob, g.cap + 64));
+        KK(ctx, hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
+        KK(ctx, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    }
+    if (g.busy) { // the ring wrapped: the kernels that read this stage's device blob must be done
+        KK(ctx, hipEventSynchronize(g.done));
+        g.busy = false;
+    }
+    *host_ptr = g.h_blob;
+    *capacity = g.cap;
+    st->acquired = true;
+    return KTA_OK;
+}
+
+int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kafka_index_stats *stats)
+{
+    if (!ctx || !stats) return KTA_ERR_INVALID;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    KafkaState *st = state_of(ctx);
+    if (!st->acquired) {
+        kta_internal_set_error(ctx, "kta_kafka_blob_submit without kta_kafka_blob_acquire");
+        return KTA_ERR_INVALID;
+    }
+    BlobStage &g = st->stages[st->cur];
+    if (len > g.cap) {
+        kta_internal_set_error(ctx, "record set larger than the blob staging capacity");
+        return KTA_ERR_CAPACITY;
+    }
+    st->acquired = false;
+    int rc = kta_flush(ctx); // keep consumption order with per-message records staged earlier
     if (rc != KTA_OK) return rc;
-    // index (grow the descriptor array on demand)
-    if (st->descs.size() < 1024) st->descs.resize(1024);
-    rc = kta_kafka_index_host(bytes, len, partition, 0, 0, st->descs.data(), st->descs.size(), stats);
+    hipStream_t s = kta_internal_stream(ctx), cs = kta_internal_copy_stream(ctx);
+    // 1. host: index the batch headers (pinned descriptor array, grown on demand)
+    if (g.desc_cap == 0) {
+        g.desc_cap = 4096;
+        KK(ctx, hipHostMalloc((void **)&g.h_descs, g.desc_cap * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
+    }
+    rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, g.h_descs, g.desc_cap, stats);
     if (rc == KTA_ERR_CAPACITY) {
-        st->descs.resize(stats->n_batches);
-        rc = kta_kafka_index_host(bytes, len, partition, 0, 0, st->descs.data(), st->descs.size(), stats);
+        (void)hipHostFree(g.h_descs);
+        g.desc_cap = stats->n_batches + stats->n_batches / 4;
+        KK(ctx, hipHostMalloc((void **)&g.h_descs, g.desc_cap * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
+        rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, g.h_descs, g.desc_cap, stats);
     }
     if (rc != KTA_OK) return rc;
     if (stats->n_batches == 0) return KTA_OK;
     const bool keys = kta_internal_count_alive(ctx);
-    const uint64_t used = stats->bytes_consumed;
-    if (used >= (1ull << 32) && keys) {
-        kta_internal_set_error(ctx, "record set too large for one call with count_alive_keys (key offsets are u32)");
-        return KTA_ERR_CAPACITY;
+    const uint64_t used = stats->bytes_consumed, nrec = stats->n_records;
+    // 2. decoded columns of this stage (grown on demand; the stage is idle here)
+    if (g.out_cap < nrec || (keys && !g.out.key_off)) {
+        free_out(g.out);
+        g.out_cap = nrec + nrec / 4 + 1024;
+        KK(ctx, hipMalloc((void **)&g.out.partition, g.out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&g.out.key_len, g.out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&g.out.val_len, g.out_cap * 4 + 16));
+        KK(ctx, hipMalloc((void **)&g.out.ts_ms, g.out_cap * 8 + 16));
+        if (keys) KK(ctx, hipMalloc((void **)&g.out.key_off, g.out_cap * 4 + 16));
+        g.out.capacity = g.out_cap;
     }
-    // device buffers: the blob, and an output batch sized by the index (keys can never exceed the blob)
-    if (st->blob_cap < used + 16) {
-        KK(ctx, hipStreamSynchronize(s));
-        if (st->d_blob) (void)hipFree(st->d_blob);
-        st->d_blob = nullptr;
-        st->blob_cap = used + used / 4 + 4096;
-        KK(ctx, hipMalloc((void **)&st->d_blob, st->blob_cap));
-    }
-    const uint64_t nrec = stats->n_records;
-    if (st->out_cap < nrec || (keys && !st->out.key_off)) {
-        KK(ctx, hipStreamSynchronize(s));
-        kta_batch &o = st->out;
-        if (o.partition) (void)hipFree(o.partition);
-        if (o.key_len) (void)hipFree(o.key_len);
-        if (o.val_len) (void)hipFree(o.val_len);
-        if (o.ts_ms) (void)hipFree(o.ts_ms);
-        if (o.key_off) (void)hipFree(o.key_off);
-        memset(&o, 0, sizeof(o));
-        st->out_cap = nrec + nrec / 4 + 1024;
-        KK(ctx, hipMalloc((void **)&o.partition, st->out_cap * 4 + 16));
-        KK(ctx, hipMalloc((void **)&o.key_len, st->out_cap * 4 + 16));
-        KK(ctx, hipMalloc((void **)&o.val_len, st->out_cap * 4 + 16));
-        KK(ctx, hipMalloc((void **)&o.ts_ms, st->out_cap * 8 + 16));
-        if (keys) KK(ctx, hipMalloc((void **)&o.key_off, st->out_cap * 4 + 16));
-        o.capacity = st->out_cap;
-    }
-    st->out.key_bytes = keys ? st->d_blob : nullptr;   // zero-copy: keys are hashed in place in the raw log
-    st->out.key_bytes_capacity = keys ? used : 0;
-    KK(ctx, hipMemcpyAsync(st->d_blob, bytes, used, hipMemcpyHostToDevice, s));
-    rc = kta_kafka_decode_device(ctx, st->d_blob, used, st->descs.data(), stats->n_batches, nrec, &st->out, nullptr,
-                                 nullptr);
+    g.out.key_bytes = keys ? g.d_blob : nullptr; // zero-copy: keys are hashed in place in the raw log
+    g.out.key_bytes_capacity = keys ? used : 0;
+    // 3. raw log over PCIe on the copy stream; decode + metric handlers on the compute stream
+    KK(ctx, hipMemcpyAsync(g.d_blob, g.h_blob, (used + 63) & ~63ull, hipMemcpyHostToDevice, cs));
+    KK(ctx, hipEventRecord(g.copied, cs));
+    KK(ctx, hipStreamWaitEvent(s, g.copied, 0));
+    rc = kta_kafka_decode_device(ctx, g.d_blob, used, g.h_descs, stats->n_batches, nrec, &g.out, nullptr, nullptr);
     if (rc != KTA_OK) return rc;
     const uint64_t base = kta_internal_take_seq(ctx, nrec);
-    return kta_submit_device(ctx, &st->out, nrec, base);
+    rc = kta_submit_device(ctx, &g.out, nrec, base);
+    if (rc != KTA_OK) return rc;
+    KK(ctx, hipEventRecord(g.done, s));
+    g.busy = true;
+    st->cur = (st->cur + 1) % (int)st->stages.size();
+    return KTA_OK;
+}
+
+int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,
+                      kta_kafka_index_stats *stats)
+{
+    if (!ctx || !bytes || !stats) return KTA_ERR_INVALID;
+    memset(stats, 0, sizeof(*stats));
+    KafkaState *st = state_of(ctx);
+    if (st->stages.empty() && len + 64 > st->blob_capacity) {   // first use: size the ring for this caller
+        int rc = kta_kafka_configure(ctx, len + len / 4 + 4096, 3);
+        if (rc != KTA_OK) return rc;
+    }
+    uint64_t pos = 0;
+    while (pos < len) {   // chunk at batch boundaries when the record set exceeds one staging blob
+        uint8_t *dst;
+        uint64_t cap;
+        int rc = kta_kafka_blob_acquire(ctx, &dst, &cap);
+        if (rc != KTA_OK) return rc;
+        const uint64_t n = len - pos < cap ? len - pos : cap;
+        memcpy(dst, bytes + pos, n);
+        kta_kafka_index_stats one;
+        rc = kta_kafka_blob_submit(ctx, n, partition, &one);
+        if (rc != KTA_OK) return rc;
+        stats->n_batches += one.n_batches;
+        stats->n_records += one.n_records;
+        stats->n_control_batches += one.n_control_batches;
+        stats->n_compressed += one.n_compressed;
+        stats->n_old_magic += one.n_old_magic;
+        stats->bytes_consumed += one.bytes_consumed;
+        if (one.bytes_consumed == 0) {   // not even one whole batch fits / trailing partial batch
+            stats->trailing_bytes = len - pos;
+            if (n == cap && cap < len - pos) {
+                kta_internal_set_error(ctx, "a single record batch exceeds the blob staging capacity");
+                return KTA_ERR_CAPACITY;
+            }
+            return KTA_OK;
+        }
+        pos += one.bytes_consumed;
+        stats->trailing_bytes = len - pos;
+    }
+    return KTA_OK;
 }
 
 // ---- producer side (host): synthetic topic -> v2 record batches ---------------------------------
