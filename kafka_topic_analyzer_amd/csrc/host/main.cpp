@@ -15,7 +15,9 @@
 //                                        v2, uncompressed): file k is partition k; decoded ON THE GPU
 //                                        (include/kta_kafka.h), the host only walks batch headers
 // anything else is refused.  Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
-// kta.batch=N, kta.write_dump=<path>), so no flag is added or renamed.
+// kta.batch=N, kta.write_dump=<path>, kta.per_message=1), so no flag is added or renamed.
+// kta.per_message=1 drives the handler exactly like the reference's loop (kafka.rs:107-109): one
+// MetricHandler::handle_message call per record instead of filling columns.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -257,7 +259,35 @@ int main(int argc, char **argv)
     const bool write_dump = cfg.count("kta.write_dump") != 0;
 
     uint64_t seq = 0;
-    if (synthetic) {
+    const bool per_message = cfg.count("kta.per_message") && cfg["kta.per_message"] == "1";
+    if (synthetic && per_message) {
+        // the reference's shape: for every polled message, every handler's handle_message (kafka.rs:107-109)
+        std::vector<kta::MetricHandler *> metric_handlers{handler};
+        std::vector<uint8_t> key;
+        for (; seq < n_records; seq++) {
+            kta::Message m;
+            int32_t p, kl, vl;
+            int64_t ts;
+            kta_synth_record(&spec, seq, &p, &kl, &vl, &ts);
+            m.partition = p;
+            m.offset = (int64_t)seq;
+            m.timestamp_ms = ts;
+            m.payload_len = vl;
+            if (kl >= 0) {
+                key.resize((size_t)kl + 1);
+                const uint64_t kid = (uint64_t)kta_synth_key_id(&spec, seq);
+                for (int32_t j = 0; j < kl; j++) key[(size_t)j] = kta_synth_key_byte(&spec, kid, (uint32_t)j);
+                m.key = key.data();   // non-null even for an empty key: Some(&[])
+                m.key_len = kl;
+            }
+            try {
+                for (auto *mh : metric_handlers) mh->handle_message(m);
+            } catch (const std::exception &e) {
+                fprintf(stderr, "%s\n", e.what());
+                return 2;
+            }
+        }
+    } else if (synthetic) {
         while (seq < n_records) {
             kta_batch hb;
             check(kta_batch_acquire(ctx, &hb), ctx, "kta_batch_acquire");

@@ -165,6 +165,17 @@ def test_cli_end_to_end_on_topic_dump_matches_golden_report(tmp_path, with_c):
 
 
 @pytest.mark.gpu
+def test_cli_per_message_handler_path_equals_column_path():
+    """kta.per_message=1: one MetricHandler::handle_message call per record through the C++ mirror of
+    the reference's handlers == the batched column path, byte for byte (incl. Alive keys)."""
+    a = run_cli("-t", "c2", "-b", "synthetic://c2?records=200000", "-c", "--librdkafka", "kta.per_message=1,kta.batch=4096")
+    b = run_cli("-t", "c2", "-b", "synthetic://c2?records=200000", "-c")
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert _normalise(a.stdout) == _normalise(b.stdout)
+    assert "Alive keys: " in a.stdout
+
+
+@pytest.mark.gpu
 def test_cli_synthetic_topic_and_dump_round_trip(tmp_path):
     path = str(tmp_path / "c2.ktadump")
     a = run_cli("-t", "c2", "-b", "synthetic://c2?records=300000", "-c", "--librdkafka", "kta.write_dump=" + path)
