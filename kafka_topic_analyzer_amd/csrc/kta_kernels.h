@@ -36,7 +36,7 @@ struct ScanPlan {
     uint32_t workgroups;   // grid size
     uint32_t rep_log2;     // LDS replication of each partition's slots
     uint32_t lds_bytes;    // dynamic LDS per workgroup
-    uint32_t variant;      // 0 = three 64-bit LDS atomics/record, 1 = packed (two), 9 = loads only (diagnostic)
+    uint32_t variant;      // 0 = accumulate (three 64-bit LDS atomics per record or quad), 9 = loads only (diagnostic)
     bool nontemporal;      // stream the columns with non-temporal loads
     bool analytics;        // additive outputs: size histograms + per-partition extrema
     uint32_t row_len;      // u64 words per workgroup row of the partial workspace

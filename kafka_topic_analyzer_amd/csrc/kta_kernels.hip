@@ -28,13 +28,12 @@ namespace kta {
 // Accumulation: per-partition partial counters live in LDS, replicated 2^rep_log2 times
 // (replica = lane & (R-1)) so records of one partition that sit in the same wave do not
 // serialise on one LDS address (a Kafka consumer delivers per-partition runs, and small
-// P is common).  Three non-returning 64-bit LDS atomics per record:
+// P is common).  Three non-returning 64-bit LDS atomics per record — or per QUAD when the
+// lane's four consecutive records share a partition (inside a per-partition run they do):
 //     A += 1 | tombstone << 21 | key_null << 42      (three 21-bit counts in one word)
 //     K += key_len (Some)      V += val_len (Some)
-// or, in the packed variant, two when every lane's sizes fit 13 bits (wave-uniform test):
-//     B += key_len | val_len << 32
 // LDS partials are flushed to this workgroup's row of the partial workspace every 2^18
-// records (so the packed fields cannot overflow) and at the end; a second tiny kernel
+// records (so the 21-bit fields cannot overflow) and at the end; a second tiny kernel
 // folds the rows.  No floating point anywhere; integer adds commute, so results are
 // independent of scheduling.
 //
@@ -46,7 +45,6 @@ namespace kta {
 constexpr uint32_t kCntBits = 21;
 constexpr uint64_t kCntMask = (1ull << kCntBits) - 1;
 constexpr uint32_t kFlushTiles = 256;          // 256 tiles x 1024 records = 2^18 records
-constexpr uint32_t kPackedSizeLimit = 1u << 13; // 2^18 records x 2^13 B < 2^32
 
 struct Quad {
     int4 p, k, v;
@@ -130,7 +128,7 @@ __device__ __forceinline__ void lane_extrema(const Rec &r, bool valid, LaneState
 }
 
 struct ScanLds {
-    unsigned long long *A, *K, *V, *B; // counters (B: packed variant only)
+    unsigned long long *A, *K, *V;     // counters
     long long *X;                      // ANALYTICS: [4][slots] signed-max arrays [~ts, ts, ~size, size]
     uint32_t *H;                       // ANALYTICS: [2][34][16] histogram counters
     uint32_t slots;
@@ -144,20 +142,7 @@ __device__ __forceinline__ void lds_record(const Rec &r, const ScanLds &L, uint3
     const uint32_t slot = (r.part << rep_log2) | rep;
     const unsigned long long a = 1ull | ((unsigned long long)r.tomb << kCntBits) |
                                  ((unsigned long long)r.knull << (2 * kCntBits));
-    if (VARIANT == 1) {
-        // wave-uniform choice: all active lanes small -> one packed add for both sizes
-        const bool small = (r.ks | r.vs) < kPackedSizeLimit;
-        if (__all(small || !r.ok)) {
-            if (r.ok) {
-                atomicAdd(&L.A[slot], a);
-                atomicAdd(&L.B[slot], (unsigned long long)r.ks | ((unsigned long long)r.vs << 32));
-            }
-        } else if (r.ok) {
-            atomicAdd(&L.A[slot], a);
-            atomicAdd(&L.K[slot], (unsigned long long)r.ks);
-            atomicAdd(&L.V[slot], (unsigned long long)r.vs);
-        }
-    } else if (r.ok) {
+    if (r.ok) {
         atomicAdd(&L.A[slot], a);
         atomicAdd(&L.K[slot], (unsigned long long)r.ks);
         atomicAdd(&L.V[slot], (unsigned long long)r.vs);
@@ -203,7 +188,7 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, bool valid, uint3
 #pragma unroll
     for (int j = 0; j < 4; j++) lds_histograms<ANALYTICS>(r[j], L);
     const bool uniform = r[0].ok && r[0].part == r[1].part && r[0].part == r[2].part && r[0].part == r[3].part;
-    if (VARIANT == 0 && uniform) {
+    if (uniform) {
         const uint32_t slot = (r[0].part << rep_log2) | rep;
         const uint32_t tombs = r[0].tomb + r[1].tomb + r[2].tomb + r[3].tomb;
         const uint32_t knulls = r[0].knull + r[1].knull + r[2].knull + r[3].knull;
@@ -232,12 +217,9 @@ __device__ __forceinline__ void accumulate_quad(const Quad &q, bool valid, uint3
         }
         return;
     }
-    // interleaved partitions (or the packed variant, whose wave-wide vote needs every lane)
-    const bool any_scalar = VARIANT == 1 ? true : !uniform;
-    if (any_scalar) {
+    // interleaved partitions: per-record atomics, spread over the replicas
 #pragma unroll
-        for (int j = 0; j < 4; j++) lds_record<VARIANT, ANALYTICS>(r[j], L, rep_log2, rep);
-    }
+    for (int j = 0; j < 4; j++) lds_record<VARIANT, ANALYTICS>(r[j], L, rep_log2, rep);
 }
 
 // ANALYTICS (opt-in, no reference counterpart — the additive outputs named by the project brief):
@@ -255,14 +237,13 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
 
     const uint32_t tid = threadIdx.x;
     const uint32_t slots = P << rep_log2;
-    const uint32_t n_arrays = (VARIANT == 1) ? 4u : 3u;
+    const uint32_t n_arrays = 3u;
     unsigned long long *sA = lds;
     unsigned long long *sK = lds + slots;
     unsigned long long *sV = lds + 2 * slots;
-    unsigned long long *sB = lds + 3 * slots; // VARIANT 1 only
     long long *sX = reinterpret_cast<long long *>(lds + n_arrays * slots);          // ANALYTICS: [4][slots]
     uint32_t *sH = reinterpret_cast<uint32_t *>(lds + (n_arrays + 4) * slots);      // ANALYTICS: [2][34][16]
-    const ScanLds L{sA, sK, sV, sB, sX, sH, slots};
+    const ScanLds L{sA, sK, sV, sX, sH, slots};
 
     for (uint32_t i = tid; i < n_arrays * slots; i += kWG) lds[i] = 0ull;
     if (ANALYTICS) {
@@ -285,7 +266,7 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
     auto flush = [&]() {
         __syncthreads();
         for (uint32_t p = tid; p < P; p += kWG) {
-            unsigned long long a = 0, k = 0, v = 0, b = 0;
+            unsigned long long a = 0, k = 0, v = 0;
             for (uint32_t r = 0; r < (1u << rep_log2); r++) {
                 const uint32_t s = (p << rep_log2) | r;
                 a += sA[s];
@@ -294,14 +275,6 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
                 sA[s] = 0ull;
                 sK[s] = 0ull;
                 sV[s] = 0ull;
-                if (VARIANT == 1) {
-                    b += sB[s];
-                    sB[s] = 0ull;
-                }
-            }
-            if (VARIANT == 1) {
-                k += b & 0xFFFFFFFFull;
-                v += b >> 32;
             }
             uint64_t *o = row + (uint64_t)p * kScanCols;
             const uint64_t c0 = a & kCntMask, c1 = (a >> kCntBits) & kCntMask,
@@ -371,7 +344,6 @@ __global__ __launch_bounds__(kWG) void kta_metrics_scan(ScanColumns c, uint64_t 
         const uint64_t i = (nquads << 2) + tid;
         const bool v = (tid < 3) && (i < n);
         const uint64_t ii = v ? i : 0;
-        // (lanes of one wave must all enter accumulate<1> because of its __all())
         if (tid < 64) {
             uint32_t p = 0; int32_t kl = 0, vl = 0; long long ts = 0;
             if (v) { p = (uint32_t)c.partition[ii]; kl = c.key_len[ii]; vl = c.val_len[ii]; ts = c.ts_ms[ii]; }
@@ -698,12 +670,12 @@ __global__ __launch_bounds__(kWG) void kta_alive_bitmap(const unsigned long long
 ScanPlan plan_scan(uint32_t P, uint64_t n, int cu_count, int req_workgroups, int req_variant, bool analytics)
 {
     ScanPlan pl;
-    // req_variant: low bits 0 = three LDS atomics, 1 = packed, 9 = loads only; +16 = non-temporal loads
+    // req_variant: low bits 0 = accumulate, 9 = loads only (diagnostic); +16 = non-temporal loads
     const int base = req_variant & 15;
     pl.analytics = analytics;
     pl.nontemporal = analytics ? true : (req_variant & 16) != 0;
-    pl.variant = analytics ? 0u : ((base == 1 || base == 9) ? (uint32_t)base : 0u);
-    const uint32_t arrays = (pl.variant == 1 ? 4u : 3u) + (analytics ? 4u : 0u);
+    pl.variant = analytics ? 0u : (base == 9 ? 9u : 0u);
+    const uint32_t arrays = 3u + (analytics ? 4u : 0u);
     const uint32_t hist_bytes = analytics ? 2u * kHistBuckets * kHistReps * 4u : 0u;
     // LDS budget per workgroup: 32 KiB (4 workgroups = 16 waves per CU can be resident); the
     // analytics kernel carries 7 arrays and gets 64 KiB (2 workgroups per CU) to keep the replication.
@@ -745,7 +717,6 @@ hipError_t launch_metrics_scan(const ScanPlan &pl, const ScanColumns &c, uint64_
         return hipGetLastError();
     }
     switch (pl.variant) {
-    case 1: if (pl.nontemporal) KTA_SCAN(1, true, false); else KTA_SCAN(1, false, false); break;
     case 9: if (pl.nontemporal) KTA_SCAN(9, true, false); else KTA_SCAN(9, false, false); break;
     default: if (pl.nontemporal) KTA_SCAN(0, true, false); else KTA_SCAN(0, false, false); break;
     }
