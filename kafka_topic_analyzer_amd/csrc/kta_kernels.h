@@ -64,7 +64,7 @@ hipError_t launch_fold_partials(const uint64_t *partials, uint32_t rows, uint32_
 hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *analytics_vec, hipStream_t s);
 
 // K2+K3: FNV (fnv32.rs:92-101) + last-writer-wins table update (metric.rs:289-304)
-// variant 0 = fused; 1 = fused + running alive count (returning atomics); 8 / 9 = ablation halves
+// variant 0 = fused; 1 = fused + running alive count (returning atomics, default); 8 / 9 = ablation halves
 // (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
                                int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s);

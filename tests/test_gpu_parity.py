@@ -247,6 +247,25 @@ def test_running_alive_count_equals_table_scan(hc):
     assert r3.alive_keys == o.alive_keys()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_alive_kernels_under_heavy_slot_contention(hc, variant):
+    """Both alive-update kernels (plain atomicMax; returning atomicMax + running count) leave exactly the
+    table sequential BitSet semantics leaves — 40 keys over 120k records is heavy same-slot contention."""
+    rng = np.random.default_rng(500 + variant)
+    o = Oracle(NOW, True)
+    hc.reset()
+    hc.set_tuning(alive_variant=variant)
+    for key_space, n in ((40, 120000), (3000, 200000), (10**6, 150000)):
+        cols = random_cols(rng, n, 32, key_space=key_space, tomb=0.45)
+        o.run_soa(cols)
+        hc.submit_columns(**cols)
+    res, c = hc.finish()
+    hc.set_tuning()
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(c[:32], o.counters(32)) and not c[32:].any()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+
+
 def test_max_partitions_uses_large_dynamic_lds():
     P = 4096  # 96 KiB of LDS partials per workgroup
     rng = np.random.default_rng(41)

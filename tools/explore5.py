@@ -7,12 +7,12 @@ n = int(os.environ.get("N", 1 << 26))
 h = kta.HipMetricHandler(64, count_alive_keys=True)
 b = h.device_batch_alloc(n, n * 16)
 h.set_timing(True)
-for D in (100_000, 10_000_000, 0):
+for D in (10_000, 1_000_000, 10_000_000, 100_000_000, 0):
     spec, _ = kta.synth_preset("c3")
     spec.n_distinct_keys = D
     kb = h.synth_fill_device(spec, 0, n, b); h.sync()
-    for variant in (8, 9, 0):
-        for wgs in (1024, 2048, 8192):
+    for variant in (1, 2):
+        for wgs in (2048, 8192):
             h.set_tuning(alive_workgroups=wgs, alive_variant=variant)
             for it in range(2):
                 h.submit_device(b, n, 0, which=2)
