@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
     uint64_t kb = 0;
     const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, blob_base, seq, seq_base, &kb);
     if (!ok) atomicAdd(n_bad, 1ull);
-    if (want_keys && kb) atomicAdd(n_keyb, (unsigned long long)kb);
+    if (n_keyb && kb) atomicAdd(n_keyb, (unsigned long long)kb);
 }
 
 // ---- wave-cooperative decode: one wave per batch -------------------------------------------------
@@ -148,8 +148,25 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
 constexpr uint32_t kWinBytes = 8192;
 constexpr uint32_t kWinRecs = 256;
 
+// zig-zag varint at byte offset `off` of the LDS window.  Fast path (values < 2^28, i.e. <= 4 bytes —
+// every length/delta of ordinary records): two aligned dword reads, one v_alignbyte, branch-free bit
+// compaction; otherwise the generic byte loop.
 __device__ __forceinline__ bool lds_varlong(const uint8_t *win, uint32_t &off, uint32_t limit, long long &out)
 {
+    if (off + 4u <= limit) {
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+        const uint32_t i = off >> 2;
+        const uint32_t w = __builtin_amdgcn_alignbyte(w32[i + 1], w32[i], off & 3u);   // 4 bytes at `off`
+        const uint32_t stop = ~w & 0x80808080u;                                       // first byte without MSB
+        if (stop) {
+            const uint32_t nb = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;            // 1..4 bytes
+            uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
+            v &= 0xFFFFFFFFu >> (32u - 7u * nb);
+            off += nb;
+            out = (long long)(v >> 1) ^ -(long long)(v & 1u);
+            return true;
+        }
+    }
     unsigned long long v = 0;
     for (uint32_t shift = 0; shift < 70; shift += 7) {
         if (off >= limit) return false;
@@ -169,21 +186,21 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
                                                         unsigned long long *n_bad, unsigned long long *n_keyb)
 {
-    __shared__ uint4 s_win[kWinBytes / 16];
+    __shared__ uint4 s_win[kWinBytes / 16 + 1];   // + 1: the fast varint path reads one dword ahead
     __shared__ uint32_t s_start[kWinRecs];   // record start, relative to the window base
     __shared__ uint32_t s_body[kWinRecs];    // offset of the record body (after the length varint)
     __shared__ uint64_t s_next;              // absolute position after the last chained record
     __shared__ uint32_t s_found, s_first_incomplete, s_bad;
     const uint8_t *win = reinterpret_cast<const uint8_t *>(s_win);
     const uint32_t lane = threadIdx.x;
-    const uint64_t b = blockIdx.x;
+    unsigned long long kb = 0;               // this lane's share of the key bytes
+    const uint64_t b = blockIdx.x;           // one workgroup (= one wave) per batch: the dispatcher balances
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
     const uint64_t end = d.byte_off + d.batch_bytes;
     const uint32_t total = (uint32_t)d.n_records;
     uint64_t pos = d.byte_off + KTA_KAFKA_BATCH_HEADER;
     uint32_t j = 0;                          // records finished
-    unsigned long long kb = 0;               // this lane's share of the key bytes
     bool bad = false;
     while (j < total) {                      // every condition below is wave-uniform
         if (pos >= end) { bad = true; break; }
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
         }
         if (lane == 0) atomicAdd(n_bad, 1ull);
     }
-    if (want_keys) {                                                           // one atomic per wave
+    if (n_keyb) {                                  // only when the caller asked for the total (one atomic per wave)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) kb += __shfl_xor(kb, off);
         if (lane == 0 && kb) atomicAdd(n_keyb, kb);
@@ -503,12 +520,12 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         hipLaunchKernelGGL(kafka_decode_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
                            want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
                            (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
-                           reinterpret_cast<unsigned long long *>(st->d_scalars));
+                           n_key_bytes ? reinterpret_cast<unsigned long long *>(st->d_scalars) : nullptr);
     else                         // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
                            want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
                            (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
-                           reinterpret_cast<unsigned long long *>(st->d_scalars));
+                           n_key_bytes ? reinterpret_cast<unsigned long long *>(st->d_scalars) : nullptr);
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
     if (n_bad_batches || n_key_bytes) {
