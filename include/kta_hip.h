@@ -230,6 +230,14 @@ int kta_export_alive_bitmap(kta_ctx *ctx, void *dst_host_512MiB);
  * kernel (returning atomicMax: +flag(new) - flag(old) whenever an entry is replaced), so
  * kta_finish does not scan the table. */
 int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
+/* Compact exchange of the table between partition-sharded GPUs.  Export: the entries ever written
+ * (value != 0) as device arrays slot u32[n] / value u64[n] (owned by the context, valid until the
+ * next export); at most one per distinct key hash the shard has seen, i.e. 12 bytes per key instead
+ * of the 32 GiB table.  Import: table[slot] = max(table[slot], value) for foreign entries (device
+ * pointers), keeping the running alive count exact.  Importing every other shard's export into one
+ * context reproduces the global last-writer state. */
+int kta_alive_export_entries(kta_ctx *ctx, void **d_slots, void **d_vals, uint64_t *n);
+int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_vals, uint64_t n);
 /* Tell the context that the table was changed behind its back (e.g. merged with other GPUs' tables
  * by an all-reduce MAX): the running alive count is dropped and the next kta_finish recounts by
  * scanning the table. */

@@ -268,6 +268,23 @@ class HipMetricHandler:
                 "value_size_hist": np.array(a.value_size_hist[:], dtype=np.uint64),
                 "part_min_ts_sec": mn, "part_max_ts_sec": mx, "part_smallest": sm, "part_largest": lg}
 
+    def alive_export_entries(self) -> Tuple[int, int, int]:
+        """(device ptr slots u32[n], device ptr values u64[n], n): the entries ever written."""
+        ps, pv, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self._lib.kta_alive_export_entries(self._ctx, C.byref(ps), C.byref(pv), C.byref(n)))
+        return ps.value or 0, pv.value or 0, n.value
+
+    def alive_export_entries_host(self) -> Tuple[np.ndarray, np.ndarray]:
+        ps, pv, n = self.alive_export_entries()
+        slots, vals = np.empty(n, np.uint32), np.empty(n, np.uint64)
+        if n:
+            self._check(self._lib.kta_copy_to_host(self._ctx, _np_ptr(slots), C.c_void_p(ps), slots.nbytes))
+            self._check(self._lib.kta_copy_to_host(self._ctx, _np_ptr(vals), C.c_void_p(pv), vals.nbytes))
+        return slots, vals
+
+    def alive_import_entries(self, d_slots: int, d_vals: int, n: int) -> None:
+        self._check(self._lib.kta_alive_import_entries(self._ctx, C.c_void_p(d_slots), C.c_void_p(d_vals), n))
+
     def alive_table_modified(self) -> None:
         self._check(self._lib.kta_alive_table_modified(self._ctx))
 

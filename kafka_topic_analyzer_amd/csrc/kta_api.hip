@@ -41,6 +41,9 @@ struct kta_ctx {
     uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
     int64_t *d_alive_running = nullptr; // running alive count (alive_variant 1)
     bool running_valid = true;          // false once an update ran without counting
+    uint32_t *d_exp_slots = nullptr;    // kta_alive_export_entries buffers
+    uint64_t *d_exp_vals = nullptr, *d_exp_count = nullptr;
+    uint64_t exp_cap = 0;
     uint32_t *d_hash_scratch = nullptr; // ablation variants only
     uint64_t hash_scratch_cap = 0;
     std::vector<Stage> stages;
@@ -224,6 +227,9 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
             if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
+    if (ctx->d_exp_slots) (void)hipFree(ctx->d_exp_slots);
+    if (ctx->d_exp_vals) (void)hipFree(ctx->d_exp_vals);
+    if (ctx->d_exp_count) (void)hipFree(ctx->d_exp_count);
             ctx->d_hash_scratch = nullptr;
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;
@@ -343,6 +349,9 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
+    if (ctx->d_exp_slots) (void)hipFree(ctx->d_exp_slots);
+    if (ctx->d_exp_vals) (void)hipFree(ctx->d_exp_vals);
+    if (ctx->d_exp_count) (void)hipFree(ctx->d_exp_count);
     if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
     for (auto &pool : ctx->ev_pool)
         for (auto ev : pool) (void)hipEventDestroy(ev);
@@ -671,6 +680,50 @@ int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
     *device_ptr = ctx->d_table;
     *n_u64 = (size_t)kta::kAliveSlots;
+    return KTA_OK;
+}
+
+int kta_alive_export_entries(kta_ctx *ctx, void **d_slots, void **d_vals, uint64_t *n)
+{
+    if (!ctx || !d_slots || !d_vals || !n) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    hipStream_t s = ctx->s_compute;
+    if (!ctx->d_exp_count) KTA_HIP(ctx, hipMalloc((void **)&ctx->d_exp_count, sizeof(uint64_t)));
+    uint64_t written = 0;
+    KTA_HIP(ctx, kta::launch_alive_count_written(ctx->d_table, kta::kAliveSlots, ctx->d_exp_count, s));
+    KTA_HIP(ctx, hipMemcpyAsync(&written, ctx->d_exp_count, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    KTA_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->exp_cap < written) {
+        if (ctx->d_exp_slots) (void)hipFree(ctx->d_exp_slots);
+        if (ctx->d_exp_vals) (void)hipFree(ctx->d_exp_vals);
+        ctx->d_exp_slots = nullptr;
+        ctx->d_exp_vals = nullptr;
+        ctx->exp_cap = written + written / 8 + 1024;
+        KTA_HIP(ctx, hipMalloc((void **)&ctx->d_exp_slots, ctx->exp_cap * sizeof(uint32_t)));
+        KTA_HIP(ctx, hipMalloc((void **)&ctx->d_exp_vals, ctx->exp_cap * sizeof(uint64_t)));
+    }
+    if (written)
+        KTA_HIP(ctx, kta::launch_alive_export(ctx->d_table, kta::kAliveSlots, ctx->d_exp_slots, ctx->d_exp_vals,
+                                              ctx->d_exp_count, ctx->exp_cap, s));
+    KTA_HIP(ctx, hipStreamSynchronize(s));
+    *d_slots = ctx->d_exp_slots;
+    *d_vals = ctx->d_exp_vals;
+    *n = written;
+    return KTA_OK;
+}
+
+int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_vals, uint64_t n)
+{
+    if (!ctx || (n && (!d_slots || !d_vals))) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    KTA_HIP(ctx, kta::launch_alive_import(static_cast<const uint32_t *>(d_slots), static_cast<const uint64_t *>(d_vals),
+                                          n, ctx->d_table, ctx->d_alive_running, ctx->s_compute));
     return KTA_OK;
 }
 

@@ -70,6 +70,12 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
                                int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
+// compact (slot, value) export / import of the entries ever written: what sharded GPUs exchange
+hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
+hipError_t launch_alive_export(const uint64_t *table, uint64_t n_slots, uint32_t *out_slots, uint64_t *out_vals,
+                               uint64_t *counter, uint64_t cap, hipStream_t s);
+hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint64_t n, uint64_t *table,
+                               int64_t *running, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)
 hipError_t launch_alive_bitmap(const uint64_t *table, uint64_t n_slots, uint32_t *bitmap, hipStream_t s);
 // hash only (tests)

@@ -651,6 +651,103 @@ __global__ __launch_bounds__(kWG) void kta_alive_count(const ulonglong2 *__restr
     }
 }
 
+// Compact export of the entries ever written (value != 0): (slot u32, value u64) pairs.  A shard's
+// table holds at most one entry per distinct key hash it has seen, so this is what partition-sharded
+// GPUs exchange instead of the 32 GiB table.  Each workgroup sweeps a contiguous slab, stages hits in
+// LDS and reserves output space with ONE device atomic per flush (not per hit).
+constexpr uint32_t kExportStage = 2048;
+
+__global__ __launch_bounds__(kWG) void kta_alive_export(const unsigned long long *__restrict__ table,
+                                                        uint64_t n_slots, uint32_t *__restrict__ out_slots,
+                                                        unsigned long long *__restrict__ out_vals,
+                                                        unsigned long long *__restrict__ counter, uint64_t cap)
+{
+    __shared__ uint32_t s_slot[kExportStage];
+    __shared__ unsigned long long s_val[kExportStage];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
+    const uint64_t per = (n_slots + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per;
+    const uint64_t hi = lo + per < n_slots ? lo + per : n_slots;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint64_t base = lo; base < hi; base += kWG * 4) {     // uniform trip count per workgroup
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + (uint64_t)u * kWG + threadIdx.x;
+            const unsigned long long v = i < hi ? table[i] : 0ull;
+            if (v) {
+                const uint32_t at = atomicAdd(&s_n, 1u);         // LDS counter; stage holds 2048 >= 4 * 256
+                s_slot[at] = (uint32_t)i;
+                s_val[at] = v;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n > kExportStage - kWG * 4 || base + kWG * 4 >= hi) {  // flush when the next round might overflow
+            if (threadIdx.x == 0 && n) s_base = atomicAdd(counter, (unsigned long long)n);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < n; k += kWG)
+                if (s_base + k < cap) {
+                    out_slots[s_base + k] = s_slot[k];
+                    out_vals[s_base + k] = s_val[k];
+                }
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// Merge foreign entries: table[slot] = max(table[slot], value), keeping the running alive count exact
+// (same telescoping argument as kta_alive_update_counting).
+__global__ __launch_bounds__(kWG) void kta_alive_import(const uint32_t *__restrict__ slots,
+                                                        const unsigned long long *__restrict__ vals, uint64_t n,
+                                                        unsigned long long *__restrict__ table,
+                                                        long long *__restrict__ running)
+{
+    __shared__ long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    long long delta = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
+        const unsigned long long v = vals[i];
+        if (!v) continue;
+        const unsigned long long old = atomicMax(&table[slots[i]], v);
+        if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) delta += __shfl_xor(delta, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = delta;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(running), (unsigned long long)t);
+    }
+}
+
+// number of entries ever written (value != 0)
+__global__ __launch_bounds__(kWG) void kta_alive_count_written(const ulonglong2 *__restrict__ table2, uint64_t n_pairs,
+                                                               unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    unsigned long long cnt = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n_pairs; i += stride) {
+        const ulonglong2 e = table2[i];
+        cnt += (e.x != 0ull) + (e.y != 0ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
 // table -> bitmap: one wave turns 64 consecutive entries into one u64 of bits via ballot.
 __global__ __launch_bounds__(kWG) void kta_alive_bitmap(const unsigned long long *__restrict__ table,
                                                         uint64_t n_slots,
@@ -768,6 +865,40 @@ hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t 
     hipLaunchKernelGGL(kta_alive_count, dim3(256 * 8), dim3(kWG), 0, s,
                        reinterpret_cast<const ulonglong2 *>(table), n_slots / 2,
                        reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kta_alive_count_written, dim3(256 * 8), dim3(kWG), 0, s,
+                       reinterpret_cast<const ulonglong2 *>(table), n_slots / 2,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_export(const uint64_t *table, uint64_t n_slots, uint32_t *out_slots, uint64_t *out_vals,
+                               uint64_t *counter, uint64_t cap, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kta_alive_export, dim3(256 * 16), dim3(kWG), 0, s,
+                       reinterpret_cast<const unsigned long long *>(table), n_slots, out_slots,
+                       reinterpret_cast<unsigned long long *>(out_vals),
+                       reinterpret_cast<unsigned long long *>(counter), cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint64_t n, uint64_t *table,
+                               int64_t *running, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t wgs = (n + kWG - 1) / kWG;
+    if (wgs > 256 * 8) wgs = 256 * 8;
+    hipLaunchKernelGGL(kta_alive_import, dim3((uint32_t)wgs), dim3(kWG), 0, s, slots,
+                       reinterpret_cast<const unsigned long long *>(vals), n,
+                       reinterpret_cast<unsigned long long *>(table), reinterpret_cast<long long *>(running));
     return hipGetLastError();
 }
 

@@ -50,3 +50,60 @@ def allreduce_alive_table(table, group=None, chunk_elems: int = 1 << 28) -> None
     n = table.numel()
     for lo in range(0, n, chunk_elems):
         dist.all_reduce(table[lo:min(lo + chunk_elems, n)], op=dist.ReduceOp.MAX, group=group)
+
+
+def gather_entries(slots, vals, group=None):
+    """all_gather of variable-length (slot u32-as-i32, value u64-as-i64) entry lists -> per-rank lists.
+    Works on device tensors (RCCL) and CPU tensors (gloo).  Shorter lists are zero padded: value 0 means
+    "never written" and is ignored by the import kernel."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([slots.numel()], dtype=torch.int64, device=slots.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    ps = torch.zeros(m, dtype=slots.dtype, device=slots.device)
+    pv = torch.zeros(m, dtype=vals.dtype, device=vals.device)
+    ps[:slots.numel()] = slots
+    pv[:vals.numel()] = vals
+    gs = [torch.empty_like(ps) for _ in range(world)]
+    gv = [torch.empty_like(pv) for _ in range(world)]
+    dist.all_gather(gs, ps, group=group)
+    dist.all_gather(gv, pv, group=group)
+    return gs, gv, sizes
+
+
+class _DevArray:
+    """Zero-copy torch view of library-owned device memory."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def exchange_alive_entries(handler, device, group=None) -> int:
+    """Merge the alive-key state of all ranks into every rank, compactly: each rank exports the table
+    entries it ever wrote (<= one per distinct key hash: 12 B each), the lists are all-gathered, and every
+    rank imports the foreign entries with atomicMax — the element-wise MAX of the tables without moving
+    32 GiB per rank.  Returns the number of foreign entries imported."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    ps, pv, n = handler.alive_export_entries()
+    dev = torch.device("cuda", device)
+    if n:
+        slots = torch.as_tensor(_DevArray(ps, n, "<i4"), device=dev)
+        vals = torch.as_tensor(_DevArray(pv, n, "<i8"), device=dev)
+    else:
+        slots = torch.zeros(0, dtype=torch.int32, device=dev)
+        vals = torch.zeros(0, dtype=torch.int64, device=dev)
+    gs, gv, sizes = gather_entries(slots, vals, group)
+    torch.cuda.synchronize(dev)            # gathered lists complete before the library's stream reads them
+    imported = 0
+    for r, k in enumerate(sizes):
+        if r != rank and k:
+            handler.alive_import_entries(gs[r].data_ptr(), gv[r].data_ptr(), k)
+            imported += k
+    handler.sync()                         # the gathered tensors may be freed after this
+    return imported

@@ -144,3 +144,41 @@ def test_shard_spec_is_rank_disjoint():
     b = kta.synth_fill_host(D.shard_spec(sp, 1, 2), 0, 5000)
     assert (a["partition"] % 2 == 0).all() and (b["partition"] % 2 == 1).all()
     assert sp.shard_count == 1  # the caller's spec is untouched
+
+
+def _gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = [5, 0, 3][rank]
+        slots = torch.arange(n, dtype=torch.int32) + 100 * rank
+        vals = (torch.arange(n, dtype=torch.int64) + 1) * (rank + 1)
+        gs, gv, sizes = D.gather_entries(slots, vals)
+        q.put((rank, sizes, [g[:k].tolist() for g, k in zip(gs, sizes)], [g[:k].tolist() for g, k in zip(gv, sizes)],
+               [int(g[k:].abs().sum()) for g, k in zip(gv, sizes)]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_variable_length_entry_gather_three_ranks():
+    """The compact alive-table exchange: ragged (slot, value) lists incl. an empty rank, zero padded."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sizes, slots, vals, pad in outs:
+        assert sizes == [5, 0, 3]
+        assert slots == [[0, 1, 2, 3, 4], [], [200, 201, 202]]
+        assert vals == [[1, 2, 3, 4, 5], [], [3, 6, 9]]
+        assert pad == [0, 0, 0]  # padding is value 0 == "never written"

@@ -59,6 +59,11 @@ h.alive_table_modified()
 res, c = h.finish()
 assert res.alive_keys == o.alive_keys(), (res.alive_keys, o.alive_keys())
 assert np.array_equal(c, o.counters(8))
+assert D.exchange_alive_entries(h, 0) == 0            # compact exchange on RCCL: nothing foreign with one rank
+res2, _ = h.finish()
+assert res2.alive_keys == o.alive_keys()
+ps, pv, ne = h.alive_export_entries()
+assert ne >= res2.alive_keys
 h.close(); dist.destroy_process_group(); print("OK")
 '''
 

@@ -415,3 +415,55 @@ def test_analytics_histograms_and_partition_extrema(P, n, runs):
     with kta.HipMetricHandler(4) as plain:
         with pytest.raises(kta.KtaError):
             plain.analytics()
+
+
+# ------------------------------------------------------------------------------------- compact table exchange
+def test_alive_export_import_merges_partition_shards(hc):
+    """Two partition shards with GLOBAL sequence numbers in two contexts; exporting one shard's written
+    entries (compact) and importing them into the other reproduces the unsharded alive set exactly."""
+    rng = np.random.default_rng(31)
+    P = 6
+    cols = random_cols(rng, 150000, P, key_space=4000, tomb=0.4)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    n = len(cols["partition"])
+    seq = np.arange(n, dtype=np.uint64)
+
+    def shard(mask):
+        idx = np.nonzero(mask)[0]
+        kl = np.maximum(cols["key_len"][idx], 0).astype(np.int64)
+        off = np.zeros(len(idx), np.int64)
+        off[1:] = np.cumsum(kl)[:-1]
+        kb = np.zeros(max(int(kl.sum()), 1), np.uint8)
+        src = cols["key_off"][idx].astype(np.int64)
+        for j in np.nonzero(kl)[0]:
+            kb[off[j]:off[j] + kl[j]] = cols["key_bytes"][src[j]:src[j] + kl[j]]
+        return {"partition": cols["partition"][idx], "key_len": cols["key_len"][idx], "val_len": cols["val_len"][idx],
+                "ts_ms": cols["ts_ms"][idx], "key_off": off.astype(np.uint32), "key_bytes": kb[:int(kl.sum())],
+                "seq": seq[idx]}
+
+    a_cols, b_cols = shard(cols["partition"] % 2 == 0), shard(cols["partition"] % 2 == 1)
+    hc.reset()
+    ba, na = hc.upload_batch(a_cols, with_keys=True)
+    hc.submit_device(ba, na, 0)
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as hb:
+        bb, nb = hb.upload_batch(b_cols, with_keys=True)
+        hb.submit_device(bb, nb, 0)
+        rb, _ = hb.finish()
+        ps, pv, ne = hb.alive_export_entries()              # shard B's entries, on the device
+        slots, vals = hb.alive_export_entries_host()
+        assert ne == len(slots) == len(np.unique(slots)) and (vals != 0).all()
+        assert int((vals & np.uint64(1)).sum()) == rb.alive_keys
+        hc.alive_import_entries(ps, pv, ne)                  # merge into shard A's context
+        hc.sync()
+        hb.device_batch_free(bb)
+    res, _ = hc.finish()                                     # running count stayed exact through the import
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+    hc.alive_table_modified()
+    res2, _ = hc.finish()                                    # and equals a recount of the merged table
+    assert res2.alive_keys == o.alive_keys()
+    hc.device_batch_free(ba)
+    # an empty table exports nothing
+    hc.reset()
+    assert hc.alive_export_entries()[2] == 0
