@@ -165,7 +165,7 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     t_index = time.perf_counter() - t0
     assert rc == 0 and st.n_records == n_records
     h = kta.HipMetricHandler(256, device=device)
-    d_blob = h.device_batch_alloc((ln.value + 3) // 4 + 16)
+    d_blob = h.device_batch_alloc((ln.value + 3) // 4 + 32)
     h._check(lib.kta_copy_to_device(h._ctx, d_blob.partition, buf.ctypes.data, (ln.value + 63) // 64 * 64))
     out = h.device_batch_alloc(n_records, 16)  # key_off wanted: keys stay in the blob (zero-copy)
     kb, bad = C.c_uint64(), C.c_uint64()

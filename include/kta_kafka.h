@@ -28,8 +28,8 @@
  *   partition = the record set's partition, timestamp = baseTimestamp + timestampDelta (or
  *   maxTimestamp for LogAppendTime), key/payload None iff the length is -1.
  * Not handled (counted, never silently mis-decoded): compressed batches (codec != 0), magic 0/1
- * message sets.  CRCs are not verified — librdkafka's `check.crcs` defaults to false and the
- * reference does not set it (src/kafka.rs:28-36).
+ * message sets.  CRCs are verified only on request (kta_kafka_set_check_crcs) — librdkafka's
+ * `check.crcs` defaults to false and the reference does not set it (src/kafka.rs:28-36).
  */
 #ifndef KTA_KAFKA_H
 #define KTA_KAFKA_H
@@ -48,11 +48,15 @@ extern "C" {
 /* flags of a batch descriptor */
 #define KTA_KB_LOG_APPEND_TIME 1u /* attributes bit 3 */
 #define KTA_KB_TRANSACTIONAL 2u   /* attributes bit 4 */
+/* status of a batch after the device passes */
+#define KTA_KB_BAD_CRC 1u         /* CRC-32C mismatch (only with kta_kafka_set_check_crcs)           */
+#define KTA_KB_BAD_FRAMING 2u     /* records overran the batch                                      */
 
 typedef struct kta_kafka_batch_desc {
     uint64_t byte_off;    /* offset of the batch (its baseOffset field) in the blob          */
     uint64_t record_base; /* index of its first record in the output columns               */
-    uint64_t key_base;    /* reserved (the batch's position in the blob)                            */
+    uint32_t crc;         /* the batch's stored CRC-32C (over attributes .. end of batch)           */
+    uint32_t status;      /* device: 0 ok, KTA_KB_BAD_CRC / KTA_KB_BAD_FRAMING after decoding       */
     int64_t base_offset;  /* Kafka offset of the first record                                */
     int64_t base_ts_ms;
     int64_t max_ts_ms;
@@ -80,7 +84,7 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                          kta_kafka_index_stats *stats);
 
 /* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
- * readable for 32 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
+ * readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
  * Keys are ZERO-COPY: when out->key_off is set, key_off[i] is the offset of record i's key inside the
  * blob, so the caller passes `blob_device` itself as `key_bytes` when submitting the columns
  * (out->key_bytes is ignored; the blob must then be < 4 GiB and stay alive until the kernels ran).
@@ -113,6 +117,17 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
  * `out` may be NULL to size the buffer; *len receives the bytes written / needed. */
 int kta_kafka_encode_synth_host(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
                                 uint32_t records_per_batch, uint8_t *out, uint64_t cap, uint64_t *len);
+
+/* librdkafka's `check.crcs` (default false; the reference forwards user options, src/kafka.rs:38-42):
+ * when enabled, every batch's CRC-32C (Castagnoli, over the bytes from `attributes` to the end of
+ * the batch) is verified on the device before decoding; a batch that fails is not delivered — its
+ * records are written with partition -1 (counted as bad-partition records) and it is counted in
+ * *n_bad_batches.  kta_kafka_crc_errors returns the number of CRC failures since the context was
+ * created. */
+int kta_kafka_set_check_crcs(kta_ctx *ctx, int enable);
+int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n);
+/* CRC-32C of host bytes (the same tables the device uses; check value of "123456789": 0xE3069283). */
+uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 
 /* Decode kernel choice (process wide): 0 = one wave per batch, cooperative through an LDS window
  * (default), 1 = one lane per batch (kept for comparison). */

@@ -74,7 +74,7 @@ class KtaSynthSpec(C.Structure):
 
 
 class KtaKafkaBatchDesc(C.Structure):
-    _fields_ = [("byte_off", C.c_uint64), ("record_base", C.c_uint64), ("key_base", C.c_uint64),
+    _fields_ = [("byte_off", C.c_uint64), ("record_base", C.c_uint64), ("crc", C.c_uint32), ("status", C.c_uint32),
                 ("base_offset", C.c_int64), ("base_ts_ms", C.c_int64), ("max_ts_ms", C.c_int64),
                 ("batch_bytes", C.c_uint32), ("partition", C.c_int32), ("n_records", C.c_int32),
                 ("flags", C.c_uint32)]
@@ -140,6 +140,9 @@ SIGNATURES = {
     "kta_kafka_encode_synth_host": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                               C.c_uint64, C.POINTER(C.c_uint64)]),
     "kta_kafka_set_variant": (C.c_int, [C.c_int]),
+    "kta_kafka_set_check_crcs": (C.c_int, [_P, C.c_int]),
+    "kta_kafka_crc_errors": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "kta_crc32c_host": (C.c_uint32, [C.c_char_p, C.c_uint64]),
     "kta_kafka_time_stats": (C.c_int, [_P, C.POINTER(C.c_float * 2), C.POINTER(C.c_uint64 * 2)]),
 }
 

@@ -205,6 +205,10 @@ int main(int argc, char **argv)
         return 2;
     }
     kta_ctx *ctx = handler->ctx();
+    // librdkafka options are forwarded as in the reference (kafka.rs:38-42); the one this build can
+    // honour for raw segments is check.crcs (default false): verify every batch's CRC-32C on the GPU
+    const bool check_crcs = cfg.count("check.crcs") && cfg["check.crcs"] == "true";
+    if (segment) check(kta_kafka_set_check_crcs(ctx, check_crcs ? 1 : 0), ctx, "kta_kafka_set_check_crcs");
 
     std::vector<int64_t> start_offsets(P, 0), end_offsets(P, 0);
     if (dump) { start_offsets = hdr.start_offsets; end_offsets = hdr.end_offsets; }
@@ -361,10 +365,16 @@ int main(int argc, char **argv)
     fprintf(stderr, "done\n");                                                      // kafka.rs:136 (spinner)
 
     try {
-        handler->finish();                       // where main.rs:121 is: the trait has no end-of-stream hook
+        handler->finish(segment);                // where main.rs:121 is: the trait has no end-of-stream hook
     } catch (const std::exception &e) {
         fprintf(stderr, "%s\n", e.what());
         return 2;
+    }
+    if (segment && handler->undelivered_records()) {                               // kafka.rs:95-97: warn, go on
+        uint64_t crc_errors = 0;
+        (void)kta_kafka_crc_errors(ctx, &crc_errors);
+        fprintf(stderr, "[WARN] Kafka error: %llu record(s) of corrupt batches were not delivered (%llu CRC failure(s))\n",
+                (unsigned long long)handler->undelivered_records(), (unsigned long long)crc_errors);
     }
     const kta::MessageMetrics &metrics = handler->metrics();
     if (synthetic)

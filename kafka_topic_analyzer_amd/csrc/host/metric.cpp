@@ -99,11 +99,13 @@ void HipMetricHandler::handle_message(const Message &m)
           "kta_handle_message");
 }
 
-void HipMetricHandler::finish()
+void HipMetricHandler::finish(bool tolerate_undelivered)
 {
     kta_result r{};
     std::vector<uint64_t> counters((size_t)P_ * KTA_NCOUNTERS);
-    check(kta_finish(ctx_, &r, counters.data()), "kta_finish");
+    const int rc = kta_finish(ctx_, &r, counters.data());
+    if (!(rc == KTA_ERR_BAD_PARTITION && tolerate_undelivered)) check(rc, "kta_finish");
+    undelivered_ = r.bad_partition_records;
     metrics_ = MessageMetrics(r, std::move(counters), now_);
     lc_ = LogCompactionInMemoryMetrics(r);
 }

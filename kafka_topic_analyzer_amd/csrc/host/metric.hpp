@@ -101,7 +101,11 @@ public:
 
     void handle_message(const Message &m) override;  // kafka.rs:107-109
     // The trait has no end-of-stream hook; call this where main.rs:121 is (before the report).
-    void finish();
+    // tolerate_undelivered: records of batches that failed check.crcs / framing were written with
+    // partition -1 (never counted); with true they are reported through undelivered_records()
+    // instead of failing the run (the reference warns on Kafka errors and goes on, kafka.rs:95-97).
+    void finish(bool tolerate_undelivered = false);
+    uint64_t undelivered_records() const { return undelivered_; }
     const MessageMetrics &metrics() const { return metrics_; }
     const LogCompactionInMemoryMetrics *log_compaction() const { return alive_ ? &lc_ : nullptr; }
     kta_ctx *ctx() { return ctx_; }
@@ -115,6 +119,7 @@ private:
     DateTimeUtc now_;
     MessageMetrics metrics_;
     LogCompactionInMemoryMetrics lc_;
+    uint64_t undelivered_ = 0;
 };
 
 // chrono 0.4.19 `Display for DateTime<Utc>` (main.rs:132-133)

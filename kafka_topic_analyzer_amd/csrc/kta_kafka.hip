@@ -128,7 +128,8 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
 {
     const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
     if (b >= n_batches) return;
-    const kta_kafka_batch_desc d = descs[b];
+    kta_kafka_batch_desc d = descs[b];
+    if (d.status & KTA_KB_BAD_CRC) d.batch_bytes = KTA_KAFKA_BATCH_HEADER;   // not delivered: walk nothing
     uint64_t kb = 0;
     const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, blob_base, seq, seq_base, &kb);
     if (!ok) atomicAdd(n_bad, 1ull);
@@ -201,8 +202,8 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
     const uint32_t total = (uint32_t)d.n_records;
     uint64_t pos = d.byte_off + KTA_KAFKA_BATCH_HEADER;
     uint32_t j = 0;                          // records finished
-    bool bad = false;
-    while (j < total) {                      // every condition below is wave-uniform
+    bool bad = (d.status & KTA_KB_BAD_CRC) != 0;   // failed check.crcs: the batch is not delivered
+    while (!bad && j < total) {              // every condition below is wave-uniform
         if (pos >= end) { bad = true; break; }
         const uint64_t wbase = pos & ~15ull;
         const uint64_t span = ((end + 15) & ~15ull) - wbase;
@@ -306,6 +307,102 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
 }
 
 // ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
+// ---- CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) on the device -------------------------
+// One wave per batch.  The bytes [start, end) are cut on the absolute 64-byte grid; per 4 KiB window
+// every lane reduces its 64-byte chunk with slicing-by-4 tables held in LDS (raw register update, no
+// init / final xor), then the chunks are stitched with the linearity of CRCs:
+//     state' = Z_len(state) ^ XOR_i Z_after(i)(c_i)
+// where Z_n (advance the register over n zero bytes) is a GF(2)[x] multiplication mod P by the
+// precomputed constant x^(8n) — a table of 4097 constants built once on the host.
+constexpr uint32_t kCrcPoly = 0x82F63B78u;
+constexpr uint32_t kCrcWindow = 4096;
+
+struct CrcTables {
+    uint32_t slice[4][256];          // slicing-by-4
+    uint32_t zshift[kCrcWindow + 1]; // zshift[n]: multiplier that advances the register over n zero bytes
+};
+
+// (a * b) mod P in the reflected representation (bit 31 = x^0)
+__host__ __device__ inline uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) r ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? kCrcPoly : 0u);
+    }
+    return r;
+}
+
+void build_crc_tables(CrcTables &t)
+{
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+        t.slice[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+        for (int s = 1; s < 4; s++) t.slice[s][i] = (t.slice[s - 1][i] >> 8) ^ t.slice[0][t.slice[s - 1][i] & 0xFFu];
+    // zshift[0] = 1 (x^0 = bit 31); advancing a register value r over one zero byte is r -> (r >> 8) ^ T0[r & 0xff],
+    // a linear map, i.e. multiplication by x^8: zshift[n+1] = zshift[n] * x^8
+    uint32_t x8 = 0x80000000u;
+    for (int k = 0; k < 8; k++) x8 = (x8 >> 1) ^ ((x8 & 1u) ? kCrcPoly : 0u);
+    t.zshift[0] = 0x80000000u;
+    for (uint32_t n = 0; n < kCrcWindow; n++) t.zshift[n + 1] = gf_mul(t.zshift[n], x8);
+}
+
+__global__ __launch_bounds__(64) void kafka_crc32c(const uint4 *blocks, kta_kafka_batch_desc *descs, uint64_t n_batches,
+                                                   const CrcTables *tables, unsigned long long *n_crc_bad)
+{
+    __shared__ uint32_t s_t[4][256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 1024; i += 64) (&s_t[0][0])[i] = (&tables->slice[0][0])[i];
+    __syncthreads();
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    const uint64_t start = d.byte_off + 21, end = d.byte_off + d.batch_bytes;   // attributes .. end of batch
+    uint32_t state = 0xFFFFFFFFu;
+    for (uint64_t wbase = start & ~63ull; wbase < end; wbase += kCrcWindow) {   // wave-uniform
+        const uint64_t cb = wbase + 64ull * lane;                               // this lane's 64-byte chunk
+        const uint64_t lo = cb > start ? cb : start;
+        const uint64_t hi = cb + 64 < end ? cb + 64 : end;
+        uint32_t c = 0;
+        if (lo < hi) {
+            const uint4 *p = blocks + (cb >> 4);
+            uint32_t w[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = p[q];
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+            if (lo == cb && hi == cb + 64) {                                    // full chunk: slicing-by-4
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    c ^= w[k];
+                    c = s_t[3][c & 0xFFu] ^ s_t[2][(c >> 8) & 0xFFu] ^ s_t[1][(c >> 16) & 0xFFu] ^ s_t[0][c >> 24];
+                }
+            } else {                                                            // first / last chunk: bytewise
+                for (uint32_t o = (uint32_t)(lo - cb); o < (uint32_t)(hi - cb); o++) {
+                    const uint32_t byte = (w[o >> 2] >> ((o & 3u) * 8u)) & 0xFFu;
+                    c = (c >> 8) ^ s_t[0][(c ^ byte) & 0xFFu];
+                }
+            }
+        }
+        const uint64_t wlo = wbase > start ? wbase : start;
+        const uint64_t whi = wbase + kCrcWindow < end ? wbase + kCrcWindow : end;
+        const uint32_t after = lo < hi ? (uint32_t)(whi - hi) : 0u;             // bytes of the window behind my chunk
+        uint32_t part = (lo < hi && c) ? gf_mul(c, tables->zshift[after]) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
+        state = gf_mul(state, tables->zshift[(uint32_t)(whi - wlo)]) ^ part;
+    }
+    if (lane == 0 && (state ^ 0xFFFFFFFFu) != d.crc) {
+        descs[b].status = KTA_KB_BAD_CRC;
+        atomicAdd(n_crc_bad, 1ull);
+    }
+}
+
 // One stage of the raw-log pipeline: a pinned host blob the fetcher fills, its device copy, the
 // pinned batch index and the decoded columns.
 struct BlobStage {
@@ -323,6 +420,9 @@ struct KafkaState {
     kta_kafka_batch_desc *d_descs = nullptr;
     uint64_t desc_cap = 0;
     uint64_t *d_scalars = nullptr; // [0] key-byte total, [1] bad batches
+    CrcTables *d_crc_tables = nullptr;
+    uint64_t *d_crc_bad = nullptr;  // CRC failures since the context was created
+    bool check_crcs = false;
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     int cur = 0;
@@ -349,6 +449,8 @@ void free_state(void *p)
     if (!st) return;
     if (st->d_descs) (void)hipFree(st->d_descs);
     if (st->d_scalars) (void)hipFree(st->d_scalars);
+    if (st->d_crc_tables) (void)hipFree(st->d_crc_tables);
+    if (st->d_crc_bad) (void)hipFree(st->d_crc_bad);
     for (auto &g : st->stages) {
         if (g.h_blob) (void)hipHostFree(g.h_blob);
         if (g.d_blob) (void)hipFree(g.d_blob);
@@ -447,7 +549,8 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     kta_kafka_batch_desc &d = descs[nb];
                     d.byte_off = blob_offset + pos;
                     d.record_base = rec;
-                    d.key_base = blob_offset + pos; // the batch's keys live at the batch's own blob offset
+                    d.crc = be32(bytes + pos + 17);
+                    d.status = 0;
                     d.base_offset = (int64_t)be64(bytes + pos);
                     d.base_ts_ms = (int64_t)be64(bytes + pos + 27);
                     d.max_ts_ms = (int64_t)be64(bytes + pos + 35);
@@ -515,6 +618,23 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     const uint4 *words = reinterpret_cast<const uint4 *>(blob_device);
     hipEvent_t a = nullptr, b = nullptr;
     uint64_t scal[2] = {0, 0};
+    if (st->check_crcs) {   // librdkafka check.crcs=true: verify every batch before it is decoded
+        if (!st->d_crc_tables) {
+            CrcTables *host = new CrcTables();
+            build_crc_tables(*host);
+            hipError_t e = hipMalloc((void **)&st->d_crc_tables, sizeof(CrcTables));
+            if (e == hipSuccess) e = hipMemcpy(st->d_crc_tables, host, sizeof(CrcTables), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&st->d_crc_bad, sizeof(uint64_t));
+            if (e == hipSuccess) e = hipMemset(st->d_crc_bad, 0, sizeof(uint64_t));
+            delete host;
+            if (e != hipSuccess) return hip_err(ctx, e, "CRC-32C tables");
+        }
+        if (timing) { int rc = pair(ctx, st, 0, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
+        hipLaunchKernelGGL(kafka_crc32c, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
+                           st->d_crc_tables, reinterpret_cast<unsigned long long *>(st->d_crc_bad));
+        KK(ctx, hipGetLastError());
+        if (timing) KK(ctx, hipEventRecord(b, s));
+    }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
     if (g_decode_variant == 0)   // one wave per batch (default)
         hipLaunchKernelGGL(kafka_decode_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
@@ -788,6 +908,27 @@ int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint
     *len = pos;
     return (!out || fits) ? KTA_OK : KTA_ERR_CAPACITY;
 }
+
+int kta_kafka_set_check_crcs(kta_ctx *ctx, int enable)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    state_of(ctx)->check_crcs = enable != 0;
+    return KTA_OK;
+}
+
+int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
+{
+    if (!ctx || !n) return KTA_ERR_INVALID;
+    KafkaState *st = state_of(ctx);
+    *n = 0;
+    if (!st->d_crc_bad) return KTA_OK;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    KK(ctx, hipMemcpyAsync(n, st->d_crc_bad, sizeof(uint64_t), hipMemcpyDeviceToHost, kta_internal_stream(ctx)));
+    KK(ctx, hipStreamSynchronize(kta_internal_stream(ctx)));
+    return KTA_OK;
+}
+
+uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len) { return bytes ? crc32c(bytes, (size_t)len) : 0u; }
 
 int kta_kafka_set_variant(int variant)
 {

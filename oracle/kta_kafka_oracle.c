@@ -109,3 +109,23 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
     if (n_key_bytes) *n_key_bytes = kb;
     return (int64_t)n;
 }
+
+/* CRC-32C (Castagnoli), bit-at-a-time on purpose (no tables shared with the product): reflected
+ * polynomial 0x82F63B78, init and final xor 0xFFFFFFFF.  Published check value: "123456789" -> 0xE3069283.
+ * A Kafka v2 batch stores it at offset 17, computed over the bytes from offset 21 to the end. */
+uint32_t kto_crc32c(const uint8_t *p, uint64_t n)
+{
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint64_t i = 0; i < n; i++) {
+        c ^= p[i];
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    }
+    return c ^ 0xFFFFFFFFu;
+}
+
+/* 1 if the v2 batch starting at `batch` (12 + batchLength bytes) carries a correct CRC */
+int kto_kafka_batch_crc_ok(const uint8_t *batch, uint64_t total)
+{
+    uint32_t stored = (uint32_t)rd_be(batch + 17, 4);
+    return stored == kto_crc32c(batch + 21, total - 21);
+}

@@ -104,7 +104,7 @@ def _decode_on_device(h, blob, partition, with_keys):
     n = st.n_records
     d_blob = C.c_void_p()
     out = h.device_batch_alloc(max(n, 1), 16 if with_keys else 0)  # key_off only: keys stay in the blob
-    blob_dev = h.device_batch_alloc((len(blob) + 3) // 4 + 4)  # reuse a column as the raw byte buffer
+    blob_dev = h.device_batch_alloc((len(blob) + 3) // 4 + 32)  # a column as the raw byte buffer (+128 B pad)
     arr = np.frombuffer(blob + b"\0" * ((-len(blob)) % 4), dtype=np.uint8).copy()
     h._check(lib.kta_copy_to_device(h._ctx, blob_dev.partition, arr.ctypes.data, arr.nbytes))
     kb, bad = C.c_uint64(), C.c_uint64()
@@ -184,3 +184,78 @@ def test_consume_raw_record_sets_end_to_end(count_alive):
         if count_alive:
             assert res.alive_keys == o.alive_keys()
             assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
+
+
+# --------------------------------------------------------------------------------------------- CRC-32C
+def _batches_of(blob):
+    out, pos = [], 0
+    while pos + 12 <= len(blob):
+        total = 12 + int.from_bytes(blob[pos + 8:pos + 12], "big")
+        if total < 61 or pos + total > len(blob):
+            break
+        out.append((pos, total))
+        pos += total
+    return out
+
+
+def test_crc32c_host_check_value_and_agreement():
+    import ctypes as C2
+    from oracle_c import lib as olib
+    L = olib()
+    L.kto_crc32c.restype = C2.c_uint32
+    L.kto_crc32c.argtypes = [C2.c_char_p, C2.c_uint64]
+    lib = N.load()
+    assert lib.kta_crc32c_host(b"123456789", 9) == 0xE3069283 == L.kto_crc32c(b"123456789", 9) == K.crc32c(b"123456789")
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 3, 4, 63, 64, 65, 4095, 4096, 4097, 10000):
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert lib.kta_crc32c_host(data, n) == L.kto_crc32c(data, n) == K.crc32c(data)
+
+
+@pytest.mark.gpu
+def test_device_crc32c_check_flags_exactly_the_corrupted_batches():
+    """check.crcs on the device: batches of every size class (shorter than a chunk .. many 4 KiB windows,
+    arbitrary start alignment); flipping one byte anywhere after the CRC field must flag that batch, and
+    only that batch; its records are not delivered (partition -1)."""
+    import ctypes as C2
+    from oracle_c import lib as olib
+    L = olib()
+    L.kto_kafka_batch_crc_ok.restype = C2.c_int
+    L.kto_kafka_batch_crc_ok.argtypes = [C2.c_char_p, C2.c_uint64]
+    rng = np.random.default_rng(77)
+    blob = bytearray()
+    for n, vmax in ((1, 3), (1, 40), (2, 70), (5, 900), (40, 300), (300, 600), (3, 30000), (1, 5), (17, 4096)):
+        recs = [(int(rng.integers(0, 1000)), bytes(rng.integers(0, 256, size=int(rng.integers(0, 30)), dtype=np.uint8)),
+                 bytes(rng.integers(0, 256, size=int(rng.integers(0, vmax)), dtype=np.uint8))) for _ in range(n)]
+        blob += K.encode_batch(len(blob), recs, 1_600_000_000_000)
+    blob = bytes(blob)
+    batches = _batches_of(blob)
+    assert all(L.kto_kafka_batch_crc_ok(blob[p:p + t], t) for p, t in batches)
+    lib = N.load()
+    with kta.HipMetricHandler(4, now=NOW) as h:
+        h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))
+        cols, st, nbad = _decode_on_device(h, blob, 1, True)
+        assert nbad == 0 and (cols["partition"] == 1).all()
+        # corrupt: one byte in batches 1, 4 and the last one (header region after the CRC, first and last byte)
+        bad = bytearray(blob)
+        victims = {1: 21, 4: None, len(batches) - 1: -1}
+        for bi, where in victims.items():
+            p, t = batches[bi]
+            off = p + 21 if where == 21 else (p + t - 1 if where == -1 else p + 61 + (t - 61) // 2)
+            bad[off] ^= 0x40
+        bad = bytes(bad)
+        assert [bool(L.kto_kafka_batch_crc_ok(bad[p:p + t], t)) for p, t in batches] == \
+            [i not in victims for i in range(len(batches))]
+        cols2, st2, nbad2 = _decode_on_device(h, bad, 1, True)
+        n_err = C.c_uint64()
+        h._check(lib.kta_kafka_crc_errors(h._ctx, C.byref(n_err)))
+        assert n_err.value == len(victims) and nbad2 == len(victims)
+        counts = [int.from_bytes(blob[p + 57:p + 61], "big") for p, _ in batches]
+        want = np.concatenate([np.full(c, -1 if i in victims else 1, np.int32) for i, c in enumerate(counts)])
+        assert np.array_equal(cols2["partition"], want)
+        # with check.crcs off (librdkafka's default) the corrupted value/header bytes go unnoticed or are
+        # caught by framing only: no CRC errors are reported
+        h._check(lib.kta_kafka_set_check_crcs(h._ctx, 0))
+        _decode_on_device(h, bad, 1, True)
+        h._check(lib.kta_kafka_crc_errors(h._ctx, C.byref(n_err)))
+        assert n_err.value == len(victims)

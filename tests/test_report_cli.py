@@ -215,3 +215,18 @@ def test_cli_on_raw_kafka_log_segments(tmp_path, with_c):
     norm = lambda t: re.sub(r"Estimated Msg/s: \d+", "Estimated Msg/s: X", re.sub(r"Scanning took: \d+ seconds", "Scanning took: 0 seconds", t))
     # earliest message: the CLI's Utc::now() sentinel never wins here (all timestamps are in 2020)
     assert norm(got) == norm(want)
+    if with_c:
+        return
+    # check.crcs=true forwarded like a librdkafka option: a flipped value byte makes that batch undeliverable
+    # (warned about, not counted); without the option the same file is analysed as if nothing happened
+    blob = bytearray(open(files[1], "rb").read())
+    total0 = 12 + int.from_bytes(blob[8:12], "big")
+    n0 = int.from_bytes(blob[57:61], "big")
+    blob[total0 - 1] ^= 0x01                      # last byte of the first batch (inside a value)
+    open(files[1], "wb").write(bytes(blob))
+    r1 = run_cli(*args, "--librdkafka", "check.crcs=true")
+    assert r1.returncode == 0 and "CRC failure" in r1.stderr and "%d record(s)" % n0 in r1.stderr
+    r2 = run_cli(*args)
+    assert r2.returncode == 0 and "CRC" not in r2.stderr
+    tot = lambda out: sum(int(l.split("|")[4]) for l in out.split("\n") if re.match(r"^\| \d", l))
+    assert tot(r2.stdout) == len(records) and tot(r1.stdout) == len(records) - n0
