@@ -161,7 +161,7 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     descs = (N.KtaKafkaBatchDesc * nb_cap)()
     st = N.KtaKafkaIndexStats()
     t0 = time.perf_counter()
-    rc = lib.kta_kafka_index_host(buf.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, descs, nb_cap, C.byref(st))
+    rc = lib.kta_kafka_index_host(buf.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, 0, descs, nb_cap, C.byref(st))
     t_index = time.perf_counter() - t0
     assert rc == 0 and st.n_records == n_records
     h = kta.HipMetricHandler(256, device=device)

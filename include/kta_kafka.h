@@ -27,8 +27,9 @@
  * What a consumer delivers per record (and what is written to the columns):
  *   partition = the record set's partition, timestamp = baseTimestamp + timestampDelta (or
  *   maxTimestamp for LogAppendTime), key/payload None iff the length is -1.
- * Not handled (counted, never silently mis-decoded): compressed batches (codec != 0), magic 0/1
- * message sets.  CRCs are verified only on request (kta_kafka_set_check_crcs) — librdkafka's
+ * Compression: Snappy batches (codec 2; bare blocks as librdkafka writes them and the snappy-java
+ * stream framing of the Java clients) are inflated on the device; gzip / lz4 / zstd batches and
+ * magic 0/1 message sets are counted, never silently mis-decoded.  CRCs are verified only on request (kta_kafka_set_check_crcs) — librdkafka's
  * `check.crcs` defaults to false and the reference does not set it (src/kafka.rs:28-36).
  */
 #ifndef KTA_KAFKA_H
@@ -48,6 +49,7 @@ extern "C" {
 /* flags of a batch descriptor */
 #define KTA_KB_LOG_APPEND_TIME 1u /* attributes bit 3 */
 #define KTA_KB_TRANSACTIONAL 2u   /* attributes bit 4 */
+#define KTA_KB_SNAPPY 4u          /* records are Snappy compressed (codec 2): inflated on the device */
 /* status of a batch after the device passes */
 #define KTA_KB_BAD_CRC 1u         /* CRC-32C mismatch (only with kta_kafka_set_check_crcs)           */
 #define KTA_KB_BAD_FRAMING 2u     /* records overran the batch                                      */
@@ -57,6 +59,8 @@ typedef struct kta_kafka_batch_desc {
     uint64_t record_base; /* index of its first record in the output columns               */
     uint32_t crc;         /* the batch's stored CRC-32C (over attributes .. end of batch)           */
     uint32_t status;      /* device: 0 ok, KTA_KB_BAD_CRC / KTA_KB_BAD_FRAMING after decoding       */
+    uint64_t payload_off; /* where the records are parsed from: byte_off + 61 for an uncompressed    */
+    uint64_t payload_end; /*   batch, else this batch's slice of the inflate area (same buffer)      */
     int64_t base_offset;  /* Kafka offset of the first record                                */
     int64_t base_ts_ms;
     int64_t max_ts_ms;
@@ -70,18 +74,25 @@ typedef struct kta_kafka_index_stats {
     uint64_t n_batches;          /* descriptors written                                     */
     uint64_t n_records;          /* sum of their recordsCount                               */
     uint64_t n_control_batches;  /* skipped: never delivered to the application             */
-    uint64_t n_compressed;       /* skipped: compression codec != 0 (not decoded here)      */
+    uint64_t n_compressed;       /* skipped: gzip / lz4 / zstd batches (not decoded here)   */
+    uint64_t n_snappy;           /* Snappy batches (codec 2): inflated on the device         */
+    uint64_t inflate_bytes;      /* bytes of inflate area the descriptors use               */
     uint64_t n_old_magic;        /* skipped: magic 0/1 message sets                         */
     uint64_t trailing_bytes;     /* bytes after the last complete batch (partial fetch tail)*/
     uint64_t bytes_consumed;
 } kta_kafka_index_stats;
 
 /* Host: walk the batch headers of one record set.  `record_base_start` is the output index of the
- * set's first record (lets several sets share one output batch).  Returns KTA_ERR_CAPACITY when
- * `cap` descriptors do not suffice (stats->n_batches then holds the number needed). */
+ * set's first record (lets several sets share one output batch).  Snappy batches get a slice of the
+ * inflate area, which starts at `inflate_offset` of the SAME device buffer as the blob (so keys stay
+ * zero-copy); stats->inflate_bytes tells how much of it is used.  Returns KTA_ERR_CAPACITY when `cap`
+ * descriptors do not suffice (stats->n_batches then holds the number needed). */
 int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, uint64_t blob_offset,
-                         uint64_t record_base_start, kta_kafka_batch_desc *descs, uint64_t cap,
-                         kta_kafka_index_stats *stats);
+                         uint64_t record_base_start, uint64_t inflate_offset, kta_kafka_batch_desc *descs,
+                         uint64_t cap, kta_kafka_index_stats *stats);
+/* Snappy inflate of one batch payload on the host (bare block or snappy-java stream framing): the
+ * same code the device runs.  Returns the bytes produced or -1. */
+int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 
 /* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
  * readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).

@@ -75,6 +75,7 @@ class KtaSynthSpec(C.Structure):
 
 class KtaKafkaBatchDesc(C.Structure):
     _fields_ = [("byte_off", C.c_uint64), ("record_base", C.c_uint64), ("crc", C.c_uint32), ("status", C.c_uint32),
+                ("payload_off", C.c_uint64), ("payload_end", C.c_uint64),
                 ("base_offset", C.c_int64), ("base_ts_ms", C.c_int64), ("max_ts_ms", C.c_int64),
                 ("batch_bytes", C.c_uint32), ("partition", C.c_int32), ("n_records", C.c_int32),
                 ("flags", C.c_uint32)]
@@ -82,7 +83,8 @@ class KtaKafkaBatchDesc(C.Structure):
 
 class KtaKafkaIndexStats(C.Structure):
     _fields_ = [("n_batches", C.c_uint64), ("n_records", C.c_uint64), ("n_control_batches", C.c_uint64),
-                ("n_compressed", C.c_uint64), ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
+                ("n_compressed", C.c_uint64), ("n_snappy", C.c_uint64), ("inflate_bytes", C.c_uint64),
+                ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
                 ("bytes_consumed", C.c_uint64)]
 
 
@@ -128,8 +130,9 @@ SIGNATURES = {
     "kta_synth_fill_device": (C.c_int, [_P, C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64,
                                         C.POINTER(KtaBatch), C.POINTER(C.c_uint64)]),
     "kta_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(KtaSynthSpec), C.POINTER(C.c_uint64)]),
-    "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,
+    "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_snappy_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,
                                           C.c_uint64, C.POINTER(KtaBatch), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]),

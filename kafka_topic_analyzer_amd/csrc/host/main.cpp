@@ -230,10 +230,10 @@ int main(int argc, char **argv)
             bytes.resize((size_t)sz);
             kta_kafka_index_stats ist;
             std::vector<kta_kafka_batch_desc> descs(1);
-            int rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, descs.data(), descs.size(), &ist);
+            int rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, 0, descs.data(), descs.size(), &ist);
             if (rc == KTA_ERR_CAPACITY) {
                 descs.resize(ist.n_batches);
-                rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, descs.data(), descs.size(), &ist);
+                rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, 0, descs.data(), descs.size(), &ist);
             }
             if (rc == KTA_OK && ist.n_batches > 0) {
                 start_offsets[p] = descs.front().base_offset;
@@ -324,7 +324,7 @@ int main(int argc, char **argv)
             check(kta_kafka_consume(ctx, segment_bytes[p].data(), segment_bytes[p].size(), (int32_t)p, &ist), ctx,
                   "kta_kafka_consume");
             if (ist.n_compressed || ist.n_old_magic)
-                fprintf(stderr, "[WARN] Kafka error: partition %u: %llu compressed and %llu pre-v2 batches skipped\n", p,
+                fprintf(stderr, "[WARN] Kafka error: partition %u: %llu gzip/lz4/zstd and %llu pre-v2 batches skipped\n", p,
                         (unsigned long long)ist.n_compressed, (unsigned long long)ist.n_old_magic);   // kafka.rs:95-97
             seq += ist.n_records;
         }

@@ -10,6 +10,7 @@
 // handlers never read them (src/metric.rs:233-245).
 #include "../../include/kta_kafka.h"
 #include "../../include/kta_synth.h"
+#include "kta_snappy.h"
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -75,8 +76,8 @@ __device__ __forceinline__ bool walk_batch(const uint4 *words, const kta_kafka_b
                                            uint32_t *koff_out, uint64_t blob_base, uint64_t *seq_out,
                                            uint64_t seq_base, uint64_t *key_total)
 {
-    Reader r{words, d.byte_off + KTA_KAFKA_BATCH_HEADER, ~0ull, make_uint4(0, 0, 0, 0)};
-    const uint64_t batch_end = d.byte_off + d.batch_bytes;
+    Reader r{words, d.payload_off, ~0ull, make_uint4(0, 0, 0, 0)};
+    const uint64_t batch_end = d.payload_end;
     uint64_t kb = 0;
     bool ok = true;
     int32_t j = 0;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
     const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
     if (b >= n_batches) return;
     kta_kafka_batch_desc d = descs[b];
-    if (d.status & KTA_KB_BAD_CRC) d.batch_bytes = KTA_KAFKA_BATCH_HEADER;   // not delivered: walk nothing
+    if (d.status) d.payload_end = d.payload_off;   // failed check.crcs / inflate: not delivered, walk nothing
     uint64_t kb = 0;
     const bool ok = walk_batch<true>(words, d, want_keys != 0, part, klen, vlen, ts, koff, blob_base, seq, seq_base, &kb);
     if (!ok) atomicAdd(n_bad, 1ull);
@@ -198,11 +199,11 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
     const uint64_t b = blockIdx.x;           // one workgroup (= one wave) per batch: the dispatcher balances
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
-    const uint64_t end = d.byte_off + d.batch_bytes;
+    const uint64_t end = d.payload_end;
     const uint32_t total = (uint32_t)d.n_records;
-    uint64_t pos = d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    uint64_t pos = d.payload_off;
     uint32_t j = 0;                          // records finished
-    bool bad = (d.status & KTA_KB_BAD_CRC) != 0;   // failed check.crcs: the batch is not delivered
+    bool bad = d.status != 0;                // failed check.crcs or inflate: the batch is not delivered
     while (!bad && j < total) {              // every condition below is wave-uniform
         if (pos >= end) { bad = true; break; }
         const uint64_t wbase = pos & ~15ull;
@@ -307,6 +308,23 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
 }
 
 // ---- per-context state for kta_kafka_consume / timing ---------------------------------------------
+// ---- Snappy inflate: one lane per compressed batch ------------------------------------------------
+// (kta_snappy.h; the same function is compiled for the host and checked there against the oracle.)
+// The inflated records land in the batch's slice of the inflate area, which is part of the same
+// device buffer as the raw blob, so key offsets stay valid for the zero-copy alive-key pass.
+__global__ __launch_bounds__(kLanesPerBlock) void kafka_snappy_inflate(uint8_t *buffer, kta_kafka_batch_desc *descs,
+                                                                        uint64_t n_batches)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_SNAPPY) || d.status) return;
+    const int64_t got = kta::snappy_inflate(buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER,
+                                            (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, buffer + d.payload_off,
+                                            d.payload_end - d.payload_off);
+    if (got < 0 || (uint64_t)got != d.payload_end - d.payload_off) descs[b].status = KTA_KB_BAD_FRAMING;
+}
+
 // ---- CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) on the device -------------------------
 // One wave per batch.  The bytes [start, end) are cut on the absolute 64-byte grid; per 4 KiB window
 // every lane reduces its 64-byte chunk with slicing-by-4 tables held in LDS (raw register update, no
@@ -407,7 +425,8 @@ __global__ __launch_bounds__(64) void kafka_crc32c(const uint4 *blocks, kta_kafk
 // pinned batch index and the decoded columns.
 struct BlobStage {
     uint8_t *h_blob = nullptr, *d_blob = nullptr;
-    uint64_t cap = 0;
+    uint64_t cap = 0;      // host blob capacity
+    uint64_t d_cap = 0;    // device buffer capacity: the blob plus the inflate area of compressed batches
     kta_kafka_batch_desc *h_descs = nullptr; // pinned: the H2D copy of the index is truly asynchronous
     uint64_t desc_cap = 0;
     kta_batch out{};
@@ -525,12 +544,12 @@ int pair(kta_ctx *ctx, KafkaState *st, int k, hipEvent_t *a, hipEvent_t *b)
 extern "C" {
 
 int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, uint64_t blob_offset,
-                         uint64_t record_base_start, kta_kafka_batch_desc *descs, uint64_t cap,
-                         kta_kafka_index_stats *stats)
+                         uint64_t record_base_start, uint64_t inflate_offset, kta_kafka_batch_desc *descs,
+                         uint64_t cap, kta_kafka_index_stats *stats)
 {
     if (!bytes || !stats || (cap && !descs)) return KTA_ERR_INVALID;
     memset(stats, 0, sizeof(*stats));
-    uint64_t pos = 0, rec = record_base_start, nb = 0;
+    uint64_t pos = 0, rec = record_base_start, nb = 0, inflate = 0;
     while (pos + 12 <= len) {
         const int32_t batch_length = (int32_t)be32(bytes + pos + 8);
         if (batch_length < KTA_KAFKA_BATCH_HEADER - 12) break;           // not a v2 batch header: stop
@@ -542,8 +561,16 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
         } else {
             const uint16_t attrs = be16(bytes + pos + 21);
             const int32_t count = (int32_t)be32(bytes + pos + 57);
+            const uint32_t codec = attrs & 0x07u;
+            int64_t inflated = 0;
+            if (codec == 2) {
+                const uint64_t clen = total - KTA_KAFKA_BATCH_HEADER;
+                inflated = kta::snappy_uncompressed_len(bytes + pos + KTA_KAFKA_BATCH_HEADER, clen);
+                // a copy element expands at most 3 bytes into 64: anything beyond ~22x is a corrupt preamble
+                if (inflated > (int64_t)(clen * 22 + 64)) inflated = -1;
+            }
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
-            else if (attrs & 0x07) stats->n_compressed++;                 // compressed: not decoded here
+            else if (codec != 0 && codec != 2) stats->n_compressed++;     // gzip / lz4 / zstd: not decoded here
             else if (count > 0) {
                 if (nb < cap) {
                     kta_kafka_batch_desc &d = descs[nb];
@@ -558,6 +585,22 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     d.partition = partition;
                     d.n_records = count;
                     d.flags = ((attrs & 0x08) ? KTA_KB_LOG_APPEND_TIME : 0u) | ((attrs & 0x10) ? KTA_KB_TRANSACTIONAL : 0u);
+                    if (codec == 2) {
+                        d.flags |= KTA_KB_SNAPPY;
+                        if (inflated < 0) {          // malformed stream: nothing to parse, reported as bad
+                            d.status = KTA_KB_BAD_FRAMING;
+                            inflated = 0;
+                        }
+                        d.payload_off = inflate_offset + inflate;
+                        d.payload_end = d.payload_off + (uint64_t)inflated;
+                    } else {
+                        d.payload_off = d.byte_off + KTA_KAFKA_BATCH_HEADER;
+                        d.payload_end = d.byte_off + total;
+                    }
+                }
+                if (codec == 2) {
+                    stats->n_snappy++;
+                    inflate += ((uint64_t)(inflated > 0 ? inflated : 0) + 63) & ~63ull;   // 64-byte aligned slices
                 }
                 nb++;
                 rec += (uint64_t)count;
@@ -569,7 +612,14 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
     stats->n_records = rec - record_base_start;
     stats->bytes_consumed = pos;
     stats->trailing_bytes = len - pos;
+    stats->inflate_bytes = inflate;
     return nb > cap ? KTA_ERR_CAPACITY : KTA_OK;
+}
+
+int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
+    return kta::snappy_inflate(src, n, dst, cap);
 }
 
 int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
@@ -635,6 +685,22 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipGetLastError());
         if (timing) KK(ctx, hipEventRecord(b, s));
     }
+    bool any_snappy = false;
+    uint64_t buffer_end = blob_len;
+    for (uint64_t i = 0; i < n_batches; i++)
+        if (descs_host[i].flags & KTA_KB_SNAPPY) {
+            any_snappy = true;
+            if (descs_host[i].payload_end > buffer_end) buffer_end = descs_host[i].payload_end;
+        }
+    if (want_keys && buffer_end >= (1ull << 32)) {
+        kta_internal_set_error(ctx, "blob + inflate area must be < 4 GiB when key offsets are wanted (key_off is u32)");
+        return KTA_ERR_CAPACITY;
+    }
+    if (any_snappy) {   // inflate compressed batches into their slices of the same buffer
+        hipLaunchKernelGGL(kafka_snappy_inflate, dim3(grid), dim3(kLanesPerBlock), 0, s,
+                           const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
+        KK(ctx, hipGetLastError());
+    }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
     if (g_decode_variant == 0)   // one wave per batch (default)
         hipLaunchKernelGGL(kafka_decode_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
@@ -684,7 +750,8 @@ int kta_kafka_blob_acquire(kta_ctx *ctx, uint8_t **host_ptr, uint64_t *capacity)
     if (!g.h_blob) {
         g.cap = st->blob_capacity;
         KK(ctx, hipHostMalloc((void **)&g.h_blob, g.cap + 64, hipHostMallocDefault));
-        KK(ctx, hipMalloc((void **)&g.d_blob, g.cap + 64));
+        g.d_cap = g.cap + 128;
+        KK(ctx, hipMalloc((void **)&g.d_blob, g.d_cap));
         KK(ctx, hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
         KK(ctx, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     }
@@ -721,17 +788,24 @@ int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kaf
         g.desc_cap = 4096;
         KK(ctx, hipHostMalloc((void **)&g.h_descs, g.desc_cap * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
     }
-    rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, g.h_descs, g.desc_cap, stats);
+    const uint64_t inflate_at = (len + 127) & ~63ull;   // inflate area: right behind the raw bytes, 64-byte aligned
+    rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, inflate_at, g.h_descs, g.desc_cap, stats);
     if (rc == KTA_ERR_CAPACITY) {
         (void)hipHostFree(g.h_descs);
         g.desc_cap = stats->n_batches + stats->n_batches / 4;
         KK(ctx, hipHostMalloc((void **)&g.h_descs, g.desc_cap * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
-        rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, g.h_descs, g.desc_cap, stats);
+        rc = kta_kafka_index_host(g.h_blob, len, partition, 0, 0, inflate_at, g.h_descs, g.desc_cap, stats);
     }
     if (rc != KTA_OK) return rc;
     if (stats->n_batches == 0) return KTA_OK;
     const bool keys = kta_internal_count_alive(ctx);
     const uint64_t used = stats->bytes_consumed, nrec = stats->n_records;
+    if (inflate_at + stats->inflate_bytes + 128 > g.d_cap) {   // compressed batches: grow the device buffer (stage is idle)
+        (void)hipFree(g.d_blob);
+        g.d_blob = nullptr;
+        g.d_cap = inflate_at + stats->inflate_bytes + stats->inflate_bytes / 4 + 4096;
+        KK(ctx, hipMalloc((void **)&g.d_blob, g.d_cap));
+    }
     // 2. decoded columns of this stage (grown on demand; the stage is idle here)
     if (g.out_cap < nrec || (keys && !g.out.key_off)) {
         free_out(g.out);
@@ -744,7 +818,7 @@ int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kaf
         g.out.capacity = g.out_cap;
     }
     g.out.key_bytes = keys ? g.d_blob : nullptr; // zero-copy: keys are hashed in place in the raw log
-    g.out.key_bytes_capacity = keys ? used : 0;
+    g.out.key_bytes_capacity = keys ? inflate_at + stats->inflate_bytes : 0;
     // 3. raw log over PCIe on the copy stream; decode + metric handlers on the compute stream
     KK(ctx, hipMemcpyAsync(g.d_blob, g.h_blob, (used + 63) & ~63ull, hipMemcpyHostToDevice, cs));
     KK(ctx, hipEventRecord(g.copied, cs));
@@ -785,6 +859,8 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         stats->n_records += one.n_records;
         stats->n_control_batches += one.n_control_batches;
         stats->n_compressed += one.n_compressed;
+        stats->n_snappy += one.n_snappy;
+        stats->inflate_bytes += one.inflate_bytes;
         stats->n_old_magic += one.n_old_magic;
         stats->bytes_consumed += one.bytes_consumed;
         if (one.bytes_consumed == 0) {   // not even one whole batch fits / trailing partial batch

@@ -12,7 +12,10 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
+
+int64_t kto_snappy_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
 
 typedef struct {
     uint64_t control_batches, compressed_batches, old_magic_batches, trailing_bytes, bad_batches, batches;
@@ -53,11 +56,12 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (batch_length < 49) break;
         uint64_t total = 12 + (uint64_t)batch_length;
         if (pos + total > len) break;
-        const uint8_t *b = bytes + pos, *bend = b + total;
+        const uint8_t *b = bytes + pos;
+        const uint8_t *bend = b + total;
         if (b[16] != 2) { st->old_magic_batches++; pos += total; continue; }
         uint16_t attrs = (uint16_t)rd_be(b + 21, 2);
         if (attrs & 0x20) { st->control_batches++; pos += total; continue; }
-        if (attrs & 0x07) { st->compressed_batches++; pos += total; continue; }
+        if ((attrs & 0x07) != 0 && (attrs & 0x07) != 2) { st->compressed_batches++; pos += total; continue; }
         int64_t base_offset = (int64_t)rd_be(b, 8);
         int64_t base_ts = (int64_t)rd_be(b + 27, 8), max_ts = (int64_t)rd_be(b + 35, 8);
         int32_t count = (int32_t)rd_be(b + 57, 4);
@@ -65,6 +69,15 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         st->batches++;
         const uint8_t *p = b + 61;
         int bad = 0;
+        uint8_t *inflated = NULL;
+        if ((attrs & 0x07) == 2) { /* Snappy: the records section is compressed as a whole */
+            uint64_t cap = (total - 61) * 64 + 65536;
+            inflated = (uint8_t *)malloc((size_t)cap);
+            int64_t got = kto_snappy_inflate(b + 61, total - 61, inflated, cap);
+            if (got < 0) { bad = 1; got = 0; }
+            p = inflated;
+            bend = inflated + got;
+        }
         for (int32_t j = 0; j < count; j++) {
             int64_t rlen, tsd, offd, kl, vl;
             size_t c;
@@ -103,6 +116,7 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
             n++;
         }
         if (bad) st->bad_batches++;
+        free(inflated);
         pos += total;
     }
     st->trailing_bytes = len - pos;
@@ -128,4 +142,84 @@ int kto_kafka_batch_crc_ok(const uint8_t *batch, uint64_t total)
 {
     uint32_t stored = (uint32_t)rd_be(batch + 17, 4);
     return stored == kto_crc32c(batch + 21, total - 21);
+}
+
+/* ---- Snappy (Kafka codec 2): independent sequential inflater --------------------------------------
+ * Restates google/snappy's format_description.txt and snappy-java's stream framing (magic
+ * "\x82SNAPPY\0", two big-endian version words, then [u32 BE length][block]...).  Written against the
+ * format text, not against the product's kta_snappy.h. */
+static int64_t kto_snappy_block(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    uint64_t ulen = 0, i = 0, o = 0;
+    int shift = 0;
+    for (;;) {
+        if (i >= n || shift > 28) return -1;
+        uint8_t b = src[i++];
+        ulen |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+        if (!(b & 0x80)) break;
+    }
+    if (ulen > cap) return -1;
+    while (i < n) {
+        uint8_t tag = src[i++];
+        switch (tag & 3) {
+        case 0: {
+            uint64_t l = (uint64_t)(tag >> 2) + 1;
+            if (l > 60) {
+                int extra = (int)l - 60;
+                if (i + (uint64_t)extra > n) return -1;
+                l = 0;
+                for (int k = extra - 1; k >= 0; k--) l = (l << 8) | src[i + (uint64_t)k];
+                l += 1;
+                i += (uint64_t)extra;
+            }
+            if (i + l > n || o + l > ulen) return -1;
+            memcpy(out + o, src + i, (size_t)l);
+            i += l; o += l;
+            break;
+        }
+        default: {
+            uint64_t l, off;
+            if ((tag & 3) == 1) {
+                if (i >= n) return -1;
+                l = ((tag >> 2) & 7) + 4;
+                off = ((uint64_t)(tag & 0xe0) << 3) | src[i];
+                i += 1;
+            } else if ((tag & 3) == 2) {
+                if (i + 2 > n) return -1;
+                l = (tag >> 2) + 1;
+                off = src[i] | ((uint64_t)src[i + 1] << 8);
+                i += 2;
+            } else {
+                if (i + 4 > n) return -1;
+                l = (tag >> 2) + 1;
+                off = src[i] | ((uint64_t)src[i + 1] << 8) | ((uint64_t)src[i + 2] << 16) | ((uint64_t)src[i + 3] << 24);
+                i += 4;
+            }
+            if (off == 0 || off > o || o + l > ulen) return -1;
+            while (l--) { out[o] = out[o - off]; o++; }
+            break;
+        }
+        }
+    }
+    return o == ulen ? (int64_t)o : -1;
+}
+
+int64_t kto_snappy_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    static const uint8_t magic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+    if (n >= 16 && memcmp(src, magic, 8) == 0) {
+        uint64_t i = 16, o = 0;
+        while (i + 4 <= n) {
+            uint64_t clen = rd_be(src + i, 4);
+            i += 4;
+            if (clen == 0 || i + clen > n) return -1;
+            int64_t got = kto_snappy_block(src + i, clen, out + o, cap - o);
+            if (got < 0) return -1;
+            o += (uint64_t)got;
+            i += clen;
+        }
+        return i == n ? (int64_t)o : -1;
+    }
+    return kto_snappy_block(src, n, out, cap);
 }

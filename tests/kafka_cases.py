@@ -5,7 +5,8 @@ import numpy as np
 import kafka_format as K
 
 
-def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50, with_noise=True, big=False):
+def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50, with_noise=True, big=False,
+                      snappy=False):
     """-> (blob bytes, expected (part, klen, vlen, ts, keys) lists, info dict)."""
     blob = bytearray()
     batches = []
@@ -24,7 +25,9 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             if big and rng.random() < 0.01:  # a key larger than the decoder's 8 KiB LDS window
                 key = bytes(rng.integers(0, 256, size=int(rng.integers(9000, 20000)), dtype=np.uint8))
             r = rng.random()
-            val = None if r < 0.2 else (b"" if r < 0.23 else bytes(int(rng.integers(1, 20000 if big else 600))))
+            vlen = int(rng.integers(1, 20000 if big else 600))
+            val = None if r < 0.2 else (b"" if r < 0.23 else
+                                        (bytes(vlen) if not snappy else (b"payload-%d " % kid) * (vlen // 12 + 1)))
             headers = [(b"h%d" % i, None if i % 3 == 0 else b"x" * i) for i in range(int(rng.integers(0, 4)))]
             recs.append((int(rng.integers(-5000, 500000)), key, val, headers))
         kind = rng.random() if with_noise else 1.0
@@ -34,7 +37,7 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             attrs = 0x20 | 0x10  # control batch (transactional marker): skipped
             info["control"] += 1
         elif kind < 0.10:
-            attrs = int(rng.integers(1, 5))  # "compressed": skipped (payload is not really compressed)
+            attrs = int(rng.choice([1, 3, 4]))  # gzip / lz4 / zstd: skipped (payload is not really compressed)
             info["compressed"] += 1
         elif kind < 0.2:
             attrs = 0x08  # LogAppendTime: every record carries maxTimestamp
@@ -44,8 +47,12 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
         if attrs & 0x27 == 0 or attrs & 0x20 == 0 and attrs & 0x07 == 0:
             info["batches"] += 1
         mt = max_ts if max_ts is not None else max(base_ts + r[0] for r in recs)
-        blob += K.encode_batch(offset, recs, base_ts, attributes=attrs, max_ts=mt)
-        batches.append((base_ts, attrs, mt, recs))
+        comp = None
+        if snappy and attrs & 0x27 == 0 and rng.random() < 0.5:  # Snappy batches, both framings
+            comp = "snappy" if rng.random() < 0.5 else "snappy-xerial"
+            info["snappy"] = info.get("snappy", 0) + 1
+        blob += K.encode_batch(offset, recs, base_ts, attributes=attrs, max_ts=mt, compression=comp)
+        batches.append((base_ts, attrs | (2 if comp else 0), mt, recs))
         offset += n
         if with_noise and rng.random() < 0.03:  # an old-format (magic 1) message set: skipped
             blob += K.encode_batch(offset, [(0, b"old", b"fmt")], base_ts, magic=1)

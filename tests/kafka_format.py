@@ -55,11 +55,17 @@ def encode_record(offset_delta, ts_delta, key, value, headers=()):
 
 
 def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, producer_id=-1, magic=2,
-                 raw_records=None, count=None):
+                 raw_records=None, count=None, compression=None):
     """records: [(ts_delta, key|None, value|None, headers)]; returns the batch bytes.
-    raw_records/count let tests build corrupt or compressed-looking batches."""
+    raw_records/count let tests build corrupt or compressed-looking batches.
+    compression: None, "snappy" (one bare block, as librdkafka writes) or "snappy-xerial" (snappy-java
+    stream framing, as the Java clients write): the records section is compressed and codec 2 is set."""
     recs = b"".join(encode_record(i, r[0], r[1], r[2], r[3] if len(r) > 3 else ()) for i, r in enumerate(records)) \
         if raw_records is None else raw_records
+    if compression:
+        import snappy_py
+        recs = snappy_py.compress_block(recs) if compression == "snappy" else snappy_py.compress_xerial(recs, 4096)
+        attributes = (attributes & ~0x07) | 2
     n = len(records) if count is None else count
     if max_ts is None:
         max_ts = max([base_ts + r[0] for r in records], default=base_ts)
@@ -73,7 +79,7 @@ def expected_columns(partition, batches):
     """batches: [(base_ts, attributes, max_ts, records)] -> the columns a consumer would deliver."""
     part, klen, vlen, ts, keys = [], [], [], [], []
     for base_ts, attributes, max_ts, records in batches:
-        if attributes & 0x20 or attributes & 0x07:
+        if attributes & 0x20 or (attributes & 0x07) not in (0, 2):   # control, or a codec that is not decoded
             continue
         for r in records:
             part.append(partition)

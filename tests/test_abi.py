@@ -21,7 +21,7 @@ def _declared_symbols():
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         # prototypes only (skip the static inline generator definitions)
-        for m in re.finditer(r"^(?:int|void|uint32_t|const char \*)\s*\*?\s*(kta_\w+)\s*\(", text, flags=re.M):
+        for m in re.finditer(r"^(?:int|void|uint32_t|int64_t|const char \*)\s*\*?\s*(kta_\w+)\s*\(", text, flags=re.M):
             names.add(m.group(1))
     return names
 

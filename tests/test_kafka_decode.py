@@ -22,7 +22,8 @@ def index_host(blob, partition, cap=None):
     st = N.KtaKafkaIndexStats()
     n = cap if cap is not None else 1 << 16
     descs = (N.KtaKafkaBatchDesc * n)()
-    rc = lib.kta_kafka_index_host(blob, len(blob), partition, 0, 0, descs, n, C.byref(st))
+    inflate_at = (len(blob) + 127) & ~63  # the inflate area of compressed batches follows the raw bytes
+    rc = lib.kta_kafka_index_host(blob, len(blob), partition, 0, 0, inflate_at, descs, n, C.byref(st))
     return rc, descs, st
 
 
@@ -104,15 +105,18 @@ def _decode_on_device(h, blob, partition, with_keys):
     n = st.n_records
     d_blob = C.c_void_p()
     out = h.device_batch_alloc(max(n, 1), 16 if with_keys else 0)  # key_off only: keys stay in the blob
-    blob_dev = h.device_batch_alloc((len(blob) + 3) // 4 + 32)  # a column as the raw byte buffer (+128 B pad)
+    buf_bytes = ((len(blob) + 127) & ~63) + st.inflate_bytes + 128   # raw bytes + inflate area + padding
+    blob_dev = h.device_batch_alloc(buf_bytes // 4 + 1)  # a column serves as the raw byte buffer
     arr = np.frombuffer(blob + b"\0" * ((-len(blob)) % 4), dtype=np.uint8).copy()
     h._check(lib.kta_copy_to_device(h._ctx, blob_dev.partition, arr.ctypes.data, arr.nbytes))
     kb, bad = C.c_uint64(), C.c_uint64()
     h._check(lib.kta_kafka_decode_device(h._ctx, blob_dev.partition, len(blob), descs, st.n_batches, n, C.byref(out),
                                          C.byref(kb), C.byref(bad)))
     cols = h.download_batch(out, n, 0)
-    if with_keys:
-        cols["key_bytes"] = np.frombuffer(blob, dtype=np.uint8)  # zero-copy: key_off indexes the raw blob
+    if with_keys:  # zero-copy: key_off indexes the device buffer (raw blob, then the inflate area)
+        whole = np.empty(buf_bytes, dtype=np.uint8)
+        h._check(lib.kta_copy_to_host(h._ctx, whole.ctypes.data, blob_dev.partition, buf_bytes))
+        cols["key_bytes"] = whole
     cols["n_key_bytes"] = kb.value
     h.device_batch_free(out)
     h.device_batch_free(blob_dev)
@@ -259,3 +263,110 @@ def test_device_crc32c_check_flags_exactly_the_corrupted_batches():
         _decode_on_device(h, bad, 1, True)
         h._check(lib.kta_kafka_crc_errors(h._ctx, C.byref(n_err)))
         assert n_err.value == len(victims)
+
+
+# --------------------------------------------------------------------------------------------- Snappy
+def test_snappy_inflate_host_matches_oracle_and_python():
+    """The product's inflater (the same function the device runs, compiled for the host) against the
+    oracle's independent inflater and the Python decompressor, on data from the Python compressor."""
+    import ctypes as C2
+    import snappy_py as S
+    from oracle_c import lib as olib
+    L = olib()
+    L.kto_snappy_inflate.restype = C2.c_int64
+    L.kto_snappy_inflate.argtypes = [C2.c_char_p, C2.c_uint64, C2.c_char_p, C2.c_uint64]
+    lib = N.load()
+    rng = np.random.default_rng(3)
+    cases = [b"", b"a", b"abcd" * 1000, bytes(rng.integers(0, 256, size=5000, dtype=np.uint8)), b"\0" * 100000,
+             bytes(rng.integers(0, 4, size=70000, dtype=np.uint8)),
+             b"".join(b"key-%d value-%d;" % (i % 97, i) for i in range(3000))]
+    for d in cases:
+        for comp in (S.compress_block(d), S.compress_xerial(d, 4096), S.compress_xerial(d)):
+            out1, out2 = C2.create_string_buffer(len(d) + 1), C2.create_string_buffer(len(d) + 1)
+            assert lib.kta_snappy_inflate_host(comp, len(comp), out1, len(d)) == len(d)
+            assert L.kto_snappy_inflate(comp, len(comp), out2, len(d)) == len(d)
+            assert out1.raw[:len(d)] == d == out2.raw[:len(d)]
+            if not comp.startswith(b"\x82SNAPPY"):
+                assert S.decompress_block(comp) == d
+    # malformed input is refused, not mis-decoded: truncated stream, zero / too-far copy offset, short output buffer
+    good = S.compress_block(b"abcdefgh" * 50)
+    out = C2.create_string_buffer(1024)
+    assert lib.kta_snappy_inflate_host(good[:-3], len(good) - 3, out, 1024) == -1
+    assert lib.kta_snappy_inflate_host(good, len(good), out, 100) == -1
+    bad_off = bytes([8, 0 << 2]) + b"a" + bytes([1 | (0 << 2), 9])   # len 8; literal "a"; copy offset 9 > produced
+    assert lib.kta_snappy_inflate_host(bad_off, len(bad_off), out, 1024) == -1
+    assert L.kto_snappy_inflate(bad_off, len(bad_off), out, 1024) == -1
+
+
+def test_host_index_sizes_snappy_batches():
+    rng = np.random.default_rng(21)
+    blob, expected, info = random_record_set(rng, 40, snappy=True)
+    rc, descs, st = index_host(blob, 3)
+    assert rc == N.KTA_OK and st.n_snappy == info["snappy"] > 0
+    cols, ost = kafka_decode(blob, 3)
+    assert_columns(cols, expected)
+    inflate_at = (len(blob) + 127) & ~63
+    run = 0
+    for i in range(st.n_batches):
+        d = descs[i]
+        if d.flags & 4:  # KTA_KB_SNAPPY: a 64-byte aligned slice of the inflate area
+            assert d.payload_off == inflate_at + run and d.payload_off % 64 == 0
+            run += (d.payload_end - d.payload_off + 63) & ~63
+        else:
+            assert (d.payload_off, d.payload_end) == (d.byte_off + 61, d.byte_off + d.batch_bytes)
+    assert run == st.inflate_bytes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_decodes_snappy_batches(variant):
+    rng = np.random.default_rng(33)
+    blob, expected, info = random_record_set(rng, 120, max_records=120, snappy=True)
+    assert info["snappy"] > 20
+    want, _ = kafka_decode(blob, 3)
+    lib = N.load()
+    lib.kta_kafka_set_variant(variant)
+    with kta.HipMetricHandler(8, now=NOW) as h:
+        h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))   # the CRC covers the compressed bytes
+        cols, st, bad = _decode_on_device(h, blob, 3, True)
+        assert bad == 0 and st.n_snappy == info["snappy"]
+        assert_columns(cols, expected, key_check=True)
+        for k in ("partition", "key_len", "val_len", "ts_ms"):
+            assert np.array_equal(cols[k], want[k]), k
+        # a corrupted compressed stream is reported, never mis-decoded (check.crcs off so that the
+        # inflater itself has to notice)
+        h._check(lib.kta_kafka_set_check_crcs(h._ctx, 0))
+        first = _batches_of(blob)
+        rc, descs, _st = index_host(blob, 3)
+        victim = next(i for i in range(_st.n_batches) if descs[i].flags & 4)
+        p = descs[victim].byte_off
+        broken = bytearray(blob)
+        broken[p + 61] = 0xFF
+        broken[p + 62] = 0xFF
+        broken[p + 63] = 0xFF
+        broken[p + 64] = 0xFF
+        broken[p + 65] = 0x7F                       # preamble claims a 34 GB block
+        cols2, st2, bad2 = _decode_on_device(h, bytes(broken), 3, True)
+        assert bad2 >= 1 and (cols2["partition"] == -1).sum() == descs[victim].n_records
+    lib.kta_kafka_set_variant(0)
+
+
+@pytest.mark.gpu
+def test_consume_snappy_record_sets_end_to_end():
+    lib = N.load()
+    rng = np.random.default_rng(44)
+    P = 3
+    o = Oracle(NOW, True)
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+        for fetch in range(5):
+            part = fetch % P
+            blob, expected, info = random_record_set(rng, 40, partition=part, key_space=60, snappy=True)
+            st = N.KtaKafkaIndexStats()
+            h._check(lib.kta_kafka_consume(h._ctx, blob, len(blob), part, C.byref(st)))
+            cols, _ = kafka_decode(blob, part)
+            assert st.n_records == len(cols["partition"]) and st.n_snappy == info["snappy"]
+            o.run_soa({k: v for k, v in cols.items() if k != "offset"})
+        res, c = h.finish()
+        assert np.array_equal(c, o.counters(P))
+        assert res.alive_keys == o.alive_keys()
+        assert np.array_equal(h.export_alive_bitmap(), o.alive_words())   # keys hashed in place in the inflate area

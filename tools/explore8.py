@@ -17,7 +17,7 @@ for preset, rpb in (("c4", 60), ("c4", 600), ("c4", 4000), ("c3", 60)):
     st = N.KtaKafkaIndexStats()
     nb_cap = n // rpb + 2
     descs = (N.KtaKafkaBatchDesc * nb_cap)()
-    t0 = time.time(); rc = lib.kta_kafka_index_host(blob.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, descs, nb_cap, C.byref(st)); ti = time.time() - t0
+    t0 = time.time(); rc = lib.kta_kafka_index_host(blob.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, 0, descs, nb_cap, C.byref(st)); ti = time.time() - t0
     assert rc == 0 and st.n_records == n
     for variant, alive in ((0, False), (0, True), (2, True)):
         waves = 0
