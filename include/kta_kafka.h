@@ -128,6 +128,11 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
  * `out` may be NULL to size the buffer; *len receives the bytes written / needed. */
 int kta_kafka_encode_synth_host(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
                                 uint32_t records_per_batch, uint8_t *out, uint64_t cap, uint64_t *len);
+/* As above with a codec: 0 = none, 2 = Snappy (bare blocks from a small greedy compressor; values are
+ * then filled with a 24-byte periodic pseudo-random pattern so that the stream has real copies). */
+int kta_kafka_encode_synth_host_ex(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
+                                   uint32_t records_per_batch, int codec, uint8_t *out, uint64_t cap,
+                                   uint64_t *len);
 
 /* librdkafka's `check.crcs` (default false; the reference forwards user options, src/kafka.rs:38-42):
  * when enabled, every batch's CRC-32C (Castagnoli, over the bytes from `attributes` to the end of

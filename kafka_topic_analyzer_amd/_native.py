@@ -142,6 +142,8 @@ SIGNATURES = {
     "kta_kafka_consume": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(KtaKafkaIndexStats)]),
     "kta_kafka_encode_synth_host": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                               C.c_uint64, C.POINTER(C.c_uint64)]),
+    "kta_kafka_encode_synth_host_ex": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "kta_kafka_set_variant": (C.c_int, [C.c_int]),
     "kta_kafka_set_check_crcs": (C.c_int, [_P, C.c_int]),
     "kta_kafka_crc_errors": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -325,6 +325,141 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_snappy_inflate(uint8_t *
     if (got < 0 || (uint64_t)got != d.payload_end - d.payload_off) descs[b].status = KTA_KB_BAD_FRAMING;
 }
 
+// ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
+// Elements are inherently sequential, but each one moves up to 64 bytes: the wave parses the tag
+// uniformly (compressed stream staged in an LDS window, so a tag costs LDS latency, not an L2 round
+// trip) and executes every literal / copy with all 64 lanes.  The last 16 KiB of output are mirrored in
+// an LDS ring: a copy whose offset reaches further back reads the global output instead (after a fence).
+constexpr uint32_t kSnapWin = 4096;
+constexpr uint32_t kSnapRing = 16384;
+
+__global__ __launch_bounds__(64) void kafka_snappy_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs,
+                                                                 uint64_t n_batches)
+{
+    __shared__ uint4 s_in[kSnapWin / 16];
+    __shared__ uint8_t s_ring[kSnapRing];
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s_in);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_SNAPPY) || d.status) return;
+    const uint64_t src0 = d.byte_off + KTA_KAFKA_BATCH_HEADER;     // absolute offsets into `buffer`
+    const uint64_t src_end = d.byte_off + d.batch_bytes;
+    uint8_t *dst = buffer + d.payload_off;
+    const uint64_t cap = d.payload_end - d.payload_off;
+    const uint4 *blocks = reinterpret_cast<const uint4 *>(buffer);
+    uint64_t wbase = ~0ull;                                          // absolute, 16-byte aligned
+    // make [at, at + need) readable through `win`; everything is wave-uniform
+    auto fetch = [&](uint64_t at, uint32_t need) {
+        if (wbase != ~0ull && at >= wbase && at + need <= wbase + kSnapWin) return;
+        __syncthreads();
+        wbase = at & ~15ull;
+        for (uint32_t o = lane * 16; o < kSnapWin; o += 64 * 16)
+            if (wbase + o < ((src_end + 15) & ~15ull)) s_in[o >> 4] = blocks[(wbase + o) >> 4];
+        __syncthreads();
+    };
+    auto in_byte = [&](uint64_t at) -> uint32_t { return win[at - wbase]; };
+
+    uint64_t pos = src0, op = 0;
+    bool bad = false;
+    fetch(pos, 16);
+    bool xerial = src_end - src0 >= 16;
+    if (xerial) {
+        const uint8_t magic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+        for (int k = 0; k < 8; k++) xerial = xerial && in_byte(pos + k) == magic[k];
+    }
+    if (xerial) pos += 16;
+    while (!bad && pos < src_end) {                                  // one iteration per block
+        uint64_t bend = src_end;
+        if (xerial) {
+            if (pos + 4 > src_end) { bad = true; break; }
+            fetch(pos, 4);
+            const uint64_t clen = ((uint64_t)in_byte(pos) << 24) | ((uint64_t)in_byte(pos + 1) << 16) |
+                                  ((uint64_t)in_byte(pos + 2) << 8) | in_byte(pos + 3);
+            pos += 4;
+            bend = pos + clen;
+            if (clen == 0 || bend > src_end) { bad = true; break; }
+        }
+        // preamble: uncompressed length of this block (little-endian base-128, at most 5 bytes)
+        uint64_t want = 0;
+        uint32_t pre = 0;
+        bool terminated = false;
+        fetch(pos, 8);
+        while (pre < 5 && pos + pre < bend && !terminated) {
+            const uint32_t byte = in_byte(pos + pre);
+            want |= (uint64_t)(byte & 0x7Fu) << (7 * pre);
+            terminated = !(byte & 0x80u);
+            pre++;
+        }
+        if (!terminated || op + want > cap) { bad = true; break; }
+        const uint64_t block_out_end = op + want;
+        uint64_t ip = pos + pre;
+        while (ip < bend) {                                          // one iteration per element
+            fetch(ip, 8);
+            const uint32_t tag = in_byte(ip);
+            ip++;
+            if ((tag & 3u) == 0u) {                                  // literal
+                uint64_t len = tag >> 2;
+                if (len >= 60) {
+                    const uint32_t nb = (uint32_t)len - 59;
+                    if (ip + nb > bend) { bad = true; break; }
+                    len = 0;
+                    for (uint32_t k = 0; k < nb; k++) len |= (uint64_t)in_byte(ip + k) << (8 * k);
+                    ip += nb;
+                }
+                len += 1;
+                if (ip + len > bend || op + len > block_out_end) { bad = true; break; }
+                for (uint64_t i = lane; i < len; i += 64) {          // straight from the compressed stream
+                    const uint8_t v = buffer[ip + i];
+                    dst[op + i] = v;
+                    s_ring[(op + i) & (kSnapRing - 1)] = v;
+                }
+                ip += len;
+                op += len;
+                continue;
+            }
+            uint32_t len;
+            uint64_t off;
+            if ((tag & 3u) == 1u) {
+                if (ip + 1 > bend) { bad = true; break; }
+                len = 4 + ((tag >> 2) & 7u);
+                off = ((uint64_t)(tag >> 5) << 8) | in_byte(ip);
+                ip += 1;
+            } else if ((tag & 3u) == 2u) {
+                if (ip + 2 > bend) { bad = true; break; }
+                len = 1 + (tag >> 2);
+                off = (uint64_t)in_byte(ip) | ((uint64_t)in_byte(ip + 1) << 8);
+                ip += 2;
+            } else {
+                if (ip + 4 > bend) { bad = true; break; }
+                len = 1 + (tag >> 2);
+                off = (uint64_t)in_byte(ip) | ((uint64_t)in_byte(ip + 1) << 8) | ((uint64_t)in_byte(ip + 2) << 16) |
+                      ((uint64_t)in_byte(ip + 3) << 24);
+                ip += 4;
+            }
+            if (off == 0 || off > op || op + len > block_out_end) { bad = true; break; }
+            // len <= 64: one step.  Source index repeats with period `off` when the copy overlaps itself.
+            uint8_t v = 0;
+            if (off <= kSnapRing) {
+                if (lane < len) v = s_ring[(op - off + (off < len ? lane % (uint32_t)off : lane)) & (kSnapRing - 1)];
+            } else {
+                __threadfence_block();                               // this wave's earlier output stores have reached L2
+                if (lane < len)                                      // off > ring >= len: no overlap; read past L1
+                    v = __hip_atomic_load(dst + (op - off + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < len) {                                        // (all reads above precede these writes)
+                dst[op + lane] = v;
+                s_ring[(op + lane) & (kSnapRing - 1)] = v;
+            }
+            op += len;
+        }
+        if (bad || op != block_out_end) { bad = true; break; }
+        pos = bend;
+    }
+    if ((bad || op != cap) && lane == 0) descs[b].status = KTA_KB_BAD_FRAMING;
+}
+
 // ---- CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) on the device -------------------------
 // One wave per batch.  The bytes [start, end) are cut on the absolute 64-byte grid; per 4 KiB window
 // every lane reduces its 64-byte chunk with slicing-by-4 tables held in LDS (raw register update, no
@@ -697,8 +832,12 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         return KTA_ERR_CAPACITY;
     }
     if (any_snappy) {   // inflate compressed batches into their slices of the same buffer
-        hipLaunchKernelGGL(kafka_snappy_inflate, dim3(grid), dim3(kLanesPerBlock), 0, s,
-                           const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
+        if (g_decode_variant == 0)
+            hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s,
+                               const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
+        else
+            hipLaunchKernelGGL(kafka_snappy_inflate, dim3(grid), dim3(kLanesPerBlock), 0, s,
+                               const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
         KK(ctx, hipGetLastError());
     }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
@@ -918,10 +1057,69 @@ void put_be(uint8_t *p, uint64_t v, int n)
 
 } // namespace
 
+namespace {
+
+// greedy Snappy compressor (bare block) for benchmark / fixture data: 4-byte hash matcher
+void snappy_compress(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    out.clear();
+    uint64_t n = in.size(), v = n;
+    while (v >= 0x80) { out.push_back((uint8_t)(v | 0x80)); v >>= 7; }
+    out.push_back((uint8_t)v);
+    std::vector<uint32_t> table(1u << 14, 0xFFFFFFFFu);
+    auto emit_literal = [&](uint64_t from, uint64_t to) {
+        while (from < to) {
+            const uint64_t l = to - from < 65536 ? to - from : 65536;
+            if (l <= 60) out.push_back((uint8_t)((l - 1) << 2));
+            else if (l <= 256) { out.push_back(60 << 2); out.push_back((uint8_t)(l - 1)); }
+            else { out.push_back(61 << 2); out.push_back((uint8_t)((l - 1) & 0xFF)); out.push_back((uint8_t)((l - 1) >> 8)); }
+            out.insert(out.end(), in.begin() + from, in.begin() + from + l);
+            from += l;
+        }
+    };
+    uint64_t i = 0, lit = 0;
+    while (i + 4 <= n) {
+        uint32_t w;
+        memcpy(&w, &in[i], 4);
+        const uint32_t h = (w * 0x1e35a7bdu) >> 18;
+        const uint32_t cand = table[h];
+        table[h] = (uint32_t)i;
+        if (cand != 0xFFFFFFFFu && i - cand < 65536 && memcmp(&in[cand], &in[i], 4) == 0) {
+            uint64_t m = 4;
+            while (i + m < n && in[cand + m] == in[i + m]) m++;
+            emit_literal(lit, i);
+            uint64_t left = m;
+            const uint64_t off = i - cand;
+            while (left) {   // copies of at most 64 bytes with a 2-byte offset
+                uint64_t l = left < 64 ? left : 64;
+                if (left - l > 0 && left - l < 4) l = left - 4;   // keep the remainder >= 4
+                out.push_back((uint8_t)(2 | ((l - 1) << 2)));
+                out.push_back((uint8_t)(off & 0xFF));
+                out.push_back((uint8_t)(off >> 8));
+                left -= l;
+            }
+            i += m;
+            lit = i;
+        } else {
+            i++;
+        }
+    }
+    emit_literal(lit, n);
+}
+
+} // namespace
+
 int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
                                 uint8_t *out, uint64_t cap, uint64_t *len)
 {
-    if (!spec || !len || records_per_batch == 0) return KTA_ERR_INVALID;
+    return kta_kafka_encode_synth_host_ex(spec, first, n, records_per_batch, 0, out, cap, len);
+}
+
+int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
+                                   int codec, uint8_t *out, uint64_t cap, uint64_t *len)
+{
+    if (!spec || !len || records_per_batch == 0 || (codec != 0 && codec != 2)) return KTA_ERR_INVALID;
+    std::vector<uint8_t> packed;
     uint64_t pos = 0;
     bool fits = true;
     std::vector<uint8_t> rec; // one batch's records
@@ -958,6 +1156,14 @@ int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint
                 q += klb;
             }
             memcpy(q, vh, vhn);                             // value bytes + the 0 headersCount are already zero
+            if (codec == 2 && vlb) {                        // a periodic pattern: compressible, but with real copies
+                const uint64_t seed = kta_mix64(first + b0 + j);
+                for (size_t x = 0; x < vlb; x++) q[vhn + x] = (uint8_t)(kta_mix64(seed + (x % 24)) >> 7);
+            }
+        }
+        if (codec == 2) {
+            snappy_compress(rec, packed);
+            rec.swap(packed);
         }
         const uint64_t total = KTA_KAFKA_BATCH_HEADER + rec.size();
         if (out && pos + total <= cap) {
@@ -966,7 +1172,7 @@ int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint
             put_be(h + 8, total - 12, 4);                   // batchLength
             put_be(h + 12, 0, 4);                           // partitionLeaderEpoch
             h[16] = 2;                                      // magic
-            put_be(h + 21, 0, 2);                           // attributes: CreateTime, no codec
+            put_be(h + 21, (uint64_t)codec, 2);             // attributes: CreateTime, codec
             put_be(h + 23, cnt - 1, 4);                     // lastOffsetDelta
             put_be(h + 27, (uint64_t)base_ts, 8);
             put_be(h + 35, (uint64_t)max_ts, 8);

@@ -352,6 +352,40 @@ def test_device_decodes_snappy_batches(variant):
 
 
 @pytest.mark.gpu
+def test_device_snappy_far_matches_and_long_literals():
+    """Copies that reach further back than the inflater's 16 KiB LDS history ring (global read-back
+    path), literals longer than its 4 KiB input window, and self-overlapping copies (offset < length)."""
+    import snappy_py as S
+    rng = np.random.default_rng(91)
+    chunk = bytes(rng.integers(0, 256, size=20000, dtype=np.uint8))           # incompressible: one long literal
+    far = chunk + bytes(rng.integers(0, 256, size=30000, dtype=np.uint8)) + chunk   # second copy: offsets ~50 KB
+    recs = [(0, b"far", far), (1, b"rle", b"\x07" * 5000), (2, b"pat", b"abcdefg" * 900), (3, None, chunk[:70] * 40)]
+    blob = b"".join(K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c)
+                    for i, c in enumerate(["snappy", "snappy-xerial", "snappy", None]))
+    # the far copy must really be encoded as a long-offset copy
+    comp = S.compress_block(b"".join(K.encode_record(i, r[0], r[1], r[2]) for i, r in enumerate(recs)))
+    assert len(comp) < len(far) and S.decompress_block(comp)
+    want, _ = kafka_decode(blob, 1)
+    lib = N.load()
+    for variant in (0, 1):
+        lib.kta_kafka_set_variant(variant)
+        with kta.HipMetricHandler(2, now=NOW) as h:
+            cols, st, bad = _decode_on_device(h, blob, 1, True)
+            assert bad == 0 and st.n_snappy == 3
+            for k in ("partition", "key_len", "val_len", "ts_ms"):
+                assert np.array_equal(cols[k], want[k]), k
+            # the inflated bytes themselves: every key readable through key_off, and the value region of the
+            # first record equals the original (checks the far copy byte for byte)
+            kb = cols["key_bytes"].tobytes()
+            for i, key in enumerate([b"far", b"rle", b"pat"]):
+                o = int(cols["key_off"][i])
+                assert kb[o:o + 3] == key
+            o = int(cols["key_off"][0])
+            assert far in kb[o:o + len(far) + 64]
+    lib.kta_kafka_set_variant(0)
+
+
+@pytest.mark.gpu
 def test_consume_snappy_record_sets_end_to_end():
     lib = N.load()
     rng = np.random.default_rng(44)
