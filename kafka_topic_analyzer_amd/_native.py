@@ -83,7 +83,8 @@ class KtaKafkaBatchDesc(C.Structure):
 
 class KtaKafkaIndexStats(C.Structure):
     _fields_ = [("n_batches", C.c_uint64), ("n_records", C.c_uint64), ("n_control_batches", C.c_uint64),
-                ("n_compressed", C.c_uint64), ("n_snappy", C.c_uint64), ("inflate_bytes", C.c_uint64),
+                ("n_compressed", C.c_uint64), ("n_snappy", C.c_uint64), ("n_lz4", C.c_uint64),
+                ("inflate_bytes", C.c_uint64),
                 ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
                 ("bytes_consumed", C.c_uint64)]
 
@@ -132,6 +133,7 @@ SIGNATURES = {
     "kta_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(KtaSynthSpec), C.POINTER(C.c_uint64)]),
     "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_lz4_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_snappy_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,
                                           C.c_uint64, C.POINTER(KtaBatch), C.POINTER(C.c_uint64),

@@ -11,6 +11,7 @@
 #include "../../include/kta_kafka.h"
 #include "../../include/kta_synth.h"
 #include "kta_snappy.h"
+#include "kta_lz4.h"
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -312,17 +313,23 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
 // (kta_snappy.h; the same function is compiled for the host and checked there against the oracle.)
 // The inflated records land in the batch's slice of the inflate area, which is part of the same
 // device buffer as the raw blob, so key offsets stay valid for the zero-copy alive-key pass.
-__global__ __launch_bounds__(kLanesPerBlock) void kafka_snappy_inflate(uint8_t *buffer, kta_kafka_batch_desc *descs,
-                                                                        uint64_t n_batches)
+__global__ __launch_bounds__(kLanesPerBlock) void kafka_inflate_lane(uint8_t *buffer, kta_kafka_batch_desc *descs,
+                                                                      uint64_t n_batches)
 {
     const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
-    if (!(d.flags & KTA_KB_SNAPPY) || d.status) return;
-    const int64_t got = kta::snappy_inflate(buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER,
-                                            (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, buffer + d.payload_off,
-                                            d.payload_end - d.payload_off);
-    if (got < 0 || (uint64_t)got != d.payload_end - d.payload_off) descs[b].status = KTA_KB_BAD_FRAMING;
+    if (!(d.flags & (KTA_KB_SNAPPY | KTA_KB_LZ4)) || d.status) return;
+    const uint8_t *src = buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    const uint64_t n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, cap = d.payload_end - d.payload_off;
+    if (d.flags & KTA_KB_SNAPPY) {
+        const int64_t got = kta::snappy_inflate(src, n, buffer + d.payload_off, cap);
+        if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;
+    } else {
+        const int64_t got = kta::lz4_inflate(src, n, buffer + d.payload_off, cap);   // cap is only a bound
+        if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
+        else descs[b].payload_end = d.payload_off + (uint64_t)got;
+    }
 }
 
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
@@ -458,6 +465,139 @@ __global__ __launch_bounds__(64) void kafka_snappy_inflate_coop(uint8_t *buffer,
         pos = bend;
     }
     if ((bad || op != cap) && lane == 0) descs[b].status = KTA_KB_BAD_FRAMING;
+}
+
+// ---- LZ4 inflate, wave-cooperative (same scheme as the Snappy kernel; grammar of kta_lz4.h) ---------
+__global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs,
+                                                              uint64_t n_batches)
+{
+    __shared__ uint4 s_in[kSnapWin / 16];
+    __shared__ uint8_t s_ring[kSnapRing];
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s_in);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_LZ4) || d.status) return;
+    const uint64_t src0 = d.byte_off + KTA_KAFKA_BATCH_HEADER, src_end = d.byte_off + d.batch_bytes;
+    uint8_t *dst = buffer + d.payload_off;
+    const uint64_t cap = d.payload_end - d.payload_off;               // a bound: blocks x block maximum size
+    const uint4 *blocks = reinterpret_cast<const uint4 *>(buffer);
+    uint64_t wbase = ~0ull;
+    auto fetch = [&](uint64_t at, uint32_t need) {
+        if (wbase != ~0ull && at >= wbase && at + need <= wbase + kSnapWin) return;
+        __syncthreads();
+        wbase = at & ~15ull;
+        for (uint32_t o = lane * 16; o < kSnapWin; o += 64 * 16)
+            if (wbase + o < ((src_end + 15) & ~15ull)) s_in[o >> 4] = blocks[(wbase + o) >> 4];
+        __syncthreads();
+    };
+    auto in_byte = [&](uint64_t at) -> uint32_t { return win[at - wbase]; };
+    // copy `len` bytes of earlier output, `off` back, to the current position (64 bytes per step)
+    auto copy_match = [&](uint64_t op, uint64_t off, uint64_t len) {
+        for (uint64_t i0 = 0; i0 < len; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            uint8_t v = 0;
+            // off >= 64: this step's sources were written before it; off < 64: index modulo the period
+            const uint64_t s = off >= 64 ? op - off + i : op - off + (i % off);
+            if (off <= kSnapRing) {
+                if (i < len) v = s_ring[s & (kSnapRing - 1)];
+            } else {
+                __threadfence_block();
+                if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (i < len) {
+                dst[op + i] = v;
+                s_ring[(op + i) & (kSnapRing - 1)] = v;
+            }
+        }
+    };
+
+    uint64_t op = 0;
+    bool bad = src_end - src0 < 7;
+    uint64_t pos = src0, block_max = 0;
+    bool block_checksum = false;
+    if (!bad) {
+        fetch(pos, 16);
+        bad = !(in_byte(pos) == 0x04 && in_byte(pos + 1) == 0x22 && in_byte(pos + 2) == 0x4D && in_byte(pos + 3) == 0x18);
+        const uint32_t flg = in_byte(pos + 4), bd = in_byte(pos + 5), bs = (bd >> 4) & 7u;
+        bad = bad || (flg >> 6) != 1u || bs < 4;
+        block_max = 1ull << (8 + 2 * bs);
+        block_checksum = (flg & 0x10u) != 0;
+        pos += 6 + ((flg & 0x08u) ? 8 : 0) + ((flg & 0x01u) ? 4 : 0) + 1;
+    }
+    while (!bad) {                                                    // one iteration per block
+        if (pos + 4 > src_end) { bad = true; break; }
+        fetch(pos, 4);
+        const uint32_t w = in_byte(pos) | (in_byte(pos + 1) << 8) | (in_byte(pos + 2) << 16) | (in_byte(pos + 3) << 24);
+        pos += 4;
+        if (w == 0) break;                                            // end mark
+        const uint64_t sz = w & 0x7FFFFFFFu, bend = pos + sz;
+        if (sz > block_max || bend > src_end) { bad = true; break; }
+        if (w & 0x80000000u) {                                        // stored block
+            if (op + sz > cap) { bad = true; break; }
+            for (uint64_t i = lane; i < sz; i += 64) {
+                const uint8_t v = buffer[pos + i];
+                dst[op + i] = v;
+                s_ring[(op + i) & (kSnapRing - 1)] = v;
+            }
+            op += sz;
+        } else {
+            uint64_t ip = pos;
+            while (ip < bend) {                                       // one iteration per sequence
+                fetch(ip, 8);
+                const uint32_t token = in_byte(ip);
+                ip++;
+                uint64_t lit = token >> 4;
+                if (lit == 15) {
+                    uint32_t byte;
+                    do {
+                        if (ip >= bend) { bad = true; break; }
+                        fetch(ip, 1);
+                        byte = in_byte(ip);
+                        ip++;
+                        lit += byte;
+                    } while (byte == 255);
+                    if (bad) break;
+                }
+                if (ip + lit > bend || op + lit > cap) { bad = true; break; }
+                for (uint64_t i = lane; i < lit; i += 64) {           // literals straight from the compressed stream
+                    const uint8_t v = buffer[ip + i];
+                    dst[op + i] = v;
+                    s_ring[(op + i) & (kSnapRing - 1)] = v;
+                }
+                ip += lit;
+                op += lit;
+                if (ip == bend) break;                                // the last sequence has no match
+                if (ip + 2 > bend) { bad = true; break; }
+                fetch(ip, 8);
+                const uint64_t off = (uint64_t)in_byte(ip) | ((uint64_t)in_byte(ip + 1) << 8);
+                ip += 2;
+                uint64_t ml = token & 15u;
+                if (ml == 15) {
+                    uint32_t byte;
+                    do {
+                        if (ip >= bend) { bad = true; break; }
+                        fetch(ip, 1);
+                        byte = in_byte(ip);
+                        ip++;
+                        ml += byte;
+                    } while (byte == 255);
+                    if (bad) break;
+                }
+                ml += 4;
+                if (off == 0 || off > op || op + ml > cap) { bad = true; break; }
+                copy_match(op, off, ml);
+                op += ml;
+            }
+            if (bad) break;
+        }
+        pos = bend + (block_checksum ? 4 : 0);
+    }
+    if (lane == 0) {
+        if (bad) descs[b].status = KTA_KB_BAD_FRAMING;
+        else descs[b].payload_end = d.payload_off + op;               // the slice was sized by a bound
+    }
 }
 
 // ---- CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) on the device -------------------------
@@ -704,8 +844,9 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                 // a copy element expands at most 3 bytes into 64: anything beyond ~22x is a corrupt preamble
                 if (inflated > (int64_t)(clen * 22 + 64)) inflated = -1;
             }
+            if (codec == 3) inflated = kta::lz4_inflate_bound(bytes + pos + KTA_KAFKA_BATCH_HEADER, total - KTA_KAFKA_BATCH_HEADER);
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
-            else if (codec != 0 && codec != 2) stats->n_compressed++;     // gzip / lz4 / zstd: not decoded here
+            else if (codec != 0 && codec != 2 && codec != 3) stats->n_compressed++;   // gzip / zstd: not decoded here
             else if (count > 0) {
                 if (nb < cap) {
                     kta_kafka_batch_desc &d = descs[nb];
@@ -720,8 +861,8 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     d.partition = partition;
                     d.n_records = count;
                     d.flags = ((attrs & 0x08) ? KTA_KB_LOG_APPEND_TIME : 0u) | ((attrs & 0x10) ? KTA_KB_TRANSACTIONAL : 0u);
-                    if (codec == 2) {
-                        d.flags |= KTA_KB_SNAPPY;
+                    if (codec == 2 || codec == 3) {
+                        d.flags |= codec == 2 ? KTA_KB_SNAPPY : KTA_KB_LZ4;
                         if (inflated < 0) {          // malformed stream: nothing to parse, reported as bad
                             d.status = KTA_KB_BAD_FRAMING;
                             inflated = 0;
@@ -733,8 +874,9 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                         d.payload_end = d.byte_off + total;
                     }
                 }
-                if (codec == 2) {
-                    stats->n_snappy++;
+                if (codec == 2 || codec == 3) {
+                    if (codec == 2) stats->n_snappy++;
+                    else stats->n_lz4++;
                     inflate += ((uint64_t)(inflated > 0 ? inflated : 0) + 63) & ~63ull;   // 64-byte aligned slices
                 }
                 nb++;
@@ -749,6 +891,12 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
     stats->trailing_bytes = len - pos;
     stats->inflate_bytes = inflate;
     return nb > cap ? KTA_ERR_CAPACITY : KTA_OK;
+}
+
+int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
+    return kta::lz4_inflate(src, n, dst, cap);
 }
 
 int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
@@ -820,24 +968,30 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipGetLastError());
         if (timing) KK(ctx, hipEventRecord(b, s));
     }
-    bool any_snappy = false;
+    bool any_snappy = false, any_lz4 = false;
     uint64_t buffer_end = blob_len;
     for (uint64_t i = 0; i < n_batches; i++)
-        if (descs_host[i].flags & KTA_KB_SNAPPY) {
-            any_snappy = true;
+        if (descs_host[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4)) {
+            any_snappy = any_snappy || (descs_host[i].flags & KTA_KB_SNAPPY);
+            any_lz4 = any_lz4 || (descs_host[i].flags & KTA_KB_LZ4);
             if (descs_host[i].payload_end > buffer_end) buffer_end = descs_host[i].payload_end;
         }
     if (want_keys && buffer_end >= (1ull << 32)) {
         kta_internal_set_error(ctx, "blob + inflate area must be < 4 GiB when key offsets are wanted (key_off is u32)");
         return KTA_ERR_CAPACITY;
     }
-    if (any_snappy) {   // inflate compressed batches into their slices of the same buffer
-        if (g_decode_variant == 0)
-            hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s,
-                               const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
-        else
-            hipLaunchKernelGGL(kafka_snappy_inflate, dim3(grid), dim3(kLanesPerBlock), 0, s,
-                               const_cast<uint8_t *>(blob_device), st->d_descs, n_batches);
+    if (any_snappy || any_lz4) {   // inflate compressed batches into their slices of the same buffer
+        uint8_t *buf = const_cast<uint8_t *>(blob_device);
+        if (g_decode_variant == 0) {
+            if (any_snappy)
+                hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
+                                   n_batches);
+            if (any_lz4)
+                hipLaunchKernelGGL(kafka_lz4_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
+                                   n_batches);
+        } else {
+            hipLaunchKernelGGL(kafka_inflate_lane, dim3(grid), dim3(kLanesPerBlock), 0, s, buf, st->d_descs, n_batches);
+        }
         KK(ctx, hipGetLastError());
     }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
@@ -999,6 +1153,7 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         stats->n_control_batches += one.n_control_batches;
         stats->n_compressed += one.n_compressed;
         stats->n_snappy += one.n_snappy;
+        stats->n_lz4 += one.n_lz4;
         stats->inflate_bytes += one.inflate_bytes;
         stats->n_old_magic += one.n_old_magic;
         stats->bytes_consumed += one.bytes_consumed;
@@ -1107,6 +1262,59 @@ void snappy_compress(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
     emit_literal(lit, n);
 }
 
+// greedy LZ4 compressor: one frame (version 1, linked blocks of at most 64 KiB, no checksums, header
+// checksum byte left 0 — decoders that verify it are not the target of benchmark data)
+void lz4_compress_frame(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    out.clear();
+    const uint8_t hdr[7] = {0x04, 0x22, 0x4D, 0x18, 0x40, 0x40, 0x00};
+    out.insert(out.end(), hdr, hdr + 7);
+    auto put_len = [&](uint64_t v) {
+        while (v >= 255) { out.push_back(255); v -= 255; }
+        out.push_back((uint8_t)v);
+    };
+    std::vector<uint32_t> table(1u << 14);
+    const uint64_t n = in.size();
+    for (uint64_t b0 = 0; b0 < n; b0 += 65536) {
+        const uint64_t bend = b0 + 65536 < n ? b0 + 65536 : n;
+        const size_t size_at = out.size();
+        out.insert(out.end(), 4, 0);
+        std::fill(table.begin(), table.end(), 0xFFFFFFFFu);
+        uint64_t i = b0, lit = b0;
+        const uint64_t limit = bend > 12 + b0 ? bend - 12 : b0;
+        while (i < limit) {
+            uint32_t w;
+            memcpy(&w, &in[i], 4);
+            const uint32_t h = (w * 2654435761u) >> 18;
+            const uint32_t cand = table[h];
+            table[h] = (uint32_t)i;
+            if (cand != 0xFFFFFFFFu && i - cand <= 65535 && memcmp(&in[cand], &in[i], 4) == 0) {
+                uint64_t m = 4;
+                while (i + m < bend - 5 && in[cand + m] == in[i + m]) m++;
+                const uint64_t ll = i - lit;
+                out.push_back((uint8_t)(((ll < 15 ? ll : 15) << 4) | (m - 4 < 15 ? m - 4 : 15)));
+                if (ll >= 15) put_len(ll - 15);
+                out.insert(out.end(), in.begin() + lit, in.begin() + i);
+                out.push_back((uint8_t)((i - cand) & 0xFF));
+                out.push_back((uint8_t)((i - cand) >> 8));
+                if (m - 4 >= 15) put_len(m - 4 - 15);
+                i += m;
+                lit = i;
+            } else {
+                i++;
+            }
+        }
+        const uint64_t ll = bend - lit;
+        out.push_back((uint8_t)((ll < 15 ? ll : 15) << 4));
+        if (ll >= 15) put_len(ll - 15);
+        out.insert(out.end(), in.begin() + lit, in.begin() + bend);
+        const uint32_t sz = (uint32_t)(out.size() - size_at - 4);
+        out[size_at] = (uint8_t)sz; out[size_at + 1] = (uint8_t)(sz >> 8);
+        out[size_at + 2] = (uint8_t)(sz >> 16); out[size_at + 3] = (uint8_t)(sz >> 24);
+    }
+    out.insert(out.end(), 4, 0); // end mark
+}
+
 } // namespace
 
 int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
@@ -1118,7 +1326,7 @@ int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t first, uint
 int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
                                    int codec, uint8_t *out, uint64_t cap, uint64_t *len)
 {
-    if (!spec || !len || records_per_batch == 0 || (codec != 0 && codec != 2)) return KTA_ERR_INVALID;
+    if (!spec || !len || records_per_batch == 0 || (codec != 0 && codec != 2 && codec != 3)) return KTA_ERR_INVALID;
     std::vector<uint8_t> packed;
     uint64_t pos = 0;
     bool fits = true;
@@ -1156,13 +1364,14 @@ int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64_t first, u
                 q += klb;
             }
             memcpy(q, vh, vhn);                             // value bytes + the 0 headersCount are already zero
-            if (codec == 2 && vlb) {                        // a periodic pattern: compressible, but with real copies
+            if (codec != 0 && vlb) {                        // a periodic pattern: compressible, but with real copies
                 const uint64_t seed = kta_mix64(first + b0 + j);
                 for (size_t x = 0; x < vlb; x++) q[vhn + x] = (uint8_t)(kta_mix64(seed + (x % 24)) >> 7);
             }
         }
-        if (codec == 2) {
-            snappy_compress(rec, packed);
+        if (codec != 0) {
+            if (codec == 2) snappy_compress(rec, packed);
+            else lz4_compress_frame(rec, packed);
             rec.swap(packed);
         }
         const uint64_t total = KTA_KAFKA_BATCH_HEADER + rec.size();

@@ -16,6 +16,7 @@
 #include <string.h>
 
 int64_t kto_snappy_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
+int64_t kto_lz4_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
 
 typedef struct {
     uint64_t control_batches, compressed_batches, old_magic_batches, trailing_bytes, bad_batches, batches;
@@ -61,7 +62,7 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (b[16] != 2) { st->old_magic_batches++; pos += total; continue; }
         uint16_t attrs = (uint16_t)rd_be(b + 21, 2);
         if (attrs & 0x20) { st->control_batches++; pos += total; continue; }
-        if ((attrs & 0x07) != 0 && (attrs & 0x07) != 2) { st->compressed_batches++; pos += total; continue; }
+        if ((attrs & 0x07) != 0 && (attrs & 0x07) != 2 && (attrs & 0x07) != 3) { st->compressed_batches++; pos += total; continue; }
         int64_t base_offset = (int64_t)rd_be(b, 8);
         int64_t base_ts = (int64_t)rd_be(b + 27, 8), max_ts = (int64_t)rd_be(b + 35, 8);
         int32_t count = (int32_t)rd_be(b + 57, 4);
@@ -70,10 +71,11 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         const uint8_t *p = b + 61;
         int bad = 0;
         uint8_t *inflated = NULL;
-        if ((attrs & 0x07) == 2) { /* Snappy: the records section is compressed as a whole */
-            uint64_t cap = (total - 61) * 64 + 65536;
+        if ((attrs & 0x07) == 2 || (attrs & 0x07) == 3) { /* Snappy / LZ4: the records section is compressed as a whole */
+            uint64_t cap = (total - 61) * 300 + (1u << 22);
             inflated = (uint8_t *)malloc((size_t)cap);
-            int64_t got = kto_snappy_inflate(b + 61, total - 61, inflated, cap);
+            int64_t got = (attrs & 0x07) == 2 ? kto_snappy_inflate(b + 61, total - 61, inflated, cap)
+                                              : kto_lz4_inflate(b + 61, total - 61, inflated, cap);
             if (got < 0) { bad = 1; got = 0; }
             p = inflated;
             bend = inflated + got;
@@ -222,4 +224,57 @@ int64_t kto_snappy_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_
         return i == n ? (int64_t)o : -1;
     }
     return kto_snappy_block(src, n, out, cap);
+}
+
+/* ---- LZ4 (Kafka codec 3, LZ4 frame format): independent sequential inflater ------------------------
+ * Restates lz4_Frame_format.md and lz4_Block_format.md (lz4 v1.9 doc/).  Checksums are skipped.
+ * Written against the format text, not against the product's kta_lz4.h. */
+int64_t kto_lz4_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    if (n < 7 || src[0] != 0x04 || src[1] != 0x22 || src[2] != 0x4d || src[3] != 0x18) return -1;
+    uint8_t flg = src[4], bd = src[5];
+    if ((flg & 0xc0) != 0x40) return -1;
+    int bsid = (bd >> 4) & 7;
+    if (bsid < 4) return -1;
+    uint64_t bmax = (uint64_t)1 << (8 + 2 * bsid);
+    uint64_t i = 6;
+    if (flg & 0x08) i += 8; /* content size */
+    if (flg & 0x01) i += 4; /* dictionary id */
+    i += 1;                 /* header checksum */
+    uint64_t o = 0;
+    for (;;) {
+        if (i + 4 > n) return -1;
+        uint32_t w = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+        i += 4;
+        if (w == 0) break; /* end mark */
+        uint64_t sz = w & 0x7fffffffu;
+        if (sz > bmax || i + sz > n) return -1;
+        if (w & 0x80000000u) {
+            if (o + sz > cap) return -1;
+            memcpy(out + o, src + i, (size_t)sz);
+            o += sz;
+        } else {
+            const uint8_t *q = src + i, *qe = q + sz;
+            while (q < qe) {
+                uint8_t tok = *q++;
+                uint64_t ll = tok >> 4;
+                if (ll == 15) { uint8_t b; do { if (q >= qe) return -1; b = *q++; ll += b; } while (b == 255); }
+                if ((uint64_t)(qe - q) < ll || o + ll > cap) return -1;
+                memcpy(out + o, q, (size_t)ll);
+                q += ll; o += ll;
+                if (q == qe) break;
+                if (qe - q < 2) return -1;
+                uint64_t off = (uint64_t)q[0] | ((uint64_t)q[1] << 8);
+                q += 2;
+                uint64_t ml = tok & 15;
+                if (ml == 15) { uint8_t b; do { if (q >= qe) return -1; b = *q++; ml += b; } while (b == 255); }
+                ml += 4;
+                if (off == 0 || off > o || o + ml > cap) return -1;
+                while (ml--) { out[o] = out[o - off]; o++; }
+            }
+        }
+        i += sz;
+        if (flg & 0x10) i += 4; /* block checksum */
+    }
+    return (int64_t)o;
 }

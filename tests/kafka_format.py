@@ -58,14 +58,21 @@ def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, produ
                  raw_records=None, count=None, compression=None):
     """records: [(ts_delta, key|None, value|None, headers)]; returns the batch bytes.
     raw_records/count let tests build corrupt or compressed-looking batches.
-    compression: None, "snappy" (one bare block, as librdkafka writes) or "snappy-xerial" (snappy-java
-    stream framing, as the Java clients write): the records section is compressed and codec 2 is set."""
+    compression: None, "snappy" (one bare block, as librdkafka writes), "snappy-xerial" (snappy-java
+    stream framing, as the Java clients write) -> codec 2; "lz4" (LZ4 frame, linked 64 KiB blocks, as
+    librdkafka's LZ4F defaults) or "lz4-indep" (independent blocks + block checksums + content size,
+    as the Java client's KafkaLZ4BlockOutputStream can) -> codec 3.  The records section is compressed."""
     recs = b"".join(encode_record(i, r[0], r[1], r[2], r[3] if len(r) > 3 else ()) for i, r in enumerate(records)) \
         if raw_records is None else raw_records
-    if compression:
+    if compression in ("snappy", "snappy-xerial"):
         import snappy_py
         recs = snappy_py.compress_block(recs) if compression == "snappy" else snappy_py.compress_xerial(recs, 4096)
         attributes = (attributes & ~0x07) | 2
+    elif compression in ("lz4", "lz4-indep"):
+        import lz4_py
+        recs = lz4_py.compress_frame(recs) if compression == "lz4" else \
+            lz4_py.compress_frame(recs, linked=False, content_size=True, block_checksum=True, content_checksum=True)
+        attributes = (attributes & ~0x07) | 3
     n = len(records) if count is None else count
     if max_ts is None:
         max_ts = max([base_ts + r[0] for r in records], default=base_ts)
@@ -79,7 +86,7 @@ def expected_columns(partition, batches):
     """batches: [(base_ts, attributes, max_ts, records)] -> the columns a consumer would deliver."""
     part, klen, vlen, ts, keys = [], [], [], [], []
     for base_ts, attributes, max_ts, records in batches:
-        if attributes & 0x20 or (attributes & 0x07) not in (0, 2):   # control, or a codec that is not decoded
+        if attributes & 0x20 or (attributes & 0x07) not in (0, 2, 3):   # control, or a codec that is not decoded
             continue
         for r in records:
             part.append(partition)

@@ -298,38 +298,71 @@ def test_snappy_inflate_host_matches_oracle_and_python():
     assert L.kto_snappy_inflate(bad_off, len(bad_off), out, 1024) == -1
 
 
-def test_host_index_sizes_snappy_batches():
+def test_host_index_sizes_compressed_batches():
     rng = np.random.default_rng(21)
-    blob, expected, info = random_record_set(rng, 40, snappy=True)
+    blob, expected, info = random_record_set(rng, 60, snappy=True)
     rc, descs, st = index_host(blob, 3)
-    assert rc == N.KTA_OK and st.n_snappy == info["snappy"] > 0
+    assert rc == N.KTA_OK and st.n_snappy == info["snappy"] > 0 and st.n_lz4 == info["lz4"] > 0
     cols, ost = kafka_decode(blob, 3)
     assert_columns(cols, expected)
     inflate_at = (len(blob) + 127) & ~63
     run = 0
     for i in range(st.n_batches):
         d = descs[i]
-        if d.flags & 4:  # KTA_KB_SNAPPY: a 64-byte aligned slice of the inflate area
+        if d.flags & (4 | 8):  # KTA_KB_SNAPPY / KTA_KB_LZ4: a 64-byte aligned slice of the inflate area
             assert d.payload_off == inflate_at + run and d.payload_off % 64 == 0
+            if d.flags & 8:    # LZ4 frames do not carry their size: the slice is a bound (blocks x 64 KiB)
+                assert (d.payload_end - d.payload_off) % 65536 == 0 and d.payload_end > d.payload_off
             run += (d.payload_end - d.payload_off + 63) & ~63
         else:
             assert (d.payload_off, d.payload_end) == (d.byte_off + 61, d.byte_off + d.batch_bytes)
     assert run == st.inflate_bytes
 
 
+def test_lz4_inflate_host_matches_oracle_and_python():
+    import ctypes as C2
+    import lz4_py as Z
+    from oracle_c import lib as olib
+    L = olib()
+    L.kto_lz4_inflate.restype = C2.c_int64
+    L.kto_lz4_inflate.argtypes = [C2.c_char_p, C2.c_uint64, C2.c_char_p, C2.c_uint64]
+    lib = N.load()
+    rng = np.random.default_rng(4)
+    cases = [b"", b"a", b"abcd" * 1000, bytes(rng.integers(0, 256, size=5000, dtype=np.uint8)), b"\0" * 200000,
+             bytes(rng.integers(0, 4, size=150000, dtype=np.uint8)),
+             b"".join(b"key-%d value-%d;" % (i % 97, i) for i in range(9000))]
+    for d in cases:
+        for kw in ({}, {"linked": False}, {"content_size": True, "block_checksum": True, "content_checksum": True},
+                   {"block_size_id": 5}):
+            comp = Z.compress_frame(d, **kw)
+            assert Z.decompress_frame(comp) == d
+            out1, out2 = C2.create_string_buffer(len(d) + 1), C2.create_string_buffer(len(d) + 1)
+            assert lib.kta_lz4_inflate_host(comp, len(comp), out1, len(d)) == len(d)
+            assert L.kto_lz4_inflate(comp, len(comp), out2, len(d)) == len(d)
+            assert out1.raw[:len(d)] == d == out2.raw[:len(d)]
+    good = Z.compress_frame(b"abcdefgh" * 500)
+    out = C2.create_string_buffer(8192)
+    assert lib.kta_lz4_inflate_host(good[:-6], len(good) - 6, out, 8192) == -1      # truncated: no end mark
+    assert lib.kta_lz4_inflate_host(good, len(good), out, 100) == -1                # output buffer too small
+    assert lib.kta_lz4_inflate_host(b"\x04\x22\x4d\x19" + good[4:], len(good), out, 8192) == -1   # bad magic
+    bad_off = good[:7] + bytes([5, 0, 0, 0]) + bytes([0x10, ord("a"), 9, 0, 0]) + bytes(4)  # match offset 9 > 1 byte produced
+    assert lib.kta_lz4_inflate_host(bad_off, len(bad_off), out, 8192) == -1
+    assert L.kto_lz4_inflate(bad_off, len(bad_off), out, 8192) == -1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1])
 def test_device_decodes_snappy_batches(variant):
     rng = np.random.default_rng(33)
-    blob, expected, info = random_record_set(rng, 120, max_records=120, snappy=True)
-    assert info["snappy"] > 20
+    blob, expected, info = random_record_set(rng, 160, max_records=120, snappy=True)
+    assert info["snappy"] > 20 and info["lz4"] > 20
     want, _ = kafka_decode(blob, 3)
     lib = N.load()
     lib.kta_kafka_set_variant(variant)
     with kta.HipMetricHandler(8, now=NOW) as h:
         h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))   # the CRC covers the compressed bytes
         cols, st, bad = _decode_on_device(h, blob, 3, True)
-        assert bad == 0 and st.n_snappy == info["snappy"]
+        assert bad == 0 and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"]
         assert_columns(cols, expected, key_check=True)
         for k in ("partition", "key_len", "val_len", "ts_ms"):
             assert np.array_equal(cols[k], want[k]), k
@@ -338,7 +371,7 @@ def test_device_decodes_snappy_batches(variant):
         h._check(lib.kta_kafka_set_check_crcs(h._ctx, 0))
         first = _batches_of(blob)
         rc, descs, _st = index_host(blob, 3)
-        victim = next(i for i in range(_st.n_batches) if descs[i].flags & 4)
+        victim = next(i for i in range(_st.n_batches) if descs[i].flags & 4)   # a Snappy batch
         p = descs[victim].byte_off
         broken = bytearray(blob)
         broken[p + 61] = 0xFF
@@ -348,11 +381,21 @@ def test_device_decodes_snappy_batches(variant):
         broken[p + 65] = 0x7F                       # preamble claims a 34 GB block
         cols2, st2, bad2 = _decode_on_device(h, bytes(broken), 3, True)
         assert bad2 >= 1 and (cols2["partition"] == -1).sum() == descs[victim].n_records
+        # same for an LZ4 batch: a match offset pointing before the start of the output
+        victim = next(i for i in range(_st.n_batches) if descs[i].flags & 8)
+        p = descs[victim].byte_off + 61
+        broken = bytearray(blob)
+        first_block = p + 7 + (8 if blob[p + 4] & 8 else 0)
+        broken[first_block + 4] = 0x0F                 # token: no literals, match length 15+4
+        broken[first_block + 5] = 0x10                 # offset 16 with nothing produced yet
+        broken[first_block + 6] = 0x00
+        cols3, st3, bad3 = _decode_on_device(h, bytes(broken), 3, True)
+        assert bad3 >= 1 and (cols3["partition"] == -1).sum() == descs[victim].n_records
     lib.kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
-def test_device_snappy_far_matches_and_long_literals():
+def test_device_inflate_far_matches_and_long_literals():
     """Copies that reach further back than the inflater's 16 KiB LDS history ring (global read-back
     path), literals longer than its 4 KiB input window, and self-overlapping copies (offset < length)."""
     import snappy_py as S
@@ -361,7 +404,7 @@ def test_device_snappy_far_matches_and_long_literals():
     far = chunk + bytes(rng.integers(0, 256, size=30000, dtype=np.uint8)) + chunk   # second copy: offsets ~50 KB
     recs = [(0, b"far", far), (1, b"rle", b"\x07" * 5000), (2, b"pat", b"abcdefg" * 900), (3, None, chunk[:70] * 40)]
     blob = b"".join(K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c)
-                    for i, c in enumerate(["snappy", "snappy-xerial", "snappy", None]))
+                    for i, c in enumerate(["snappy", "snappy-xerial", "lz4", "lz4-indep", None]))
     # the far copy must really be encoded as a long-offset copy
     comp = S.compress_block(b"".join(K.encode_record(i, r[0], r[1], r[2]) for i, r in enumerate(recs)))
     assert len(comp) < len(far) and S.decompress_block(comp)
@@ -371,7 +414,7 @@ def test_device_snappy_far_matches_and_long_literals():
         lib.kta_kafka_set_variant(variant)
         with kta.HipMetricHandler(2, now=NOW) as h:
             cols, st, bad = _decode_on_device(h, blob, 1, True)
-            assert bad == 0 and st.n_snappy == 3
+            assert bad == 0 and st.n_snappy == 2 and st.n_lz4 == 2
             for k in ("partition", "key_len", "val_len", "ts_ms"):
                 assert np.array_equal(cols[k], want[k]), k
             # the inflated bytes themselves: every key readable through key_off, and the value region of the
@@ -398,7 +441,7 @@ def test_consume_snappy_record_sets_end_to_end():
             st = N.KtaKafkaIndexStats()
             h._check(lib.kta_kafka_consume(h._ctx, blob, len(blob), part, C.byref(st)))
             cols, _ = kafka_decode(blob, part)
-            assert st.n_records == len(cols["partition"]) and st.n_snappy == info["snappy"]
+            assert st.n_records == len(cols["partition"]) and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"]
             o.run_soa({k: v for k, v in cols.items() if k != "offset"})
         res, c = h.finish()
         assert np.array_equal(c, o.counters(P))
