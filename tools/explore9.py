@@ -9,11 +9,12 @@ lib = N.load()
 n = 900_000  # ~240 MB of raw log per blob
 sp, _ = kta.synth_preset("c4")
 ln = C.c_uint64()
-lib.kta_kafka_encode_synth_host(C.byref(sp), 0, n, 60, None, 0, C.byref(ln))
+codec = int(os.environ.get("CODEC", "0"))
+lib.kta_kafka_encode_synth_host_ex(C.byref(sp), 0, n, 60, codec, None, 0, C.byref(ln))
 buf = np.zeros(ln.value + 64, np.uint8)
-lib.kta_kafka_encode_synth_host(C.byref(sp), 0, n, 60, buf.ctypes.data, ln.value, C.byref(ln))
+lib.kta_kafka_encode_synth_host_ex(C.byref(sp), 0, n, 60, codec, buf.ctypes.data, ln.value, C.byref(ln))
 for alive in (False, True):
-    for stages in (2, 3):
+    for stages in (3,):
         h = kta.HipMetricHandler(256, count_alive_keys=alive)
         h._check(lib.kta_kafka_configure(h._ctx, ln.value + 4096, stages))
         st = N.KtaKafkaIndexStats()
@@ -33,6 +34,6 @@ for alive in (False, True):
         dt = time.perf_counter() - t0
         res, c = h.finish()
         assert res.overall_count == n * (reps + stages), (res.overall_count, n * (reps + stages))
-        print(f"raw-log pipeline alive={alive!s:5s} stages={stages}: {ln.value*reps/dt/1e9:.1f} GB/s of Kafka log end to end, "
+        print(f"codec={codec} raw-log pipeline alive={alive!s:5s} stages={stages}: {ln.value*reps/dt/1e9:.1f} GB/s of Kafka log end to end, "
               f"{n*reps/dt/1e6:.1f} M records/s  (blob {ln.value/1e6:.0f} MB, {st.n_batches} batches)", flush=True)
         h.close()
