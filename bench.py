@@ -266,6 +266,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON, rank 0): native libraries (RCCL prints a version banner
+    # on stdout when the first communicator is created) are pointed at stderr at the fd level.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch  # first: its bundled HIP runtime must be the one this process loads
     import torch.distributed as dist
     import numpy as np
@@ -306,14 +312,17 @@ def main():
     vec = torch.as_tensor(_DevVec(ptr, nwords), device=torch.device("cuda", local_rank))
     n_sum = D.sum_prefix_len(P)
 
+    if exchange:
+        # run the library on torch's stream: scan, fold and the two all-reduces are then stream-ordered and
+        # a step needs no host synchronisation at all
+        h.use_stream(torch.cuda.current_stream().cuda_stream)
+
     def step():
         """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
         h.reset()                                          # MessageMetrics::new state (tiny kernel)
-        h.submit_device(batch, n, 0, which=1)              # scan + fold on the library's stream
+        h.submit_device(batch, n, 0, which=1)              # scan + fold
         if exchange:
-            h.sync()                                       # shard result complete before the collectives
-            D.allreduce_counter_vector(vec, P)             # C1 SUM (counters) + C2 MAX (four extrema)
-            torch.cuda.current_stream().synchronize()
+            D.allreduce_counter_vector(vec, P)             # C1 SUM (counters) + C2 MAX (four extrema), same stream
 
     def barrier():
         if exchange:
@@ -339,6 +348,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if exchange:
+        h.use_stream(None)
     # sanity inside the bench: a single fresh pass must count exactly n records on this rank
     h.reset()
     h.submit_device(batch, n, 0, which=1)
@@ -381,7 +392,8 @@ def main():
         if world == 1 and not args.no_decode:
             line["kafka_decode"] = kafka_decode_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                        args.decode_records, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if exchange:
         dist.barrier()
         dist.destroy_process_group()

@@ -187,6 +187,11 @@ int kta_device_batch_free(kta_ctx *ctx, kta_batch *cols);
 int kta_copy_to_device(kta_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int kta_copy_to_host(kta_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 
+/* Run the context's kernels on a caller-owned HIP stream (e.g. the stream RCCL collectives are issued
+ * on), so that submit -> collective -> next submit needs no host synchronisation.  NULL restores the
+ * context's own compute stream.  The stream must belong to the context's device and outlive its use. */
+int kta_set_compute_stream(kta_ctx *ctx, void *hip_stream);
+
 /* ---- results --------------------------------------------------------------------- */
 /* Wait for everything submitted so far. */
 int kta_sync(kta_ctx *ctx);

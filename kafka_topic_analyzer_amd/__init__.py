@@ -221,6 +221,10 @@ class HipMetricHandler:
         return b, n
 
     # ------------------------------------------------------------------ results
+    def use_stream(self, hip_stream: Optional[int]) -> None:
+        """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None restores."""
+        self._check(self._lib.kta_set_compute_stream(self._ctx, C.c_void_p(hip_stream) if hip_stream else None))
+
     def sync(self) -> None:
         self._check(self._lib.kta_sync(self._ctx))
 

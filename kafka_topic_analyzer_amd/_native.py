@@ -107,6 +107,7 @@ SIGNATURES = {
     "kta_device_batch_free": (C.c_int, [_P, C.POINTER(KtaBatch)]),
     "kta_copy_to_device": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_size_t]),
     "kta_copy_to_host": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "kta_set_compute_stream": (C.c_int, [_P, C.c_void_p]),
     "kta_sync": (C.c_int, [_P]),
     "kta_finish": (C.c_int, [_P, C.POINTER(KtaResult), C.c_void_p]),
     "kta_result_vector": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

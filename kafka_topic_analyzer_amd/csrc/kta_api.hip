@@ -32,6 +32,7 @@ struct kta_ctx {
     bool alive = false;
     int cu_count = 256;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
+    hipStream_t s_own = nullptr;    // the context's own compute stream (s_compute may be caller-owned)
     hipEvent_t ev_copied = nullptr;
     bool analytics = false;
     uint64_t *d_avec = nullptr;     // analytics vector u64[2*34 + 4*P] (KTA_FLAG_ANALYTICS)
@@ -309,6 +310,7 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
         if (e__ != hipSuccess) return bail(hip_fail(ctx, e__, #call));    \
     } while (0)
     KTA_TRY(hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
+    ctx->s_own = ctx->s_compute;
     KTA_TRY(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
     KTA_TRY(hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming));
     const size_t vec_words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
@@ -355,7 +357,7 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
     for (auto &pool : ctx->ev_pool)
         for (auto ev : pool) (void)hipEventDestroy(ev);
-    if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
+    if (ctx->s_own) (void)hipStreamDestroy(ctx->s_own);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
     delete ctx;
 }
@@ -521,6 +523,15 @@ int kta_copy_to_host(kta_ctx *ctx, void *dst, const void *src, size_t bytes)
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
     KTA_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return KTA_OK;
+}
+
+int kta_set_compute_stream(kta_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));   // nothing of ours may still be in flight on the old stream
+    ctx->s_compute = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->s_own;
     return KTA_OK;
 }
 
