@@ -151,8 +151,10 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n);
 /* CRC-32C of host bytes (the same tables the device uses; check value of "123456789": 0xE3069283). */
 uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 
-/* Decode kernel choice (process wide): 0 = one wave per batch, cooperative through an LDS window
- * (default), 1 = one lane per batch (kept for comparison). */
+/* Decode kernel choice (process wide): 0 = automatic (default: by the number of batches in the call and
+ * their mean size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch
+ * inflate), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
+ * 5 = 8 batches per wave (1 KiB windows). */
 int kta_kafka_set_variant(int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);

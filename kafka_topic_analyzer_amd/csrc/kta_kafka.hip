@@ -31,7 +31,18 @@ hipStream_t kta_internal_copy_stream(kta_ctx *ctx);
 namespace {
 
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
-int g_decode_variant = 0;          // 0 = wave per batch (cooperative), 1 = lane per batch
+int g_decode_variant = 0;          // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..5 = wave geometries
+
+// Automatic choice (measured on MI355X, tools/explore_decode.py): sharing a wave between batches pays as
+// long as the waves still fill the chip; the smaller the batches, the smaller the windows (more waves
+// resident, fewer bytes staged for nothing).
+int decode_variant_for(uint64_t n_batches, uint64_t blob_len)
+{
+    if (g_decode_variant) return g_decode_variant;
+    if (n_batches < 2048) return 2;
+    const uint64_t mean = blob_len / n_batches;
+    return mean < 4096 ? 5 : (mean < 65536 ? 4 : 3);
+}
 
 // ---- device-side byte reader over the blob: aligned 16-byte loads, one block cached -------------
 // A record header (length, attributes, timestamp delta, offset delta, key length) is <= 26 bytes, so
@@ -138,18 +149,26 @@ __global__ __launch_bounds__(kLanesPerBlock) void kafka_decode(const uint4 *word
     if (n_keyb && kb) atomicAdd(n_keyb, (unsigned long long)kb);
 }
 
-// ---- wave-cooperative decode: one wave per batch -------------------------------------------------
+// Keeps a staged load where it was issued: without it the compiler sinks each load into the conditional
+// LDS store that consumes it and the window fill becomes load -> wait -> store, one HBM round trip each.
+__device__ __forceinline__ void pin(uint4 &v)
+{
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
+// ---- wave-cooperative decode: G batches per wave ---------------------------------------------------
 // The lane-per-batch walk above is latency bound (one dependent HBM round trip per varint) and has
-// only as many active lanes as there are batches.  Here one wave owns one batch:
-//   1. the wave streams a window of the batch into LDS with coalesced 16-byte loads;
-//   2. lane 0 chains the record length prefixes inside the window (LDS latency, ~100 cycles/record)
-//      and publishes the record starts;
-//   3. all lanes parse one record each from LDS and write the columns (consecutive indices:
+// only as many active lanes as there are batches.  Here a group of L = 64/G lanes owns one batch:
+//   1. the group streams a window of the batch into LDS with coalesced 16-byte loads (all in flight);
+//   2. the group's first lane chains the record length prefixes inside the window (LDS latency) and
+//      publishes the record starts.  This step is serial per batch and costs a full wave instruction
+//      per operation whatever the number of active lanes, so G > 1 matters: the G leaders of a wave
+//      chain their batches in the same instruction stream (G = 1 spends half of the kernel here);
+//   3. the group's lanes parse one record each from LDS and write the columns (consecutive indices:
 //      coalesced stores); keys stay where they are (key_off points into the blob);
 //   4. the next window starts at the first record that did not fit — or, after a large value, at the
 //      next record start, so value bytes beyond the window are never loaded.
-constexpr uint32_t kWinBytes = 8192;
-constexpr uint32_t kWinRecs = 256;
+// Every group runs its own rounds; the wave loops until its last group is done.
 
 // zig-zag varint at byte offset `off` of the LDS window.  Fast path (values < 2^28, i.e. <= 4 bytes —
 // every length/delta of ordinary records): two aligned dword reads, one v_alignbyte, branch-free bit
@@ -183,123 +202,186 @@ __device__ __forceinline__ bool lds_varlong(const uint8_t *win, uint32_t &off, u
     return false;
 }
 
+template <int G, uint32_t W, uint32_t R>   // batches per wave, window bytes and records per round of a group
 __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                         uint64_t n_batches, int want_keys, int32_t *part,
                                                         int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
                                                         unsigned long long *n_bad, unsigned long long *n_keyb)
 {
-    __shared__ uint4 s_win[kWinBytes / 16 + 1];   // + 1: the fast varint path reads one dword ahead
-    __shared__ uint32_t s_start[kWinRecs];   // record start, relative to the window base
-    __shared__ uint32_t s_body[kWinRecs];    // offset of the record body (after the length varint)
-    __shared__ uint64_t s_next;              // absolute position after the last chained record
-    __shared__ uint32_t s_found, s_first_incomplete, s_bad;
-    const uint8_t *win = reinterpret_cast<const uint8_t *>(s_win);
-    const uint32_t lane = threadIdx.x;
-    unsigned long long kb = 0;               // this lane's share of the key bytes
-    const uint64_t b = blockIdx.x;           // one workgroup (= one wave) per batch: the dispatcher balances
-    if (b >= n_batches) return;
-    const kta_kafka_batch_desc d = descs[b];
-    const uint64_t end = d.payload_end;
-    const uint32_t total = (uint32_t)d.n_records;
-    uint64_t pos = d.payload_off;
-    uint32_t j = 0;                          // records finished
-    bool bad = d.status != 0;                // failed check.crcs or inflate: the batch is not delivered
-    while (!bad && j < total) {              // every condition below is wave-uniform
-        if (pos >= end) { bad = true; break; }
-        const uint64_t wbase = pos & ~15ull;
-        const uint64_t span = ((end + 15) & ~15ull) - wbase;
-        const uint32_t wbytes = span < kWinBytes ? (uint32_t)span : kWinBytes;
-        const uint64_t wlimit_abs = wbase + wbytes < end ? wbase + wbytes : end;
-        const uint32_t limit = (uint32_t)(wlimit_abs - wbase);                 // valid bytes in the window
-        for (uint32_t o = lane * 16; o < wbytes; o += 64 * 16) s_win[o >> 4] = blocks[(wbase + o) >> 4];
-        if (lane == 0) { s_bad = 0; s_found = 0; s_first_incomplete = kWinRecs; }
+    constexpr uint32_t L = 64 / G;                // lanes per batch
+    constexpr uint32_t NLOAD = W / (L * 16);      // staged 16-byte loads per lane and window
+    constexpr uint32_t NT = R / L;                // parse rounds per window
+    static_assert(W % (L * 16) == 0 && R % L == 0, "window geometry");
+    __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the fast varint path reads one dword ahead
+    __shared__ uint32_t s_start[G][R];            // record start, relative to the window base
+    __shared__ uint32_t s_body[G][R];             // offset of the record body (after the length varint)
+    __shared__ uint64_t s_next[G];                // absolute position after the last chained record
+    __shared__ uint32_t s_found[G], s_first_incomplete[G], s_bad[G];
+    const uint32_t lane = threadIdx.x, g = lane / L, sub = lane % L;
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s_win[g]);
+    const uint64_t b = (uint64_t)blockIdx.x * G + g;      // the dispatcher balances the waves
+    unsigned long long kb = 0;                            // this lane's share of the key bytes
+    uint64_t end = 0, pos = 0, record_base = 0;
+    int64_t base_ts = 0, max_ts = 0;
+    uint32_t total = 0, flags = 0, j = 0;                 // j: records finished
+    int32_t partition = 0;
+    bool bad = false;
+    if (b < n_batches) {
+        const kta_kafka_batch_desc &d = descs[b];
+        end = d.payload_end; pos = d.payload_off; record_base = d.record_base;
+        base_ts = d.base_ts_ms; max_ts = d.max_ts_ms;
+        total = (uint32_t)d.n_records; flags = d.flags; partition = d.partition;
+        bad = d.status != 0;                              // failed check.crcs or inflate: the batch is not delivered
+    }
+    bool run = !bad && j < total;                         // uniform inside a group
+    while (__any(run)) {
+        uint64_t wbase = 0, wlimit_abs = 0;
+        uint32_t limit = 0;                               // valid bytes in the window
+        if (run && pos >= end) { bad = true; run = false; }
+        if (run) {
+            wbase = pos & ~15ull;
+            const uint64_t span = ((end + 15) & ~15ull) - wbase;
+            const uint32_t wbytes = span < W ? (uint32_t)span : W;
+            wlimit_abs = wbase + wbytes < end ? wbase + wbytes : end;
+            limit = (uint32_t)(wlimit_abs - wbase);
+            // all loads of the window are in flight together (clamped address, conditional LDS store)
+            uint4 stage[NLOAD];
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) {
+                const uint32_t o = (sub + u * L) * 16;
+                stage[u] = blocks[(wbase + (o < wbytes ? o : wbytes - 16)) >> 4];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) {
+                const uint32_t o = (sub + u * L) * 16;
+                if (o < wbytes) s_win[g][o >> 4] = stage[u];
+            }
+            if (sub == 0) { s_bad[g] = 0; s_found[g] = 0; s_first_incomplete[g] = R; }
+        }
         __syncthreads();
-        if (lane == 0) {                                                       // chain the length prefixes
-            uint32_t k = 0;
-            uint64_t cur = pos;
-            const uint32_t want = total - j;
-            while (k < kWinRecs && k < want && cur < wlimit_abs) {
-                uint32_t off = (uint32_t)(cur - wbase);
+        if (run && sub == 0) {                                                 // chain the length prefixes
+            // Offsets are relative to the window base.  Fast step: the length is a 1..4 byte varint inside
+            // the window (always, for ordinary records) — one LDS read, straight-line integer code.
+            const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+            const uint64_t end_rel64 = end - wbase;
+            const uint32_t end_rel = end_rel64 > 0xF0000000ull ? 0xF0000000u : (uint32_t)end_rel64;
+            const uint32_t want = total - j < R ? total - j : R;
+            uint32_t k = 0, cur = (uint32_t)(pos - wbase);
+            uint64_t next = 0;                                                 // set when the slow step leaves the window
+            uint32_t flag_bad = 0;
+            while (k < want && cur < limit) {
+                uint32_t stop = 0, w = 0;
+                if (cur + 4u <= limit) {
+                    w = __builtin_amdgcn_alignbyte(w32[(cur >> 2) + 1], w32[cur >> 2], cur & 3u);
+                    stop = ~w & 0x80808080u;
+                }
+                if (stop) {
+                    const uint32_t nb = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;
+                    uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
+                    v &= 0xFFFFFFFFu >> (32u - 7u * nb);
+                    const uint32_t body = cur + nb, rec_end = body + (v >> 1);  // < 2^13 + 2^27: no overflow
+                    if ((v & 1u) || rec_end > end_rel) { flag_bad = 1; break; } // negative length / overruns the batch
+                    s_start[g][k] = cur;
+                    s_body[g][k] = body;
+                    k++;
+                    cur = rec_end;
+                    continue;
+                }
+                uint32_t off = cur;                                            // slow step: long varint or window edge
                 long long len;
                 if (!lds_varlong(win, off, limit, len)) {
-                    if (wlimit_abs == end) s_bad = 1;                          // ran into the end of the batch
+                    if (wlimit_abs == end) flag_bad = 1;                       // ran into the end of the batch
                     break;                                                     // else it straddles the window: next round
                 }
                 const uint64_t rec_end = wbase + off + (uint64_t)len;
-                if (len < 0 || rec_end > end) { s_bad = 1; break; }
-                s_start[k] = (uint32_t)(cur - wbase);
-                s_body[k] = off;
-                cur = rec_end;
+                if (len < 0 || rec_end > end) { flag_bad = 1; break; }
+                s_start[g][k] = cur;
+                s_body[g][k] = off;
                 k++;
+                if (rec_end >= wlimit_abs) { next = rec_end; break; }
+                cur = (uint32_t)(rec_end - wbase);
             }
-            s_found = k;
-            s_next = cur;
+            if (flag_bad) s_bad[g] = 1;
+            s_found[g] = k;
+            s_next[g] = next ? next : wbase + cur;
         }
         __syncthreads();
-        const uint32_t found = s_found;
-        long long my_kl[kWinRecs / 64];
+        long long my_kl[NT];
 #pragma unroll
-        for (uint32_t t = 0; t < kWinRecs / 64; t++) {                         // one record per lane and round
-            my_kl[t] = 0;
-            const uint32_t k = lane + 64 * t;
-            if (k >= found) continue;
-            uint32_t off = s_body[k] + 1;                                      // + record attributes byte
-            const uint64_t rec_end = (k + 1 < found) ? wbase + s_start[k + 1] : s_next;
-            long long ts_delta = 0, od = 0, kl = 0, vl = 0;
-            if (!(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
-                  lds_varlong(win, off, limit, kl))) {
-                atomicMin(&s_first_incomplete, k);                             // header not inside this window
-                continue;
-            }
-            const uint64_t key_pos = wbase + off;
-            const uint64_t vpos = key_pos + (kl > 0 ? (uint64_t)kl : 0);
-            bool rec_ok = kl >= -1 && vpos < rec_end;
-            if (rec_ok) {
-                bool got = false;
-                uint64_t after = 0;                                            // position after the value length
-                if (vpos < wlimit_abs) {
-                    uint32_t voff = (uint32_t)(vpos - wbase);
-                    got = lds_varlong(win, voff, limit, vl);
-                    after = wbase + voff;
+        for (uint32_t t = 0; t < NT; t++) my_kl[t] = 0;
+        if (run) {
+            const uint32_t found = s_found[g];
+            const uint64_t next = s_next[g];
+#pragma unroll
+            for (uint32_t t = 0; t < NT; t++) {                                // one record per lane and round
+                const uint32_t k = sub + L * t;
+                if (k >= found) continue;
+                uint32_t off = s_body[g][k] + 1;                               // + record attributes byte
+                const uint64_t rec_end = (k + 1 < found) ? wbase + s_start[g][k + 1] : next;
+                long long ts_delta = 0, od = 0, kl = 0, vl = 0;
+                if (!(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
+                      lds_varlong(win, off, limit, kl))) {
+                    atomicMin(&s_first_incomplete[g], k);                      // header not inside this window
+                    continue;
                 }
-                if (!got) {                                                    // value length lies beyond the window
-                    Reader gr{blocks, vpos, ~0ull, make_uint4(0, 0, 0, 0)};
-                    vl = read_varlong(gr);
-                    after = gr.pos;
+                const uint64_t key_pos = wbase + off;
+                const uint64_t vpos = key_pos + (kl > 0 ? (uint64_t)kl : 0);
+                bool rec_ok = kl >= -1 && vpos < rec_end;
+                if (rec_ok) {
+                    bool got = false;
+                    uint64_t after = 0;                                        // position after the value length
+                    if (vpos < wlimit_abs) {
+                        uint32_t voff = (uint32_t)(vpos - wbase);
+                        got = lds_varlong(win, voff, limit, vl);
+                        after = wbase + voff;
+                    }
+                    if (!got) {                                                // value length lies beyond the window
+                        Reader gr{blocks, vpos, ~0ull, make_uint4(0, 0, 0, 0)};
+                        vl = read_varlong(gr);
+                        after = gr.pos;
+                    }
+                    rec_ok = vl >= -1 && after + (uint64_t)(vl > 0 ? vl : 0) <= rec_end;
                 }
-                rec_ok = vl >= -1 && after + (uint64_t)(vl > 0 ? vl : 0) <= rec_end;
+                if (!rec_ok) { s_bad[g] = 1; continue; }
+                const uint64_t i = record_base + j + k;
+                part[i] = partition;
+                klen[i] = (int32_t)kl;
+                vlen[i] = (int32_t)vl;
+                ts[i] = (flags & KTA_KB_LOG_APPEND_TIME) ? max_ts : base_ts + ts_delta;
+                if (seq) seq[i] = seq_base + i;
+                if (want_keys) koff[i] = (uint32_t)(kl > 0 ? key_pos - blob_base : 0);
+                my_kl[t] = kl;
             }
-            if (!rec_ok) { s_bad = 1; continue; }
-            const uint64_t i = d.record_base + j + k;
-            part[i] = d.partition;
-            klen[i] = (int32_t)kl;
-            vlen[i] = (int32_t)vl;
-            ts[i] = (d.flags & KTA_KB_LOG_APPEND_TIME) ? d.max_ts_ms : d.base_ts_ms + ts_delta;
-            if (seq) seq[i] = seq_base + i;
-            if (want_keys) koff[i] = (uint32_t)(kl > 0 ? key_pos - blob_base : 0);
-            my_kl[t] = kl;
         }
         __syncthreads();
-        if (s_bad) { bad = true; break; }
-        const uint32_t first_inc = s_first_incomplete;
-        const uint32_t done = first_inc < found ? first_inc : found;
-        if (done == 0) { bad = true; break; }                                  // no progress: truncated batch
+        if (run) {
+            const uint32_t found = s_found[g], first_inc = s_first_incomplete[g];
+            const uint32_t done = first_inc < found ? first_inc : found;
+            if (s_bad[g] || done == 0) {                                       // done == 0: no progress, truncated batch
+                bad = true;
+                run = false;
+            } else {
 #pragma unroll
-        for (uint32_t t = 0; t < kWinRecs / 64; t++)
-            if (lane + 64 * t < done && my_kl[t] > 0) kb += (unsigned long long)my_kl[t];
-        j += done;
-        pos = done < found ? wbase + s_start[done] : s_next;                   // records >= done are redone
+                for (uint32_t t = 0; t < NT; t++)
+                    if (sub + L * t < done && my_kl[t] > 0) kb += (unsigned long long)my_kl[t];
+                j += done;
+                pos = done < found ? wbase + s_start[g][done] : s_next[g];     // records >= done are redone
+                run = j < total;
+            }
+        }
         __syncthreads();
     }
     if (bad) {
-        for (uint32_t r = j + lane; r < total; r += 64) {
-            const uint64_t i = d.record_base + r;
+        for (uint32_t r = j + sub; r < total; r += L) {
+            const uint64_t i = record_base + r;
             part[i] = -1; klen[i] = -1; vlen[i] = -1; ts[i] = -1;
             if (seq) seq[i] = seq_base + i;
             if (want_keys) koff[i] = 0u;
         }
-        if (lane == 0) atomicAdd(n_bad, 1ull);
+        if (sub == 0) atomicAdd(n_bad, 1ull);
     }
     if (n_keyb) {                                  // only when the caller asked for the total (one atomic per wave)
 #pragma unroll
@@ -362,8 +444,17 @@ __global__ __launch_bounds__(64) void kafka_snappy_inflate_coop(uint8_t *buffer,
         if (wbase != ~0ull && at >= wbase && at + need <= wbase + kSnapWin) return;
         __syncthreads();
         wbase = at & ~15ull;
-        for (uint32_t o = lane * 16; o < kSnapWin; o += 64 * 16)
-            if (wbase + o < ((src_end + 15) & ~15ull)) s_in[o >> 4] = blocks[(wbase + o) >> 4];
+        const uint64_t last = ((src_end + 15) & ~15ull) - 16;          // last readable block of the batch
+        uint4 stage[kSnapWin / 1024];                                  // loads in flight together, then LDS
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) {
+            const uint64_t a = wbase + lane * 16 + u * 1024;
+            stage[u] = blocks[(a < last ? a : last) >> 4];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) pin(stage[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) s_in[lane + 64 * u] = stage[u];
         __syncthreads();
     };
     auto in_byte = [&](uint64_t at) -> uint32_t { return win[at - wbase]; };
@@ -488,8 +579,17 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
         if (wbase != ~0ull && at >= wbase && at + need <= wbase + kSnapWin) return;
         __syncthreads();
         wbase = at & ~15ull;
-        for (uint32_t o = lane * 16; o < kSnapWin; o += 64 * 16)
-            if (wbase + o < ((src_end + 15) & ~15ull)) s_in[o >> 4] = blocks[(wbase + o) >> 4];
+        const uint64_t last = ((src_end + 15) & ~15ull) - 16;          // last readable block of the batch
+        uint4 stage[kSnapWin / 1024];                                  // loads in flight together, then LDS
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) {
+            const uint64_t a = wbase + lane * 16 + u * 1024;
+            stage[u] = blocks[(a < last ? a : last) >> 4];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) pin(stage[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < kSnapWin / 1024; u++) s_in[lane + 64 * u] = stage[u];
         __syncthreads();
     };
     auto in_byte = [&](uint64_t at) -> uint32_t { return win[at - wbase]; };
@@ -982,7 +1082,7 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     }
     if (any_snappy || any_lz4) {   // inflate compressed batches into their slices of the same buffer
         uint8_t *buf = const_cast<uint8_t *>(blob_device);
-        if (g_decode_variant == 0) {
+        if (g_decode_variant != 1) {
             if (any_snappy)
                 hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
                                    n_batches);
@@ -995,16 +1095,25 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipGetLastError());
     }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
-    if (g_decode_variant == 0)   // one wave per batch (default)
-        hipLaunchKernelGGL(kafka_decode_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, words, st->d_descs, n_batches,
-                           want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
-                           (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
-                           n_key_bytes ? reinterpret_cast<unsigned long long *>(st->d_scalars) : nullptr);
-    else                         // one lane per batch (kept for comparison)
-        hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches,
-                           want_keys ? 1 : 0, out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off,
-                           (uint64_t)0, out->seq, (uint64_t)0, reinterpret_cast<unsigned long long *>(st->d_scalars + 1),
-                           n_key_bytes ? reinterpret_cast<unsigned long long *>(st->d_scalars) : nullptr);
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(st->d_scalars + 1);
+    unsigned long long *d_keyb = n_key_bytes ? reinterpret_cast<unsigned long long *>(st->d_scalars) : nullptr;
+    const int wk = want_keys ? 1 : 0;
+#define KTA_DECODE_COOP(G, W, R)                                                                                      \
+    hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
+                       words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
+                       out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
+    switch (decode_variant_for(n_batches, blob_len)) {
+    case 1: // one lane per batch (kept for comparison)
+        hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
+                           out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off, (uint64_t)0, out->seq,
+                           (uint64_t)0, d_bad, d_keyb);
+        break;
+    case 2: KTA_DECODE_COOP(1, 8192u, 256u); break;   // one wave per batch
+    case 3: KTA_DECODE_COOP(4, 4096u, 64u); break;    // 16 lanes per batch, 4 KiB windows
+    case 4: KTA_DECODE_COOP(4, 2048u, 32u); break;    // 16 lanes per batch, 2 KiB windows
+    default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
+    }
+#undef KTA_DECODE_COOP
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
     if (n_bad_batches || n_key_bytes) {
@@ -1192,7 +1301,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(int variant)
 {
-    if (variant != 0 && variant != 1) return KTA_ERR_INVALID;
+    if (variant < 0 || variant > 5) return KTA_ERR_INVALID;
     g_decode_variant = variant;
     return KTA_OK;
 }

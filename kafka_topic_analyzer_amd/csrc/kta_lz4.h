@@ -42,7 +42,8 @@ KTA_LZ4_HD bool lz4_frame_header(const uint8_t *p, uint64_t n, Lz4Frame *f)
     return f->first_block <= n;
 }
 
-// Upper bound of the inflated size (blocks x block maximum size); -1 if the framing is malformed.
+// Upper bound of the inflated size; -1 if the framing is malformed.  A compressed block expands at most
+// 255x (every match-length extension byte adds 255 bytes), and never beyond the block maximum size.
 KTA_LZ4_HD int64_t lz4_inflate_bound(const uint8_t *p, uint64_t n)
 {
     Lz4Frame f;
@@ -55,7 +56,8 @@ KTA_LZ4_HD int64_t lz4_inflate_bound(const uint8_t *p, uint64_t n)
         if (w == 0) break;
         const uint64_t sz = w & 0x7FFFFFFFu;
         if (sz > f.block_max || pos + sz > n) return -1;
-        bound += (w & 0x80000000u) ? sz : f.block_max;
+        const uint64_t grown = sz * 255u + 64u;
+        bound += (w & 0x80000000u) ? sz : (grown < f.block_max ? grown : f.block_max);
         pos += sz + (f.block_checksum ? 4 : 0);
     }
     return (int64_t)bound;
