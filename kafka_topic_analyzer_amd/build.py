@@ -23,7 +23,7 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "libkta_oracle.so")
 
 HIP_SOURCES = ["kta_kernels.hip", "kta_api.hip", "kta_synth.hip", "kta_kafka.hip"]
 LIB_HOST_SOURCES = ["host/metric.cpp", "host/report.cpp", "host/kafka_encode.cpp"]  # C++ host mirror, inside libkta_hip.so
-HOST_SOURCES = ["host/main.cpp"]
+HOST_SOURCES = ["host/main.cpp", "host/rdkafka_source.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
                "-Wno-unused-result"]
 
@@ -83,7 +83,7 @@ def build_cli(force: bool = False):
     if not force and _newer(CLI, deps):
         return CLI
     _run([_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(ROOT, "include"),
-          "-I", CSRC, *srcs, "-o", CLI, "-L", HERE, "-lkta_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+          "-I", CSRC, *srcs, "-o", CLI, "-L", HERE, "-lkta_hip", "-ldl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return CLI
 
 

@@ -7,14 +7,16 @@
 //   -c, --count-alive-keys                                           main.rs:60-66, 77-80
 //   -h/--help, -V/--version ("0.4.1", main.rs:35)
 //
-// The consume loop (src/kafka.rs) needs librdkafka and a broker, neither of which exists in this
-// build, so the record source is chosen by the scheme of --bootstrap-server:
+// The record source is chosen by the scheme of --bootstrap-server:
+//     <host:port,...>                    a Kafka cluster, through the reference's consume loop (src/kafka.rs)
+//                                        over librdkafka, which is bound at run time (host/rdkafka_source.hpp);
+//                                        "Consumer creation failed" when the library is not installed
 //     synthetic://<c1..c5>[?records=N]   the synthetic topic of include/kta_synth.h
 //     dump://<path>                      a KTADUMP1 topic dump (host/dump.hpp)
 //     segment://<f0>[,<f1>...]           raw Kafka log segments (`*.log` files of a broker, record-batch
 //                                        v2, uncompressed): file k is partition k; decoded ON THE GPU
 //                                        (include/kta_kafka.h), the host only walks batch headers
-// anything else is refused.  Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
+// Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
 // kta.batch=N, kta.write_dump=<path>, kta.per_message=1), so no flag is added or renamed.
 // kta.per_message=1 drives the handler exactly like the reference's loop (kafka.rs:107-109): one
 // MetricHandler::handle_message call per record instead of filling columns.
@@ -32,6 +34,7 @@
 #include "kta_kafka.h"
 #include "kta_synth.h"
 #include "metric.hpp"
+#include "rdkafka_source.hpp"
 
 namespace {
 
@@ -154,10 +157,16 @@ int main(int argc, char **argv)
     const std::string &b = args.bootstrap;
     bool synthetic = b.rfind("synthetic://", 0) == 0, dump = b.rfind("dump://", 0) == 0;
     const bool segment = b.rfind("segment://", 0) == 0;
-    if (!synthetic && !dump && !segment) {
-        fprintf(stderr, "Consumer creation failed: this build has no librdkafka; --bootstrap-server must be "
-                        "synthetic://<c1..c5>[?records=N], dump://<path> or segment://<log>[,<log>...]\n");
-        return 101;
+    const bool kafka = !synthetic && !dump && !segment;   // a broker list: the reference's own path
+    kta::TopicAnalyzer *topic_analyzer = nullptr;
+    std::map<int32_t, int64_t> kafka_start, kafka_end;
+    if (kafka) {
+        try {
+            topic_analyzer = kta::TopicAnalyzer::new_from_bootstrap_servers(b, cfg);      // main.rs:93
+            topic_analyzer->get_topic_offsets(args.topic, &kafka_start, &kafka_end);      // main.rs:94-96
+        } catch (const kta::RustPanic &p) {
+            rust_panic(p.what(), p.location);
+        }
     }
     std::vector<std::string> segment_files;
     if (segment) {
@@ -188,6 +197,8 @@ int main(int argc, char **argv)
     } else if (segment) {
         hdr.n_partitions = (uint32_t)segment_files.size();
         n_records = 1;  // unknown until decoded; non-zero so the emptiness test below looks at the files
+    } else if (kafka) {
+        hdr.n_partitions = kafka_end.empty() ? 0u : (uint32_t)(kafka_end.rbegin()->first + 1);   // ids are dense
     } else {
         reader = new kta::DumpReader(b.substr(strlen("dump://")));
         if (!reader->ok() || !reader->read_header(&hdr)) {
@@ -212,6 +223,11 @@ int main(int argc, char **argv)
 
     std::vector<int64_t> start_offsets(P, 0), end_offsets(P, 0);
     if (dump) { start_offsets = hdr.start_offsets; end_offsets = hdr.end_offsets; }
+    if (kafka)
+        for (const auto &kv : kafka_end) {
+            start_offsets[(size_t)kv.first] = kafka_start[kv.first];
+            end_offsets[(size_t)kv.first] = kv.second;
+        }
     std::vector<std::vector<uint8_t>> segment_bytes;
     if (segment) {  // watermarks = first / last offset found in each partition's segment (kafka.rs:60-72)
         for (uint32_t p = 0; p < P; p++) {
@@ -254,9 +270,11 @@ int main(int argc, char **argv)
     std::vector<int32_t> partitions(P);                                             // main.rs:103-106
     for (uint32_t p = 0; p < P; p++) partitions[p] = (int32_t)p;
 
-    printf("Subscribing to %s\n", args.topic.c_str());                              // kafka.rs:88
-    printf("Starting message consumption...\n");                                    // kafka.rs:91
-    fflush(stdout);
+    if (!kafka) {
+        printf("Subscribing to %s\n", args.topic.c_str());                          // kafka.rs:88
+        printf("Starting message consumption...\n");                                // kafka.rs:91
+        fflush(stdout);
+    }
 
     kta::DumpWriter *writer = nullptr;
     std::vector<kta::DumpBatch> to_write;
@@ -264,7 +282,21 @@ int main(int argc, char **argv)
 
     uint64_t seq = 0;
     const bool per_message = cfg.count("kta.per_message") && cfg["kta.per_message"] == "1";
-    if (synthetic && per_message) {
+    if (kafka) {
+        // the reference's loop: every polled message goes to every handler (kafka.rs:92-135); the handler
+        // stages it into pinned columns and the device accumulates batch by batch
+        topic_analyzer->add_metric_handler(handler);                               // main.rs:108-115
+        try {
+            seq = topic_analyzer->read_topic_into_metrics(args.topic, kafka_end);  // main.rs:117
+        } catch (const kta::RustPanic &p) {
+            rust_panic(p.what(), p.location);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 2;
+        }
+        delete topic_analyzer;                                                     // end of the block, main.rs:118
+        topic_analyzer = nullptr;
+    } else if (synthetic && per_message) {
         // the reference's shape: for every polled message, every handler's handle_message (kafka.rs:107-109)
         std::vector<kta::MetricHandler *> metric_handlers{handler};
         std::vector<uint8_t> key;
@@ -362,7 +394,7 @@ int main(int argc, char **argv)
             }
         }
     }
-    fprintf(stderr, "done\n");                                                      // kafka.rs:136 (spinner)
+    if (!kafka) fprintf(stderr, "done\n");                                          // kafka.rs:136 (spinner)
 
     try {
         handler->finish(segment);                // where main.rs:121 is: the trait has no end-of-stream hook

@@ -1,0 +1,267 @@
+// mock_rdkafka.cpp — TEST DOUBLE of librdkafka: the ~20 C entry points kta::TopicAnalyzer binds
+// (kafka_topic_analyzer_amd/csrc/host/rdkafka_source.cpp), served from the synthetic topic of
+// include/kta_synth.h instead of a broker.  Built by the tests into a shared object that is handed
+// to the analyzer through $KTA_RDKAFKA_LIB.  Not part of the product.
+//
+// Environment:
+//   MOCK_RDKAFKA_SPEC        file: a kta_synth_spec followed by a u64 record count (required)
+//   MOCK_RDKAFKA_LOG         file: one line per noteworthy call (conf_set pairs, subscribe, close ...)
+//   MOCK_RDKAFKA_ERR_EVERY   k: every k-th poll returns an error event (no record consumed)
+//   MOCK_RDKAFKA_NULL_EVERY  k: every k-th poll times out (NULL)
+//   MOCK_RDKAFKA_START       low watermark of every partition (offsets start there; default 0)
+// Records are delivered in the synthetic topic's global order, so a run equals `synthetic://`.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kta_synth.h"
+
+namespace {
+
+struct Message {   // must match rd_kafka_message_t
+    int err;
+    void *rkt;
+    int32_t partition;
+    void *payload;
+    size_t len;
+    void *key;
+    size_t key_len;
+    int64_t offset;
+    void *_private;
+};
+struct MdBroker { int32_t id; char *host; int port; };
+struct MdPartition { int32_t id; int err; int32_t leader; int replica_cnt; int32_t *replicas; int isr_cnt; int32_t *isrs; };
+struct MdTopic { char *topic; int partition_cnt; MdPartition *partitions; int err; };
+struct Metadata { int broker_cnt; MdBroker *brokers; int topic_cnt; MdTopic *topics; int32_t orig_broker_id; char *orig_broker_name; };
+
+struct Conf { std::vector<std::pair<std::string, std::string>> kv; };
+struct Topic { std::string name; };
+struct Private { int64_t ts; std::vector<uint8_t> key; };
+
+struct Handle {
+    kta_synth_spec spec{};
+    uint64_t n_records = 0, next = 0, polls = 0, stored = 0;
+    int64_t start = 0;
+    uint64_t err_every = 0, null_every = 0;
+    std::vector<int64_t> count;      // records per partition
+    std::vector<int64_t> delivered;  // per partition so far
+    bool subscribed = false;
+    Topic topic_handle;
+};
+
+uint8_t g_byte = 0;
+
+void log_line(const std::string &s)
+{
+    const char *p = getenv("MOCK_RDKAFKA_LOG");
+    if (!p) return;
+    FILE *f = fopen(p, "a");
+    if (!f) return;
+    fprintf(f, "%s\n", s.c_str());
+    fclose(f);
+}
+
+uint64_t env_u64(const char *name)
+{
+    const char *v = getenv(name);
+    return v ? strtoull(v, nullptr, 10) : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void *rd_kafka_conf_new() { return new Conf(); }
+
+int rd_kafka_conf_set(void *conf, const char *name, const char *value, char *errstr, size_t errstr_size)
+{
+    if (strcmp(name, "mock.reject") == 0) {   // lets a test provoke "Consumer creation failed"
+        snprintf(errstr, errstr_size, "No such configuration property: \"%s\"", name);
+        return -2;
+    }
+    static_cast<Conf *>(conf)->kv.emplace_back(name, value);
+    log_line(std::string("conf_set ") + name + "=" + value);
+    return 0;
+}
+
+void rd_kafka_conf_destroy(void *conf) { delete static_cast<Conf *>(conf); }
+
+void *rd_kafka_new(int type, void *conf, char *errstr, size_t errstr_size)
+{
+    const char *path = getenv("MOCK_RDKAFKA_SPEC");
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    Handle *h = new Handle();
+    if (!f || fread(&h->spec, sizeof(h->spec), 1, f) != 1 || fread(&h->n_records, 8, 1, f) != 1) {
+        snprintf(errstr, errstr_size, "mock: cannot read MOCK_RDKAFKA_SPEC");
+        if (f) fclose(f);
+        delete h;
+        return nullptr;
+    }
+    fclose(f);
+    h->start = (int64_t)env_u64("MOCK_RDKAFKA_START");
+    h->err_every = env_u64("MOCK_RDKAFKA_ERR_EVERY");
+    h->null_every = env_u64("MOCK_RDKAFKA_NULL_EVERY");
+    h->count.assign(h->spec.n_partitions, 0);
+    h->delivered.assign(h->spec.n_partitions, 0);
+    for (uint64_t i = 0; i < h->n_records; i++) {
+        int32_t p, kl, vl;
+        int64_t ts;
+        kta_synth_record(&h->spec, i, &p, &kl, &vl, &ts);
+        h->count[(size_t)p]++;
+    }
+    log_line("new type=" + std::to_string(type));
+    delete static_cast<Conf *>(conf);   // rd_kafka_new takes ownership of the configuration
+    return h;
+}
+
+void rd_kafka_set_log_level(void *, int level) { log_line("set_log_level " + std::to_string(level)); }
+int rd_kafka_poll_set_consumer(void *) { log_line("poll_set_consumer"); return 0; }
+
+void *rd_kafka_topic_new(void *, const char *topic, void *) { Topic *t = new Topic(); t->name = topic; return t; }
+void rd_kafka_topic_destroy(void *rkt) { delete static_cast<Topic *>(rkt); }
+
+int rd_kafka_metadata(void *rk, int all_topics, void *only_rkt, const Metadata **out, int timeout_ms)
+{
+    Handle *h = static_cast<Handle *>(rk);
+    log_line("metadata all_topics=" + std::to_string(all_topics) + " timeout_ms=" + std::to_string(timeout_ms));
+    Metadata *md = new Metadata();
+    memset(md, 0, sizeof(*md));
+    const std::string name = only_rkt ? static_cast<Topic *>(only_rkt)->name : "";
+    if (name != "absent-topic") {
+        md->topic_cnt = 1;
+        md->topics = new MdTopic[1];
+        md->topics[0].topic = strdup(name.c_str());
+        md->topics[0].err = 0;
+        md->topics[0].partition_cnt = (int)h->spec.n_partitions;
+        md->topics[0].partitions = new MdPartition[h->spec.n_partitions];
+        for (uint32_t p = 0; p < h->spec.n_partitions; p++) {
+            MdPartition &mp = md->topics[0].partitions[p];
+            memset(&mp, 0, sizeof(mp));
+            mp.id = (int32_t)p;
+        }
+    }
+    *out = md;
+    return 0;
+}
+
+void rd_kafka_metadata_destroy(const Metadata *cmd)
+{
+    Metadata *md = const_cast<Metadata *>(cmd);
+    if (md->topics) {
+        free(md->topics[0].topic);
+        delete[] md->topics[0].partitions;
+        delete[] md->topics;
+    }
+    delete md;
+}
+
+int rd_kafka_query_watermark_offsets(void *rk, const char *, int32_t partition, int64_t *low, int64_t *high, int timeout_ms)
+{
+    Handle *h = static_cast<Handle *>(rk);
+    if (partition < 0 || (uint32_t)partition >= h->spec.n_partitions) return 3;   // UNKNOWN_TOPIC_OR_PART
+    *low = h->start;
+    *high = h->start + h->count[(size_t)partition];
+    log_line("watermarks p=" + std::to_string(partition) + " timeout_ms=" + std::to_string(timeout_ms));
+    return 0;
+}
+
+struct Tpl { std::vector<std::pair<std::string, int32_t>> items; };
+void *rd_kafka_topic_partition_list_new(int) { return new Tpl(); }
+void *rd_kafka_topic_partition_list_add(void *l, const char *topic, int32_t partition)
+{
+    static_cast<Tpl *>(l)->items.emplace_back(topic, partition);
+    return l;
+}
+void rd_kafka_topic_partition_list_destroy(void *l) { delete static_cast<Tpl *>(l); }
+
+int rd_kafka_subscribe(void *rk, const void *l)
+{
+    Handle *h = static_cast<Handle *>(rk);
+    const Tpl *t = static_cast<const Tpl *>(l);
+    for (const auto &it : t->items) log_line("subscribe " + it.first + " partition=" + std::to_string(it.second));
+    if (!t->items.empty()) h->topic_handle.name = t->items[0].first;
+    h->subscribed = true;
+    return 0;
+}
+
+Message *rd_kafka_consumer_poll(void *rk, int)
+{
+    Handle *h = static_cast<Handle *>(rk);
+    if (!h->subscribed) return nullptr;
+    h->polls++;
+    if (h->null_every && h->polls % h->null_every == 0) return nullptr;
+    Message *m = new Message();
+    memset(m, 0, sizeof(*m));
+    m->rkt = &h->topic_handle;
+    if (h->err_every && h->polls % h->err_every == 0) {
+        m->err = -195;   // RD_KAFKA_RESP_ERR__TRANSPORT
+        return m;
+    }
+    if (h->next >= h->n_records) { delete m; return nullptr; }   // caught up: poll times out for ever
+    int32_t p, kl, vl;
+    int64_t ts;
+    kta_synth_record(&h->spec, h->next, &p, &kl, &vl, &ts);
+    Private *pv = new Private();
+    pv->ts = ts;
+    m->_private = pv;
+    m->partition = p;
+    m->offset = h->start + h->delivered[(size_t)p]++;
+    if (kl >= 0) {
+        const uint64_t kid = (uint64_t)kta_synth_key_id(&h->spec, h->next);
+        pv->key.resize((size_t)kl + 1);
+        for (int32_t j = 0; j < kl; j++) pv->key[(size_t)j] = kta_synth_key_byte(&h->spec, kid, (uint32_t)j);
+        m->key = pv->key.data();     // empty key: non-null pointer, length 0
+        m->key_len = (size_t)kl;
+    }
+    if (vl >= 0) {
+        m->payload = &g_byte;        // the analyzer never reads value bytes; only the length matters
+        m->len = (size_t)vl;
+    }
+    h->next++;
+    return m;
+}
+
+int64_t rd_kafka_message_timestamp(const Message *m, int *tstype)
+{
+    const Private *pv = static_cast<const Private *>(m->_private);
+    if (!pv || pv->ts == -1) { *tstype = 0; return -1; }   // RD_KAFKA_TIMESTAMP_NOT_AVAILABLE
+    *tstype = 1;                                            // CREATE_TIME
+    return pv->ts;
+}
+
+void rd_kafka_message_destroy(Message *m)
+{
+    delete static_cast<Private *>(m->_private);
+    delete m;
+}
+
+int rd_kafka_offset_store(void *, int32_t, int64_t) { return 0; }
+
+const char *rd_kafka_err2str(int err)
+{
+    switch (err) {
+    case 0: return "Success";
+    case -195: return "Local: Broker transport failure";
+    case 3: return "Broker: Unknown topic or partition";
+    default: return "Unknown error";
+    }
+}
+
+int rd_kafka_consumer_close(void *rk)
+{
+    Handle *h = static_cast<Handle *>(rk);
+    log_line("consumer_close delivered=" + std::to_string(h->next) + " polls=" + std::to_string(h->polls));
+    return 0;
+}
+
+void rd_kafka_destroy(void *rk)
+{
+    log_line("destroy");
+    delete static_cast<Handle *>(rk);
+}
+
+}  // extern "C"
