@@ -243,6 +243,11 @@ int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
  * context reproduces the global last-writer state. */
 int kta_alive_export_entries(kta_ctx *ctx, void **d_slots, void **d_vals, uint64_t *n);
 int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_vals, uint64_t n);
+/* Alive keys whose hash slot lies in [slot_lo, slot_hi) (0 <= lo <= hi <= 2^32): the share of the owner
+ * of a hash range after the hash-range exchange of a multi-GPU run (distributed.py,
+ * exchange_alive_by_hash_range; SURVEY section 8(e) option ii).  Synchronous. */
+int kta_alive_count_range(kta_ctx *ctx, uint64_t slot_lo, uint64_t slot_hi, uint64_t *count);
+
 /* Tell the context that the table was changed behind its back (e.g. merged with other GPUs' tables
  * by an all-reduce MAX): the running alive count is dropped and the next kta_finish recounts by
  * scanning the table. */

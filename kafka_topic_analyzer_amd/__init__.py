@@ -289,6 +289,12 @@ class HipMetricHandler:
     def alive_import_entries(self, d_slots: int, d_vals: int, n: int) -> None:
         self._check(self._lib.kta_alive_import_entries(self._ctx, C.c_void_p(d_slots), C.c_void_p(d_vals), n))
 
+    def alive_count_range(self, slot_lo: int, slot_hi: int) -> int:
+        """Alive keys whose hash slot is in [slot_lo, slot_hi) (the owner's share of a hash range)."""
+        n = C.c_uint64()
+        self._check(self._lib.kta_alive_count_range(self._ctx, slot_lo, slot_hi, C.byref(n)))
+        return n.value
+
     def alive_table_modified(self) -> None:
         self._check(self._lib.kta_alive_table_modified(self._ctx))
 

@@ -120,6 +120,7 @@ SIGNATURES = {
     "kta_alive_table": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "kta_alive_export_entries": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "kta_alive_import_entries": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kta_alive_count_range": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "kta_alive_table_modified": (C.c_int, [_P]),
     "kta_fnv32_device": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kta_render_report": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_uint32,

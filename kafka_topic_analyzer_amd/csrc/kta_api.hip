@@ -738,6 +738,21 @@ int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_va
     return KTA_OK;
 }
 
+int kta_alive_count_range(kta_ctx *ctx, uint64_t slot_lo, uint64_t slot_hi, uint64_t *count)
+{
+    if (!ctx || !count || slot_lo > slot_hi || slot_hi > kta::kAliveSlots) return KTA_ERR_INVALID;
+    if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = kta_flush(ctx);
+    if (rc != KTA_OK) return rc;
+    hipStream_t s = ctx->s_compute;
+    if (!ctx->d_exp_count) KTA_HIP(ctx, hipMalloc((void **)&ctx->d_exp_count, sizeof(uint64_t)));
+    KTA_HIP(ctx, kta::launch_alive_count_span(ctx->d_table, slot_lo, slot_hi, ctx->d_exp_count, s));
+    KTA_HIP(ctx, hipMemcpyAsync(count, ctx->d_exp_count, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    KTA_HIP(ctx, hipStreamSynchronize(s));
+    return KTA_OK;
+}
+
 int kta_alive_table_modified(kta_ctx *ctx)
 {
     if (!ctx) return KTA_ERR_INVALID;

@@ -71,6 +71,7 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 // compact (slot, value) export / import of the entries ever written: what sharded GPUs exchange
+hipError_t launch_alive_count_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint64_t *out, hipStream_t s);
 hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 hipError_t launch_alive_export(const uint64_t *table, uint64_t n_slots, uint32_t *out_slots, uint64_t *out_vals,
                                uint64_t *counter, uint64_t cap, hipStream_t s);

@@ -651,6 +651,26 @@ __global__ __launch_bounds__(kWG) void kta_alive_count(const ulonglong2 *__restr
     }
 }
 
+// Alive bits of the slots [lo, hi) only (any bounds): what the owner of a hash range counts after the
+// hash-range exchange of a multi-GPU run.  8 B/lane.
+__global__ __launch_bounds__(kWG) void kta_alive_count_span(const uint64_t *__restrict__ table, uint64_t lo,
+                                                            uint64_t hi, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    unsigned long long cnt = 0;
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * kWG + threadIdx.x; i < hi; i += stride) cnt += table[i] & 1ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
 // Compact export of the entries ever written (value != 0): (slot u32, value u64) pairs.  A shard's
 // table holds at most one entry per distinct key hash it has seen, so this is what partition-sharded
 // GPUs exchange instead of the 32 GiB table.  Each workgroup sweeps a contiguous slab, stages hits in
@@ -864,6 +884,15 @@ hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kta_alive_count, dim3(256 * 8), dim3(kWG), 0, s,
                        reinterpret_cast<const ulonglong2 *>(table), n_slots / 2,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_alive_count_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint64_t *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess || lo >= hi) return e;
+    hipLaunchKernelGGL(kta_alive_count_span, dim3(256 * 8), dim3(kWG), 0, s, table, lo, hi,
                        reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }

@@ -107,3 +107,64 @@ def exchange_alive_entries(handler, device, group=None) -> int:
             imported += k
     handler.sync()                         # the gathered tensors may be freed after this
     return imported
+
+
+# ---- hash-range exchange (option ii) ------------------------------------------------
+# exchange_alive_entries leaves the WHOLE merged table on every rank: every rank receives and imports
+# every other rank's entries (traffic and atomics grow with the world size).  When only the number of
+# alive keys is wanted — which is all the report prints (src/main.rs:141-147) — a hash range per rank
+# suffices: rank r owns the slots [ceil(r * 2^32 / world), ceil((r+1) * 2^32 / world)), receives only the
+# entries of its range (all-to-all: every link carries 1/world of the entries, all 7 xGMI links in
+# parallel), merges them by MAX, counts its range and the counts are summed.
+
+def hash_range(rank: int, world: int):
+    """Slots owned by `rank`: owner(slot) == (slot * world) >> 32."""
+    lo = -((-rank * (1 << 32)) // world)
+    hi = -((-(rank + 1) * (1 << 32)) // world)
+    return lo, hi
+
+
+def route_entries_by_hash_range(slots, vals, group=None):
+    """all-to-all of (slot u32-as-i32, value u64-as-i64) entries: each entry goes to the rank that owns
+    its slot.  Returns (slots, vals) received by this rank (its own entries of its range included).
+    Works on device tensors (RCCL) and CPU tensors (gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    owner = ((slots.to(torch.int64) & 0xFFFFFFFF) * world) >> 32
+    order = torch.argsort(owner, stable=True)
+    send_slots, send_vals = slots[order].contiguous(), vals[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    ss, rs = send_counts.tolist(), recv_counts.tolist()
+    recv_slots = torch.empty(sum(rs), dtype=slots.dtype, device=slots.device)
+    recv_vals = torch.empty(sum(rs), dtype=vals.dtype, device=vals.device)
+    dist.all_to_all_single(recv_slots, send_slots, rs, ss, group=group)
+    dist.all_to_all_single(recv_vals, send_vals, rs, ss, group=group)
+    return recv_slots, recv_vals
+
+
+def exchange_alive_by_hash_range(handler, device, group=None) -> int:
+    """The global number of alive keys of a partition-sharded run (every rank gets the same number).
+    Afterwards a rank's table is merged for its own hash range only."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ps, pv, n = handler.alive_export_entries()
+    dev = torch.device("cuda", device)
+    if n:
+        slots = torch.as_tensor(_DevArray(ps, n, "<i4"), device=dev)
+        vals = torch.as_tensor(_DevArray(pv, n, "<i8"), device=dev)
+    else:
+        slots = torch.zeros(0, dtype=torch.int32, device=dev)
+        vals = torch.zeros(0, dtype=torch.int64, device=dev)
+    rslots, rvals = route_entries_by_hash_range(slots, vals, group)
+    torch.cuda.synchronize(dev)            # received lists complete before the library's stream reads them
+    if rslots.numel():                     # own entries are among them: atomicMax makes that a no-op
+        handler.alive_import_entries(rslots.data_ptr(), rvals.data_ptr(), rslots.numel())
+    lo, hi = hash_range(rank, world)
+    mine = handler.alive_count_range(lo, hi)   # synchronous: the received tensors may be freed after this
+    total = torch.tensor([mine], dtype=torch.int64, device=dev)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return int(total.item())

@@ -182,3 +182,64 @@ def test_variable_length_entry_gather_three_ranks():
         assert slots == [[0, 1, 2, 3, 4], [], [200, 201, 202]]
         assert vals == [[1, 2, 3, 4, 5], [], [3, 6, 9]]
         assert pad == [0, 0, 0]  # padding is value 0 == "never written"
+
+
+def _route_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank's "table": slots all over the 32-bit range, values ((seq+1)<<1)|alive with global seq
+        rng = np.random.default_rng(100 + rank)
+        n = [4000, 0, 2500][rank]
+        pool = np.unique(np.concatenate([np.random.default_rng(7).integers(0, 1 << 32, 6000, dtype=np.uint64),
+                                         np.array([0, (1 << 32) - 1, 1431655765, 1431655766, 2863311530, 2863311531],
+                                                  np.uint64)]))   # shared by the ranks: slots collide across shards
+        slots_u = rng.choice(pool, n, replace=False) if n else np.zeros(0, np.uint64)
+        seq = rng.permutation(20000)[:n].astype(np.uint64) * np.uint64(world) + np.uint64(rank)   # globally unique
+        vals_u = ((seq + np.uint64(1)) << np.uint64(1)) | rng.integers(0, 2, n, dtype=np.uint64)
+        slots = torch.from_numpy(slots_u.astype(np.uint32).view(np.int32).copy())
+        vals = torch.from_numpy(vals_u.view(np.int64).copy())
+        rs, rv = D.route_entries_by_hash_range(slots, vals)
+        lo, hi = D.hash_range(rank, world)
+        got_slots = rs.numpy().view(np.uint32).astype(np.uint64)
+        assert ((got_slots >= lo) & (got_slots < hi)).all()           # only my range arrives
+        merged = {}
+        for sl, v in zip(got_slots.tolist(), rv.numpy().view(np.uint64).tolist()):
+            merged[sl] = max(merged.get(sl, 0), v)                    # atomicMax import
+        mine = sum(v & 1 for v in merged.values())
+        total = torch.tensor([mine], dtype=torch.int64)
+        dist.all_reduce(total)
+        q.put((rank, slots_u.tolist(), vals_u.tolist(), int(total.item()), len(got_slots)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hash_range_exchange_counts_the_merged_alive_set_three_ranks():
+    """SURVEY section 8(e) option ii: entries travel to the owner of their hash range (all-to-all), the owner
+    merges by MAX and counts; the sum equals the alive count of the element-wise MAX of all tables."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_route_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    merged = {}
+    for _, slots, vals, _, _ in outs:
+        for sl, v in zip(slots, vals):
+            merged[sl] = max(merged.get(sl, 0), v)
+    want = sum(v & 1 for v in merged.values())
+    assert [o[3] for o in outs] == [want] * 3
+    assert sum(o[4] for o in outs) == sum(len(o[1]) for o in outs)   # every entry went to exactly one owner
+    for w in (1, 2, 3, 7, 8):                                         # ranges tile [0, 2^32) exactly
+        rs = [D.hash_range(r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == 1 << 32 and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        assert all((lo * w) >> 32 == r and ((hi - 1) * w) >> 32 == r for r, (lo, hi) in enumerate(rs))

@@ -64,6 +64,7 @@ res2, _ = h.finish()
 assert res2.alive_keys == o.alive_keys()
 ps, pv, ne = h.alive_export_entries()
 assert ne >= res2.alive_keys
+assert D.exchange_alive_by_hash_range(h, 0) == o.alive_keys()   # hash-range owner exchange (all-to-all) on RCCL
 h.close(); dist.destroy_process_group(); print("OK")
 '''
 

@@ -463,6 +463,15 @@ def test_alive_export_import_merges_partition_shards(hc):
     hc.alive_table_modified()
     res2, _ = hc.finish()                                    # and equals a recount of the merged table
     assert res2.alive_keys == o.alive_keys()
+    # per-hash-range counts (what the owners of a hash-range exchange report) tile the table, any bounds
+    from kafka_topic_analyzer_amd import distributed as D
+    for world in (1, 3, 8):
+        assert sum(hc.alive_count_range(*D.hash_range(r, world)) for r in range(world)) == o.alive_keys()
+    words = o.alive_words()
+    lo, hi = 0x40000001, 0x40000001 + 64 * 1000 + 7
+    bits = np.unpackbits(words[lo // 32:(hi + 31) // 32 + 1].view(np.uint8), bitorder="little")
+    assert hc.alive_count_range(lo, hi) == int(bits[lo % 32:lo % 32 + (hi - lo)].sum())
+    assert hc.alive_count_range(5, 5) == 0
     hc.device_batch_free(ba)
     # an empty table exports nothing
     hc.reset()
