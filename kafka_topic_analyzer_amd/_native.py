@@ -86,7 +86,7 @@ class KtaKafkaIndexStats(C.Structure):
                 ("n_compressed", C.c_uint64), ("n_snappy", C.c_uint64), ("n_lz4", C.c_uint64),
                 ("inflate_bytes", C.c_uint64),
                 ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
-                ("bytes_consumed", C.c_uint64)]
+                ("bytes_consumed", C.c_uint64), ("n_gzip", C.c_uint64), ("n_zstd", C.c_uint64)]
 
 
 # every symbol include/kta_hip.h, kta_synth.h and kta_kafka.h declare: (restype, argtypes)
@@ -135,6 +135,7 @@ SIGNATURES = {
     "kta_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(KtaSynthSpec), C.POINTER(C.c_uint64)]),
     "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_gzip_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_lz4_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_snappy_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,

@@ -12,6 +12,7 @@
 #include "../../include/kta_synth.h"
 #include "kta_snappy.h"
 #include "kta_lz4.h"
+#include "kta_gzip.h"
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -396,16 +397,19 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
 // The inflated records land in the batch's slice of the inflate area, which is part of the same
 // device buffer as the raw blob, so key offsets stay valid for the zero-copy alive-key pass.
 __global__ __launch_bounds__(kLanesPerBlock) void kafka_inflate_lane(uint8_t *buffer, kta_kafka_batch_desc *descs,
-                                                                      uint64_t n_batches)
+                                                                      uint64_t n_batches, uint32_t codecs)
 {
     const uint64_t b = (uint64_t)blockIdx.x * kLanesPerBlock + threadIdx.x;
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
-    if (!(d.flags & (KTA_KB_SNAPPY | KTA_KB_LZ4)) || d.status) return;
+    if (!(d.flags & codecs) || d.status) return;       // `codecs`: the KTA_KB_* codecs this launch handles
     const uint8_t *src = buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER;
     const uint64_t n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, cap = d.payload_end - d.payload_off;
     if (d.flags & KTA_KB_SNAPPY) {
         const int64_t got = kta::snappy_inflate(src, n, buffer + d.payload_off, cap);
+        if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;
+    } else if (d.flags & KTA_KB_GZIP) {                // the trailer told the size: it must come out exactly
+        const int64_t got = kta::gzip_inflate(src, n, buffer + d.payload_off, cap);
         if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;
     } else {
         const int64_t got = kta::lz4_inflate(src, n, buffer + d.payload_off, cap);   // cap is only a bound
@@ -945,8 +949,13 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                 if (inflated > (int64_t)(clen * 22 + 64)) inflated = -1;
             }
             if (codec == 3) inflated = kta::lz4_inflate_bound(bytes + pos + KTA_KAFKA_BATCH_HEADER, total - KTA_KAFKA_BATCH_HEADER);
+            if (codec == 1) {
+                const uint64_t clen = total - KTA_KAFKA_BATCH_HEADER;
+                inflated = kta::gzip_uncompressed_len(bytes + pos + KTA_KAFKA_BATCH_HEADER, clen);
+                if (inflated > (int64_t)(clen * 1032 + 64)) inflated = -1;   // DEFLATE expands at most 1032x
+            }
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
-            else if (codec != 0 && codec != 2 && codec != 3) stats->n_compressed++;   // gzip / zstd: not decoded here
+            else if (codec > 3) stats->n_compressed++;                    // zstd (4) and unknown codecs: not decoded here
             else if (count > 0) {
                 if (nb < cap) {
                     kta_kafka_batch_desc &d = descs[nb];
@@ -961,8 +970,8 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     d.partition = partition;
                     d.n_records = count;
                     d.flags = ((attrs & 0x08) ? KTA_KB_LOG_APPEND_TIME : 0u) | ((attrs & 0x10) ? KTA_KB_TRANSACTIONAL : 0u);
-                    if (codec == 2 || codec == 3) {
-                        d.flags |= codec == 2 ? KTA_KB_SNAPPY : KTA_KB_LZ4;
+                    if (codec != 0) {
+                        d.flags |= codec == 2 ? KTA_KB_SNAPPY : (codec == 3 ? KTA_KB_LZ4 : KTA_KB_GZIP);
                         if (inflated < 0) {          // malformed stream: nothing to parse, reported as bad
                             d.status = KTA_KB_BAD_FRAMING;
                             inflated = 0;
@@ -974,9 +983,10 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                         d.payload_end = d.byte_off + total;
                     }
                 }
-                if (codec == 2 || codec == 3) {
+                if (codec != 0) {
                     if (codec == 2) stats->n_snappy++;
-                    else stats->n_lz4++;
+                    else if (codec == 3) stats->n_lz4++;
+                    else stats->n_gzip++;
                     inflate += ((uint64_t)(inflated > 0 ? inflated : 0) + 63) & ~63ull;   // 64-byte aligned slices
                 }
                 nb++;
@@ -997,6 +1007,12 @@ int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint6
 {
     if (!src || (!dst && cap)) return -1;
     return kta::lz4_inflate(src, n, dst, cap);
+}
+
+int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
+    return kta::gzip_inflate(src, n, dst, cap);
 }
 
 int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
@@ -1068,20 +1084,22 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipGetLastError());
         if (timing) KK(ctx, hipEventRecord(b, s));
     }
-    bool any_snappy = false, any_lz4 = false;
+    bool any_snappy = false, any_lz4 = false, any_gzip = false;
     uint64_t buffer_end = blob_len;
     for (uint64_t i = 0; i < n_batches; i++)
-        if (descs_host[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4)) {
+        if (descs_host[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4 | KTA_KB_GZIP)) {
             any_snappy = any_snappy || (descs_host[i].flags & KTA_KB_SNAPPY);
             any_lz4 = any_lz4 || (descs_host[i].flags & KTA_KB_LZ4);
+            any_gzip = any_gzip || (descs_host[i].flags & KTA_KB_GZIP);
             if (descs_host[i].payload_end > buffer_end) buffer_end = descs_host[i].payload_end;
         }
     if (want_keys && buffer_end >= (1ull << 32)) {
         kta_internal_set_error(ctx, "blob + inflate area must be < 4 GiB when key offsets are wanted (key_off is u32)");
         return KTA_ERR_CAPACITY;
     }
-    if (any_snappy || any_lz4) {   // inflate compressed batches into their slices of the same buffer
+    if (any_snappy || any_lz4 || any_gzip) {   // inflate compressed batches into their slices of the same buffer
         uint8_t *buf = const_cast<uint8_t *>(blob_device);
+        uint32_t lane_codecs = any_gzip ? KTA_KB_GZIP : 0u;   // DEFLATE is bit-serial: always one lane per batch
         if (g_decode_variant != 1) {
             if (any_snappy)
                 hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
@@ -1090,8 +1108,11 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
                 hipLaunchKernelGGL(kafka_lz4_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
                                    n_batches);
         } else {
-            hipLaunchKernelGGL(kafka_inflate_lane, dim3(grid), dim3(kLanesPerBlock), 0, s, buf, st->d_descs, n_batches);
+            lane_codecs |= KTA_KB_SNAPPY | KTA_KB_LZ4;
         }
+        if (lane_codecs)
+            hipLaunchKernelGGL(kafka_inflate_lane, dim3(grid), dim3(kLanesPerBlock), 0, s, buf, st->d_descs, n_batches,
+                               lane_codecs);
         KK(ctx, hipGetLastError());
     }
     if (timing) { int rc = pair(ctx, st, 1, &a, &b); if (rc != KTA_OK) return rc; KK(ctx, hipEventRecord(a, s)); }
@@ -1263,6 +1284,7 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         stats->n_compressed += one.n_compressed;
         stats->n_snappy += one.n_snappy;
         stats->n_lz4 += one.n_lz4;
+        stats->n_gzip += one.n_gzip;
         stats->inflate_bytes += one.inflate_bytes;
         stats->n_old_magic += one.n_old_magic;
         stats->bytes_consumed += one.bytes_consumed;

@@ -17,6 +17,7 @@
 
 int64_t kto_snappy_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
 int64_t kto_lz4_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
+int64_t kto_gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap);
 
 typedef struct {
     uint64_t control_batches, compressed_batches, old_magic_batches, trailing_bytes, bad_batches, batches;
@@ -62,7 +63,7 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (b[16] != 2) { st->old_magic_batches++; pos += total; continue; }
         uint16_t attrs = (uint16_t)rd_be(b + 21, 2);
         if (attrs & 0x20) { st->control_batches++; pos += total; continue; }
-        if ((attrs & 0x07) != 0 && (attrs & 0x07) != 2 && (attrs & 0x07) != 3) { st->compressed_batches++; pos += total; continue; }
+        if ((attrs & 0x07) > 3) { st->compressed_batches++; pos += total; continue; }   /* zstd: not decoded */
         int64_t base_offset = (int64_t)rd_be(b, 8);
         int64_t base_ts = (int64_t)rd_be(b + 27, 8), max_ts = (int64_t)rd_be(b + 35, 8);
         int32_t count = (int32_t)rd_be(b + 57, 4);
@@ -71,11 +72,12 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         const uint8_t *p = b + 61;
         int bad = 0;
         uint8_t *inflated = NULL;
-        if ((attrs & 0x07) == 2 || (attrs & 0x07) == 3) { /* Snappy / LZ4: the records section is compressed as a whole */
-            uint64_t cap = (total - 61) * 300 + (1u << 22);
+        if ((attrs & 0x07) != 0) { /* gzip / Snappy / LZ4: the records section is compressed as a whole */
+            uint64_t cap = (total - 61) * 1100 + (1u << 22);
             inflated = (uint8_t *)malloc((size_t)cap);
             int64_t got = (attrs & 0x07) == 2 ? kto_snappy_inflate(b + 61, total - 61, inflated, cap)
-                                              : kto_lz4_inflate(b + 61, total - 61, inflated, cap);
+                        : (attrs & 0x07) == 3 ? kto_lz4_inflate(b + 61, total - 61, inflated, cap)
+                                              : kto_gzip_inflate(b + 61, total - 61, inflated, cap);
             if (got < 0) { bad = 1; got = 0; }
             p = inflated;
             bend = inflated + got;
@@ -277,4 +279,25 @@ int64_t kto_lz4_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t c
         if (flg & 0x10) i += 4; /* block checksum */
     }
     return (int64_t)o;
+}
+
+
+/* ---- gzip (Kafka codec 1) -----------------------------------------------------------------------
+ * Not a restatement: the oracle hands the member to zlib itself (inflateInit2 with windowBits 15 + 16 =
+ * gzip wrapper, header and CRC-32 / ISIZE trailer checked by zlib), the library every Kafka client uses
+ * for this codec.  Like the product, exactly one member is accepted. */
+#include <zlib.h>
+int64_t kto_gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return -1;
+    z.next_in = (Bytef *)src;
+    z.avail_in = (uInt)n;
+    z.next_out = out;
+    z.avail_out = (uInt)(cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : cap);
+    int rc = inflate(&z, Z_FINISH);
+    int64_t got = (rc == Z_STREAM_END && z.avail_in == 0) ? (int64_t)z.total_out : -1;
+    inflateEnd(&z);
+    return got;
 }

@@ -37,7 +37,7 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             attrs = 0x20 | 0x10  # control batch (transactional marker): skipped
             info["control"] += 1
         elif kind < 0.10:
-            attrs = int(rng.choice([1, 4]))  # gzip / zstd: skipped (payload is not really compressed)
+            attrs = 4  # zstd: skipped (payload is not really compressed)
             info["compressed"] += 1
         elif kind < 0.2:
             attrs = 0x08  # LogAppendTime: every record carries maxTimestamp
@@ -48,12 +48,14 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             info["batches"] += 1
         mt = max_ts if max_ts is not None else max(base_ts + r[0] for r in recs)
         comp = None
-        if snappy and attrs & 0x27 == 0 and rng.random() < 0.6:  # Snappy / LZ4 batches, all framings
-            comp = str(rng.choice(["snappy", "snappy-xerial", "lz4", "lz4-indep"]))
-            kind_key = "snappy" if comp.startswith("snappy") else "lz4"
+        if snappy and attrs & 0x27 == 0 and rng.random() < 0.6:  # gzip / Snappy / LZ4 batches, all framings
+            comp = str(rng.choice(["snappy", "snappy-xerial", "lz4", "lz4-indep", "gzip", "gzip-fixed", "gzip-stored",
+                                   "gzip-named"]))
+            kind_key = comp.split("-")[0]
             info[kind_key] = info.get(kind_key, 0) + 1
         blob += K.encode_batch(offset, recs, base_ts, attributes=attrs, max_ts=mt, compression=comp)
-        batches.append((base_ts, attrs | (0 if not comp else (2 if comp.startswith("snappy") else 3)), mt, recs))
+        codec = 0 if not comp else {"gzip": 1, "snappy": 2, "lz4": 3}[comp.split("-")[0]]
+        batches.append((base_ts, attrs | codec, mt, recs))
         offset += n
         if with_noise and rng.random() < 0.03:  # an old-format (magic 1) message set: skipped
             blob += K.encode_batch(offset, [(0, b"old", b"fmt")], base_ts, magic=1)

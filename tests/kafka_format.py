@@ -61,13 +61,35 @@ def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, produ
     compression: None, "snappy" (one bare block, as librdkafka writes), "snappy-xerial" (snappy-java
     stream framing, as the Java clients write) -> codec 2; "lz4" (LZ4 frame, linked 64 KiB blocks, as
     librdkafka's LZ4F defaults) or "lz4-indep" (independent blocks + block checksums + content size,
-    as the Java client's KafkaLZ4BlockOutputStream can) -> codec 3.  The records section is compressed."""
+    as the Java client's KafkaLZ4BlockOutputStream can) -> codec 3; "snappy-lib" / "lz4-lib": the same
+    two codecs from the real libraries (Google snappy, lz4 frame) through pyarrow; "gzip" (zlib level 6:
+    dynamic Huffman blocks), "gzip-fixed" (Z_FIXED), "gzip-stored" (level 0), "gzip-named" (GzipFile with
+    a file name in the header) -> codec 1.  The records section is compressed."""
     recs = b"".join(encode_record(i, r[0], r[1], r[2], r[3] if len(r) > 3 else ()) for i, r in enumerate(records)) \
         if raw_records is None else raw_records
     if compression in ("snappy", "snappy-xerial"):
         import snappy_py
         recs = snappy_py.compress_block(recs) if compression == "snappy" else snappy_py.compress_xerial(recs, 4096)
         attributes = (attributes & ~0x07) | 2
+    elif compression in ("gzip", "gzip-fixed", "gzip-stored", "gzip-named"):
+        import gzip as _gzip
+        import io
+        import zlib
+        if compression == "gzip-named":          # FNAME + MTIME header fields, as GzipFile writes them
+            f = io.BytesIO()
+            with _gzip.GzipFile(filename="records.bin", mode="wb", fileobj=f, mtime=1600000000) as g:
+                g.write(recs)
+            recs = f.getvalue()
+        else:
+            level = 0 if compression == "gzip-stored" else 6
+            strategy = zlib.Z_FIXED if compression == "gzip-fixed" else zlib.Z_DEFAULT_STRATEGY
+            co = zlib.compressobj(level, zlib.DEFLATED, 15 + 16, 8, strategy)
+            recs = co.compress(recs) + co.flush()
+        attributes = (attributes & ~0x07) | 1
+    elif compression in ("snappy-lib", "lz4-lib"):
+        import pyarrow as pa
+        recs = pa.compress(recs, codec=compression[:-4], asbytes=True)
+        attributes = (attributes & ~0x07) | (2 if compression == "snappy-lib" else 3)
     elif compression in ("lz4", "lz4-indep"):
         import lz4_py
         recs = lz4_py.compress_frame(recs) if compression == "lz4" else \
@@ -86,7 +108,7 @@ def expected_columns(partition, batches):
     """batches: [(base_ts, attributes, max_ts, records)] -> the columns a consumer would deliver."""
     part, klen, vlen, ts, keys = [], [], [], [], []
     for base_ts, attributes, max_ts, records in batches:
-        if attributes & 0x20 or (attributes & 0x07) not in (0, 2, 3):   # control, or a codec that is not decoded
+        if attributes & 0x20 or (attributes & 0x07) not in (0, 1, 2, 3):   # control, or a codec that is not decoded
             continue
         for r in records:
             part.append(partition)

@@ -303,13 +303,14 @@ def test_host_index_sizes_compressed_batches():
     blob, expected, info = random_record_set(rng, 60, snappy=True)
     rc, descs, st = index_host(blob, 3)
     assert rc == N.KTA_OK and st.n_snappy == info["snappy"] > 0 and st.n_lz4 == info["lz4"] > 0
+    assert st.n_gzip == info["gzip"] > 0
     cols, ost = kafka_decode(blob, 3)
     assert_columns(cols, expected)
     inflate_at = (len(blob) + 127) & ~63
     run = 0
     for i in range(st.n_batches):
         d = descs[i]
-        if d.flags & (4 | 8):  # KTA_KB_SNAPPY / KTA_KB_LZ4: a 64-byte aligned slice of the inflate area
+        if d.flags & (4 | 8 | 16):  # KTA_KB_SNAPPY / _LZ4 / _GZIP: a 64-byte aligned slice of the inflate area
             assert d.payload_off == inflate_at + run and d.payload_off % 64 == 0
             if d.flags & 8:    # LZ4 frames do not carry their size: the slice is a bound (<= 255x per block)
                 clen = d.batch_bytes - 61
@@ -351,19 +352,127 @@ def test_lz4_inflate_host_matches_oracle_and_python():
     assert L.kto_lz4_inflate(bad_off, len(bad_off), out, 8192) == -1
 
 
+def test_gzip_inflate_host_against_zlib():
+    """The product's DEFLATE decoder (the function the device runs, compiled for the host) on members
+    written by zlib at every level and strategy, by GzipFile (FNAME header) and by pyarrow; the oracle
+    inflates with zlib itself."""
+    import ctypes as C2
+    import gzip
+    import io
+    import zlib
+    from oracle_c import lib as olib
+    L = olib()
+    L.kto_gzip_inflate.restype = C2.c_int64
+    L.kto_gzip_inflate.argtypes = [C2.c_char_p, C2.c_uint64, C2.c_char_p, C2.c_uint64]
+    lib = N.load()
+
+    def check(comp, d):
+        out1, out2 = C2.create_string_buffer(len(d) + 1), C2.create_string_buffer(len(d) + 1)
+        assert lib.kta_gzip_inflate_host(comp, len(comp), out1, len(d)) == len(d)
+        assert L.kto_gzip_inflate(comp, len(comp), out2, len(d)) == len(d)
+        assert out1.raw[:len(d)] == d == out2.raw[:len(d)]
+
+    for d in _library_cases():
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                co = zlib.compressobj(level, zlib.DEFLATED, 15 + 16, 8, strategy)
+                check(co.compress(d) + co.flush(), d)
+        co = zlib.compressobj(6, zlib.DEFLATED, 15 + 16)      # several deflate blocks: sync flushes in the middle
+        third = len(d) // 3
+        check(co.compress(d[:third]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(d[third:2 * third]) +
+              co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[2 * third:]) + co.flush(), d)
+        f = io.BytesIO()
+        with gzip.GzipFile(filename="some-name.bin", mode="wb", fileobj=f, mtime=12345) as g:
+            g.write(d)
+        check(f.getvalue(), d)
+    pa = pytest.importorskip("pyarrow")
+    for d in _library_cases():
+        check(pa.compress(d, codec="gzip", asbytes=True), d)
+    # malformed members are refused: truncation, wrong magic, a second member, a corrupted code, short output
+    d = b"".join(b"key-%d value-%d;" % (i % 97, i) for i in range(3000))
+    good = gzip.compress(d, mtime=0)
+    out = C2.create_string_buffer(len(d) + 64)
+    assert lib.kta_gzip_inflate_host(good, len(good), out, len(d)) == len(d)
+    assert lib.kta_gzip_inflate_host(good[:-20], len(good) - 20, out, len(d)) == -1
+    assert lib.kta_gzip_inflate_host(b"\x1f\x8c" + good[2:], len(good), out, len(d)) == -1
+    assert lib.kta_gzip_inflate_host(good + good, 2 * len(good), out, len(d) + 64) == -1
+    assert lib.kta_gzip_inflate_host(good, len(good), out, 100) == -1
+    rng = np.random.default_rng(5)
+    refused = 0
+    for _ in range(200):                                       # flipped bits never crash and never write past `cap`
+        bad = bytearray(good)
+        bad[int(rng.integers(10, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
+        guard = C2.create_string_buffer(len(d) + 64)
+        got = lib.kta_gzip_inflate_host(bytes(bad), len(bad), guard, len(d))
+        assert got in (-1, len(d)) and guard.raw[len(d):] == bytes(64)
+        refused += got == -1
+    assert refused > 50
+
+
+def _library_cases():
+    rng = np.random.default_rng(17)
+    text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(40000))
+    return [b"", b"a", b"abcd" * 1000, bytes(rng.integers(0, 256, size=70000, dtype=np.uint8)), b"\0" * 300000,
+            bytes(rng.integers(0, 4, size=200000, dtype=np.uint8)), text,
+            text[:100000] + bytes(rng.integers(0, 256, size=90000, dtype=np.uint8)) + text[:100000]]
+
+
+def test_inflaters_against_the_real_snappy_and_lz4_libraries():
+    """Streams written by Google's snappy and by liblz4 (LZ4 frame), through pyarrow: a third-party pin for
+    the product's inflaters (same functions the device runs) and for the oracle's."""
+    pa = pytest.importorskip("pyarrow")
+    import ctypes as C2
+    from oracle_c import lib as olib
+    L = olib()
+    lib = N.load()
+    for name, mine, theirs in (("snappy", lib.kta_snappy_inflate_host, L.kto_snappy_inflate),
+                               ("lz4", lib.kta_lz4_inflate_host, L.kto_lz4_inflate)):
+        theirs.restype = C2.c_int64
+        theirs.argtypes = [C2.c_char_p, C2.c_uint64, C2.c_char_p, C2.c_uint64]
+        for d in _library_cases():
+            comp = pa.compress(d, codec=name, asbytes=True)
+            out1, out2 = C2.create_string_buffer(len(d) + 1), C2.create_string_buffer(len(d) + 1)
+            assert mine(comp, len(comp), out1, len(d)) == len(d), (name, len(d))
+            assert theirs(comp, len(comp), out2, len(d)) == len(d), (name, len(d))
+            assert out1.raw[:len(d)] == d == out2.raw[:len(d)]
+
+
+@pytest.mark.gpu
+def test_device_inflates_streams_of_the_real_libraries():
+    pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(23)
+    cases = _library_cases()
+    recs = [(i, b"k%d" % i, cases[3 + i % 5][: 3000 + 9000 * i]) for i in range(12)] + [(12, None, cases[6][:150000])]
+    blob = b"".join(K.encode_batch(100 * i, recs[i % 3:], 1_600_000_000_000 + i, compression=c)
+                    for i, c in enumerate(["snappy-lib", "lz4-lib", None, "lz4-lib", "snappy-lib"]))
+    want, _ = kafka_decode(blob, 2)
+    lib = N.load()
+    for variant in (0, 1):
+        lib.kta_kafka_set_variant(variant)
+        with kta.HipMetricHandler(4, now=NOW) as h:
+            cols, st, bad = _decode_on_device(h, blob, 2, True)
+            assert bad == 0 and st.n_snappy == 2 and st.n_lz4 == 2
+            for k in ("partition", "key_len", "val_len", "ts_ms"):
+                assert np.array_equal(cols[k], want[k]), k
+            kb = cols["key_bytes"].tobytes()
+            o = int(cols["key_off"][0])                       # first record of the first (snappy) batch: key, value follow
+            assert kb[o:o + 2] == b"k0" and recs[0][2] in kb[o:o + len(recs[0][2]) + 16]
+    lib.kta_kafka_set_variant(0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 3, 5])
 def test_device_decodes_snappy_batches(variant):
     rng = np.random.default_rng(33)
     blob, expected, info = random_record_set(rng, 160, max_records=120, snappy=True)
-    assert info["snappy"] > 20 and info["lz4"] > 20
+    assert info["snappy"] > 10 and info["lz4"] > 10 and info["gzip"] > 20
     want, _ = kafka_decode(blob, 3)
     lib = N.load()
     lib.kta_kafka_set_variant(variant)
     with kta.HipMetricHandler(8, now=NOW) as h:
         h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))   # the CRC covers the compressed bytes
         cols, st, bad = _decode_on_device(h, blob, 3, True)
-        assert bad == 0 and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"]
+        assert bad == 0 and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"] and st.n_gzip == info["gzip"]
         assert_columns(cols, expected, key_check=True)
         for k in ("partition", "key_len", "val_len", "ts_ms"):
             assert np.array_equal(cols[k], want[k]), k
@@ -443,6 +552,7 @@ def test_consume_snappy_record_sets_end_to_end():
             h._check(lib.kta_kafka_consume(h._ctx, blob, len(blob), part, C.byref(st)))
             cols, _ = kafka_decode(blob, part)
             assert st.n_records == len(cols["partition"]) and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"]
+            assert st.n_gzip == info.get("gzip", 0)
             o.run_soa({k: v for k, v in cols.items() if k != "offset"})
         res, c = h.finish()
         assert np.array_equal(c, o.counters(P))
