@@ -145,6 +145,24 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     return out
 
 
+def _gzip_batches(lib, raw):
+    """Re-encode uncompressed v2 batches as gzip batches (codec 1): records section through zlib, header
+    lengths and CRC-32C redone."""
+    import zlib
+    out, pos = bytearray(), 0
+    while pos + 61 <= len(raw):
+        total = 12 + int.from_bytes(raw[pos + 8:pos + 12], "big")
+        b = raw[pos:pos + total]
+        co = zlib.compressobj(6, zlib.DEFLATED, 15 + 16)
+        comp = co.compress(b[61:]) + co.flush()
+        attrs = int.from_bytes(b[21:23], "big") | 1
+        after_crc = attrs.to_bytes(2, "big") + b[23:61] + comp
+        crc = lib.kta_crc32c_host(after_crc, len(after_crc))
+        out += b[0:8] + (49 + len(comp)).to_bytes(4, "big") + b[12:17] + crc.to_bytes(4, "big") + after_crc
+        pos += total
+    return bytes(out)
+
+
 def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     """The step before the hot path: raw Kafka v2 record batches -> columns, on the GPU."""
     import numpy as np
@@ -217,10 +235,16 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     # compressed record sets: inflate + decode (wall time of the device work, keys zero-copy)
     rep["compressed"] = {}
     nc = min(n_records, 1_000_000)
-    for codec, name in ((2, "snappy"), (3, "lz4")):
-        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, codec, None, 0, C.byref(ln))
+    for codec, name in ((2, "snappy"), (3, "lz4"), (1, "gzip")):
+        enc = codec if codec != 1 else 0x100   # gzip: zlib (level 6) over the uncompressed, patterned batches
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, None, 0, C.byref(ln))
         cbuf = np.zeros(ln.value + 128, np.uint8)
-        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, codec, cbuf.ctypes.data, ln.value, C.byref(ln))
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, cbuf.ctypes.data, ln.value, C.byref(ln))
+        if codec == 1:
+            gz = _gzip_batches(lib, cbuf[:ln.value].tobytes())
+            cbuf = np.zeros(len(gz) + 128, np.uint8)
+            cbuf[:len(gz)] = np.frombuffer(gz, np.uint8)
+            ln.value = len(gz)
         inflate_at = (ln.value + 127) & ~63
         cdescs = (N.KtaKafkaBatchDesc * (nc // rpb + 2))()
         cst = N.KtaKafkaIndexStats()

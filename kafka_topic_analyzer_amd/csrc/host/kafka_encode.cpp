@@ -165,6 +165,8 @@ extern "C" int kta_kafka_encode_synth_host(const kta_synth_spec *spec, uint64_t 
 extern "C" int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64_t first, uint64_t n, uint32_t records_per_batch,
                                    int codec, uint8_t *out, uint64_t cap, uint64_t *len)
 {
+    const bool patterned = codec != 0;   // 0x100: uncompressed, but with the value pattern of the compressed forms
+    codec &= 0xFF;
     if (!spec || !len || records_per_batch == 0 || (codec != 0 && codec != 2 && codec != 3)) return KTA_ERR_INVALID;
     std::vector<uint8_t> packed;
     uint64_t pos = 0;
@@ -203,7 +205,7 @@ extern "C" int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64
                 q += klb;
             }
             memcpy(q, vh, vhn);                             // value bytes + the 0 headersCount are already zero
-            if (codec != 0 && vlb) {                        // a periodic pattern: compressible, but with real copies
+            if (patterned && vlb) {                         // a periodic pattern: compressible, but with real copies
                 const uint64_t seed = kta_mix64(first + b0 + j);
                 for (size_t x = 0; x < vlb; x++) q[vhn + x] = (uint8_t)(kta_mix64(seed + (x % 24)) >> 7);
             }
