@@ -337,9 +337,14 @@ def main():
     n_sum = D.sum_prefix_len(P)
 
     if exchange:
-        # run the library on torch's stream: scan, fold and the two all-reduces are then stream-ordered and
-        # a step needs no host synchronisation at all
-        h.use_stream(torch.cuda.current_stream().cuda_stream)
+        # Run the library on a torch stream: scan, fold and the two all-reduces are then stream-ordered
+        # (ProcessGroupNCCL orders its internal stream against the CURRENT torch stream with events) and a
+        # step needs no host synchronisation at all.  It must be a created stream: torch's default stream
+        # is the null stream, whose handle 0 means "restore the library's own stream" to kta_set_compute_stream.
+        stream = torch.cuda.Stream(device=local_rank)
+        assert stream.cuda_stream != 0
+        torch.cuda.set_stream(stream)
+        h.use_stream(stream.cuda_stream)
 
     def step():
         """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
@@ -373,7 +378,15 @@ def main():
         elapsed = float(t.item())
 
     if exchange:
+        # the exchange result itself: after one more step every rank must hold the whole job's totals
+        step()
+        barrier()
+        totals = vec[0:P * N.KTA_NCOUNTERS:N.KTA_NCOUNTERS]
+        got = int(totals.sum().item())
+        assert got == n * world, "exchange step lost records: %d != %d" % (got, n * world)
+        assert int(vec[P * N.KTA_NCOUNTERS + N.KTA_G_RECORDS].item()) == n * world
         h.use_stream(None)
+        torch.cuda.set_stream(torch.cuda.default_stream(local_rank))
     # sanity inside the bench: a single fresh pass must count exactly n records on this rank
     h.reset()
     h.submit_device(batch, n, 0, which=1)

@@ -189,7 +189,9 @@ int kta_copy_to_host(kta_ctx *ctx, void *dst_host, const void *src_device, size_
 
 /* Run the context's kernels on a caller-owned HIP stream (e.g. the stream RCCL collectives are issued
  * on), so that submit -> collective -> next submit needs no host synchronisation.  NULL restores the
- * context's own compute stream.  The stream must belong to the context's device and outlive its use. */
+ * context's own compute stream — so the null (default) stream, whose handle is 0, cannot be selected:
+ * pass a created stream (PyTorch: a torch.cuda.Stream, not the default stream).  The stream must belong to
+ * the context's device and outlive its use. */
 int kta_set_compute_stream(kta_ctx *ctx, void *hip_stream);
 
 /* ---- results --------------------------------------------------------------------- */

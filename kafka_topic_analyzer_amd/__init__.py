@@ -222,7 +222,8 @@ class HipMetricHandler:
 
     # ------------------------------------------------------------------ results
     def use_stream(self, hip_stream: Optional[int]) -> None:
-        """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None restores."""
+        """Run on a caller-owned, CREATED HIP stream (e.g. torch.cuda.Stream().cuda_stream; torch's default
+        stream is the null stream, handle 0, which means "restore" here); None restores."""
         self._check(self._lib.kta_set_compute_stream(self._ctx, C.c_void_p(hip_stream) if hip_stream else None))
 
     def sync(self) -> None:
