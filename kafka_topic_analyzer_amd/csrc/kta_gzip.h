@@ -118,8 +118,10 @@ KTA_GZIP_HD int gz_build(GzCode &c, uint16_t *work, uint32_t stride, uint32_t le
 #pragma unroll
     for (int l = 1; l < 16; l++) {
         const uint32_t cnt = count[l * stride];
-        left = (left << 1) - (int)cnt;
-        if (left < 0) over = true;
+        if (!over) {
+            left = (left << 1) - (int)cnt;
+            if (left < 0) over = true;
+        }
         c.limit[l] = over ? 0u : (first + cnt) << (15 - l);
         c.base[l] = (int32_t)index - (int32_t)first;
         count[l * stride] = (uint16_t)index;           // becomes the running offset of this length's symbols

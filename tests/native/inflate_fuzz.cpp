@@ -1,0 +1,87 @@
+// inflate_fuzz.cpp — TEST HARNESS: the product's inflaters (csrc/kta_snappy.h, kta_lz4.h, kta_gzip.h — the
+// very functions the device kernels run, compiled here for the host) under AddressSanitizer on mutated
+// streams.  Input and output live in exact-size heap blocks, so any read past the input or write past
+// `cap` aborts.  A malformed batch on the GPU must be "reported, never mis-decoded" — and must never
+// fault the device.
+//   inflate_fuzz <codec: snappy|lz4|gzip> <seed-file>... ; prints "<codec> ok=<n> refused=<n>"
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kta_gzip.h"
+#include "kta_lz4.h"
+#include "kta_snappy.h"
+
+namespace {
+
+uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+uint64_t rnd()
+{
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state;
+}
+
+int64_t run(const std::string &codec, const std::vector<uint8_t> &in, uint64_t cap)
+{
+    uint8_t *src = (uint8_t *)malloc(in.size() ? in.size() : 1);   // exact size: over-reads are caught
+    memcpy(src, in.data(), in.size());
+    uint8_t *dst = (uint8_t *)malloc(cap ? cap : 1);               // exact size: over-writes are caught
+    int64_t got;
+    if (codec == "snappy") got = kta::snappy_inflate(src, in.size(), dst, cap);
+    else if (codec == "lz4") got = kta::lz4_inflate(src, in.size(), dst, cap);
+    else {
+        uint16_t work[kta::GZ_WORK];
+        got = kta::gzip_inflate(src, in.size(), dst, cap, work, 1);
+    }
+    if (got > (int64_t)cap) { fprintf(stderr, "produced %lld > cap %llu\n", (long long)got, (unsigned long long)cap); abort(); }
+    free(src);
+    free(dst);
+    return got;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 64;
+    const std::string codec = argv[1];
+    uint64_t ok = 0, refused = 0;
+    for (int a = 2; a < argc; a++) {
+        FILE *f = fopen(argv[a], "rb");
+        if (!f) return 65;
+        std::vector<uint8_t> seed;
+        uint8_t buf[65536];
+        size_t r;
+        while ((r = fread(buf, 1, sizeof buf, f)) > 0) seed.insert(seed.end(), buf, buf + r);
+        fclose(f);
+        // the file: u64 uncompressed length, then the stream
+        uint64_t want = 0;
+        memcpy(&want, seed.data(), 8);
+        seed.erase(seed.begin(), seed.begin() + 8);
+        if (run(codec, seed, want) != (int64_t)want) { fprintf(stderr, "seed %s does not inflate\n", argv[a]); return 66; }
+        if (want && run(codec, seed, want - 1) >= 0 && codec != "lz4") { fprintf(stderr, "short buffer accepted\n"); return 67; }
+        for (int it = 0; it < 1500; it++) {
+            std::vector<uint8_t> m = seed;
+            const int kind = (int)(rnd() % 5);
+            if (m.empty()) break;
+            if (kind == 0) m[rnd() % m.size()] ^= (uint8_t)(1u << (rnd() % 8));                  // bit flip
+            else if (kind == 1) m[rnd() % m.size()] = (uint8_t)rnd();                          // byte set
+            else if (kind == 2) m.resize(rnd() % m.size());                                      // truncation
+            else if (kind == 3) for (int k = 0; k < 8; k++) m[rnd() % m.size()] = (uint8_t)rnd();   // several bytes
+            else { const size_t at = rnd() % m.size(); m.insert(m.begin() + at, (uint8_t)rnd()); }   // insertion
+            // capacities around the truth: exact, smaller, larger (LZ4 treats cap as a bound)
+            const uint64_t caps[3] = {want, want / 2, want + 4096};
+            const int64_t got = run(codec, m, caps[rnd() % 3]);
+            if (got < 0) refused++;
+            else ok++;
+        }
+    }
+    printf("%s ok=%llu refused=%llu\n", codec.c_str(), (unsigned long long)ok, (unsigned long long)refused);
+    return 0;
+}
