@@ -145,22 +145,32 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     return out
 
 
-def _gzip_batches(lib, raw):
-    """Re-encode uncompressed v2 batches as gzip batches (codec 1): records section through zlib, header
-    lengths and CRC-32C redone."""
+def _recompress_batches(lib, raw, codec):
+    """Re-encode uncompressed v2 batches as gzip (codec 1: zlib level 6) or zstd (codec 4: libzstd level 3
+    through pyarrow) batches: records section compressed, header lengths and CRC-32C redone."""
     import zlib
+    if codec == 4:
+        import pyarrow as pa
+        zstd = pa.Codec("zstd", compression_level=3)
     out, pos = bytearray(), 0
     while pos + 61 <= len(raw):
         total = 12 + int.from_bytes(raw[pos + 8:pos + 12], "big")
         b = raw[pos:pos + total]
-        co = zlib.compressobj(6, zlib.DEFLATED, 15 + 16)
-        comp = co.compress(b[61:]) + co.flush()
-        attrs = int.from_bytes(b[21:23], "big") | 1
+        if codec == 1:
+            co = zlib.compressobj(6, zlib.DEFLATED, 15 + 16)
+            comp = co.compress(b[61:]) + co.flush()
+        else:
+            comp = zstd.compress(b[61:], asbytes=True)
+        attrs = int.from_bytes(b[21:23], "big") | codec
         after_crc = attrs.to_bytes(2, "big") + b[23:61] + comp
         crc = lib.kta_crc32c_host(after_crc, len(after_crc))
         out += b[0:8] + (49 + len(comp)).to_bytes(4, "big") + b[12:17] + crc.to_bytes(4, "big") + after_crc
         pos += total
     return bytes(out)
+
+
+def _gzip_batches(lib, raw):
+    return _recompress_batches(lib, raw, 1)
 
 
 def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
@@ -235,13 +245,19 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     # compressed record sets: inflate + decode (wall time of the device work, keys zero-copy)
     rep["compressed"] = {}
     nc = min(n_records, 1_000_000)
-    for codec, name in ((2, "snappy"), (3, "lz4"), (1, "gzip")):
-        enc = codec if codec != 1 else 0x100   # gzip: zlib (level 6) over the uncompressed, patterned batches
+    codecs = [(2, "snappy"), (3, "lz4"), (1, "gzip")]
+    try:
+        import pyarrow  # noqa: F401  (libzstd for the zstd sample)
+        codecs.append((4, "zstd"))
+    except ImportError:
+        pass
+    for codec, name in codecs:
+        enc = codec if codec in (2, 3) else 0x100   # gzip / zstd: the real libraries over the uncompressed, patterned batches
         lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, None, 0, C.byref(ln))
         cbuf = np.zeros(ln.value + 128, np.uint8)
         lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, cbuf.ctypes.data, ln.value, C.byref(ln))
-        if codec == 1:
-            gz = _gzip_batches(lib, cbuf[:ln.value].tobytes())
+        if codec in (1, 4):
+            gz = _recompress_batches(lib, cbuf[:ln.value].tobytes(), codec)
             cbuf = np.zeros(len(gz) + 128, np.uint8)
             cbuf[:len(gz)] = np.frombuffer(gz, np.uint8)
             ln.value = len(gz)

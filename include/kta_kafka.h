@@ -29,8 +29,9 @@
  *   maxTimestamp for LogAppendTime), key/payload None iff the length is -1.
  * Compression: Snappy batches (codec 2; bare blocks as librdkafka writes them and the snappy-java
  * stream framing of the Java clients) and LZ4 batches (codec 3, LZ4 frame format, linked or
- * independent blocks) are inflated on the device by wave-cooperative kernels, gzip batches (codec 1)
- * by one lane per batch; zstd batches and magic 0/1 message sets are counted, never silently mis-decoded.  CRCs are verified only on request (kta_kafka_set_check_crcs) — librdkafka's
+ * independent blocks) are inflated on the device by wave-cooperative kernels, gzip (codec 1) and zstd
+ * (codec 4) batches by one lane per batch; batches of an unknown codec and magic 0/1 message sets are
+ * counted, never silently mis-decoded.  CRCs are verified only on request (kta_kafka_set_check_crcs) — librdkafka's
  * `check.crcs` defaults to false and the reference does not set it (src/kafka.rs:28-36).
  */
 #ifndef KTA_KAFKA_H
@@ -53,6 +54,7 @@ extern "C" {
 #define KTA_KB_SNAPPY 4u          /* records are Snappy compressed (codec 2): inflated on the device */
 #define KTA_KB_LZ4 8u             /* records are LZ4 compressed (codec 3, LZ4 frame format): likewise */
 #define KTA_KB_GZIP 16u           /* records are gzip compressed (codec 1): likewise                  */
+#define KTA_KB_ZSTD 32u           /* records are zstd compressed (codec 4): likewise                  */
 /* status of a batch after the device passes */
 #define KTA_KB_BAD_CRC 1u         /* CRC-32C mismatch (only with kta_kafka_set_check_crcs)           */
 #define KTA_KB_BAD_FRAMING 2u     /* records overran the batch                                      */
@@ -71,13 +73,14 @@ typedef struct kta_kafka_batch_desc {
     int32_t partition;
     int32_t n_records;
     uint32_t flags;
+    uint64_t scratch_end; /* zstd: [payload_end, scratch_end) is the decoder's scratch in the inflate area */
 } kta_kafka_batch_desc;
 
 typedef struct kta_kafka_index_stats {
     uint64_t n_batches;          /* descriptors written                                     */
     uint64_t n_records;          /* sum of their recordsCount                               */
     uint64_t n_control_batches;  /* skipped: never delivered to the application             */
-    uint64_t n_compressed;       /* skipped: zstd batches (not decoded here)                */
+    uint64_t n_compressed;       /* skipped: batches of an unknown codec (5..7)             */
     uint64_t n_snappy;           /* Snappy batches (codec 2): inflated on the device         */
     uint64_t n_lz4;              /* LZ4 batches (codec 3): inflated on the device            */
     uint64_t inflate_bytes;      /* bytes of inflate area the descriptors use               */
@@ -85,7 +88,7 @@ typedef struct kta_kafka_index_stats {
     uint64_t trailing_bytes;     /* bytes after the last complete batch (partial fetch tail)*/
     uint64_t bytes_consumed;
     uint64_t n_gzip;             /* gzip batches (codec 1): inflated on the device           */
-    uint64_t n_zstd;             /* reserved (zstd batches are counted in n_compressed)      */
+    uint64_t n_zstd;             /* zstd batches (codec 4): inflated on the device           */
 } kta_kafka_index_stats;
 
 /* Host: walk the batch headers of one record set.  `record_base_start` is the output index of the
@@ -101,6 +104,8 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
 int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 /* LZ4 frame inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
 int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
+/* zstd (one or more frames) inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
+int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 /* gzip (one member) inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 

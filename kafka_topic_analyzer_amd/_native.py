@@ -78,7 +78,7 @@ class KtaKafkaBatchDesc(C.Structure):
                 ("payload_off", C.c_uint64), ("payload_end", C.c_uint64),
                 ("base_offset", C.c_int64), ("base_ts_ms", C.c_int64), ("max_ts_ms", C.c_int64),
                 ("batch_bytes", C.c_uint32), ("partition", C.c_int32), ("n_records", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("scratch_end", C.c_uint64)]
 
 
 class KtaKafkaIndexStats(C.Structure):
@@ -135,6 +135,7 @@ SIGNATURES = {
     "kta_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(KtaSynthSpec), C.POINTER(C.c_uint64)]),
     "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
+    "kta_zstd_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_gzip_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_lz4_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_snappy_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),

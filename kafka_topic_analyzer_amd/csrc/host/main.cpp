@@ -14,7 +14,7 @@
 //     synthetic://<c1..c5>[?records=N]   the synthetic topic of include/kta_synth.h
 //     dump://<path>                      a KTADUMP1 topic dump (host/dump.hpp)
 //     segment://<f0>[,<f1>...]           raw Kafka log segments (`*.log` files of a broker, record-batch
-//                                        v2; uncompressed, gzip, Snappy, LZ4): file k is partition k; decoded ON THE GPU
+//                                        v2; uncompressed, gzip, Snappy, LZ4, zstd): file k is partition k; decoded ON THE GPU
 //                                        (include/kta_kafka.h), the host only walks batch headers
 // Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
 // kta.batch=N, kta.write_dump=<path>, kta.per_message=1), so no flag is added or renamed.
@@ -356,7 +356,7 @@ int main(int argc, char **argv)
             check(kta_kafka_consume(ctx, segment_bytes[p].data(), segment_bytes[p].size(), (int32_t)p, &ist), ctx,
                   "kta_kafka_consume");
             if (ist.n_compressed || ist.n_old_magic)
-                fprintf(stderr, "[WARN] Kafka error: partition %u: %llu zstd and %llu pre-v2 batches skipped\n", p,
+                fprintf(stderr, "[WARN] Kafka error: partition %u: %llu unknown-codec and %llu pre-v2 batches skipped\n", p,
                         (unsigned long long)ist.n_compressed, (unsigned long long)ist.n_old_magic);   // kafka.rs:95-97
             seq += ist.n_records;
         }

@@ -13,6 +13,7 @@
 #include "kta_snappy.h"
 #include "kta_lz4.h"
 #include "kta_gzip.h"
+#include "kta_zstd.h"
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -436,6 +437,28 @@ __global__ __launch_bounds__(L) void kafka_gzip_inflate(uint8_t *buffer, kta_kaf
     const uint64_t n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, cap = d.payload_end - d.payload_off;
     const int64_t got = kta::gzip_inflate(src, n, buffer + d.payload_off, cap, s_work + threadIdx.x, L);
     if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;   // the trailer told the size
+}
+
+// ---- zstd inflate: one lane per batch -------------------------------------------------------------
+// csrc/kta_zstd.h; the decoder's tables (10.6 KiB) and the Huffman-decoded literals of a block live in the
+// batch's scratch, which the host index placed right behind its slice of the inflate area.
+constexpr uint64_t kZstdWorkBytes = (sizeof(kta::ZsWork) + 63) & ~63ull;
+
+__global__ __launch_bounds__(kGzipLanes) void kafka_zstd_inflate(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * kGzipLanes + threadIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_ZSTD) || d.status) return;
+    const uint8_t *src = buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    const uint64_t n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, cap = d.payload_end - d.payload_off;
+    const uint64_t scratch = (d.payload_end + 63) & ~63ull;          // 64-byte aligned: the tables are u32
+    if (d.scratch_end < scratch + kZstdWorkBytes) { descs[b].status = KTA_KB_BAD_FRAMING; return; }
+    kta::ZsWork *w = reinterpret_cast<kta::ZsWork *>(buffer + scratch);
+    const int64_t got = kta::zstd_inflate(src, n, buffer + d.payload_off, cap, w, buffer + scratch + kZstdWorkBytes,
+                                          d.scratch_end - scratch - kZstdWorkBytes);
+    if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
+    else descs[b].payload_end = d.payload_off + (uint64_t)got;       // the slice was sized by a bound
 }
 
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
@@ -974,8 +997,18 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                 inflated = kta::gzip_uncompressed_len(bytes + pos + KTA_KAFKA_BATCH_HEADER, clen);
                 if (inflated > (int64_t)(clen * 1032 + 64)) inflated = -1;   // DEFLATE expands at most 1032x
             }
+            uint64_t scratch = 0;
+            if (codec == 4) {
+                uint64_t bound = 0, lit = 0;
+                if (kta::zstd_scan(bytes + pos + KTA_KAFKA_BATCH_HEADER, total - KTA_KAFKA_BATCH_HEADER, &bound, &lit)) {
+                    inflated = (int64_t)bound;
+                    scratch = kZstdWorkBytes + lit + 64;                  // tables + literals (+ alignment slack)
+                } else {
+                    inflated = -1;
+                }
+            }
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
-            else if (codec > 3) stats->n_compressed++;                    // zstd (4) and unknown codecs: not decoded here
+            else if (codec > 4) stats->n_compressed++;                    // unknown codecs (5..7): not decoded here
             else if (count > 0) {
                 if (nb < cap) {
                     kta_kafka_batch_desc &d = descs[nb];
@@ -991,23 +1024,28 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     d.n_records = count;
                     d.flags = ((attrs & 0x08) ? KTA_KB_LOG_APPEND_TIME : 0u) | ((attrs & 0x10) ? KTA_KB_TRANSACTIONAL : 0u);
                     if (codec != 0) {
-                        d.flags |= codec == 2 ? KTA_KB_SNAPPY : (codec == 3 ? KTA_KB_LZ4 : KTA_KB_GZIP);
+                        d.flags |= codec == 2 ? KTA_KB_SNAPPY : (codec == 3 ? KTA_KB_LZ4 : (codec == 1 ? KTA_KB_GZIP : KTA_KB_ZSTD));
                         if (inflated < 0) {          // malformed stream: nothing to parse, reported as bad
                             d.status = KTA_KB_BAD_FRAMING;
                             inflated = 0;
                         }
                         d.payload_off = inflate_offset + inflate;
                         d.payload_end = d.payload_off + (uint64_t)inflated;
+                        d.scratch_end = inflated > 0 && scratch ? ((d.payload_end + 63) & ~63ull) + scratch : d.payload_end;
                     } else {
                         d.payload_off = d.byte_off + KTA_KAFKA_BATCH_HEADER;
                         d.payload_end = d.byte_off + total;
+                        d.scratch_end = d.payload_end;
                     }
                 }
                 if (codec != 0) {
                     if (codec == 2) stats->n_snappy++;
                     else if (codec == 3) stats->n_lz4++;
-                    else stats->n_gzip++;
+                    else if (codec == 1) stats->n_gzip++;
+                    else stats->n_zstd++;
                     inflate += ((uint64_t)(inflated > 0 ? inflated : 0) + 63) & ~63ull;   // 64-byte aligned slices
+                    if (inflated > 0 && scratch) inflate += (scratch + 63) & ~63ull;
+
                 }
                 nb++;
                 rec += (uint64_t)count;
@@ -1027,6 +1065,15 @@ int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint6
 {
     if (!src || (!dst && cap)) return -1;
     return kta::lz4_inflate(src, n, dst, cap);
+}
+
+int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
+    uint64_t bound = 0, lit = 0;
+    if (!kta::zstd_scan(src, n, &bound, &lit)) return -1;
+    std::vector<uint8_t> scratch(sizeof(kta::ZsWork) + lit + 64);
+    return kta::zstd_inflate(src, n, dst, cap, reinterpret_cast<kta::ZsWork *>(scratch.data()), scratch.data() + sizeof(kta::ZsWork), lit);
 }
 
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
@@ -1105,20 +1152,22 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipGetLastError());
         if (timing) KK(ctx, hipEventRecord(b, s));
     }
-    bool any_snappy = false, any_lz4 = false, any_gzip = false;
+    bool any_snappy = false, any_lz4 = false, any_gzip = false, any_zstd = false;
     uint64_t buffer_end = blob_len;
     for (uint64_t i = 0; i < n_batches; i++)
-        if (descs_host[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4 | KTA_KB_GZIP)) {
+        if (descs_host[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4 | KTA_KB_GZIP | KTA_KB_ZSTD)) {
             any_snappy = any_snappy || (descs_host[i].flags & KTA_KB_SNAPPY);
             any_lz4 = any_lz4 || (descs_host[i].flags & KTA_KB_LZ4);
             any_gzip = any_gzip || (descs_host[i].flags & KTA_KB_GZIP);
+            any_zstd = any_zstd || (descs_host[i].flags & KTA_KB_ZSTD);
             if (descs_host[i].payload_end > buffer_end) buffer_end = descs_host[i].payload_end;
+            if ((descs_host[i].flags & KTA_KB_ZSTD) && descs_host[i].scratch_end > buffer_end) buffer_end = descs_host[i].scratch_end;
         }
     if (want_keys && buffer_end >= (1ull << 32)) {
         kta_internal_set_error(ctx, "blob + inflate area must be < 4 GiB when key offsets are wanted (key_off is u32)");
         return KTA_ERR_CAPACITY;
     }
-    if (any_snappy || any_lz4 || any_gzip) {   // inflate compressed batches into their slices of the same buffer
+    if (any_snappy || any_lz4 || any_gzip || any_zstd) {   // inflate compressed batches into their slices of the same buffer
         uint8_t *buf = const_cast<uint8_t *>(blob_device);
         uint32_t lane_codecs = 0u;
         if (g_decode_variant != 1) {
@@ -1134,6 +1183,9 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         if (any_gzip)     // DEFLATE is bit-serial: always one lane per batch
             hipLaunchKernelGGL((kafka_gzip_inflate<kGzipLanes>), dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)),
                                dim3(kGzipLanes), 0, s, buf, st->d_descs, n_batches);
+        if (any_zstd)     // bit-serial entropy stages: one lane per batch as well
+            hipLaunchKernelGGL(kafka_zstd_inflate, dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)), dim3(kGzipLanes), 0,
+                               s, buf, st->d_descs, n_batches);
         if (lane_codecs)
             hipLaunchKernelGGL(kafka_inflate_lane, dim3(grid), dim3(kLanesPerBlock), 0, s, buf, st->d_descs, n_batches,
                                lane_codecs);
@@ -1309,6 +1361,7 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         stats->n_snappy += one.n_snappy;
         stats->n_lz4 += one.n_lz4;
         stats->n_gzip += one.n_gzip;
+        stats->n_zstd += one.n_zstd;
         stats->inflate_bytes += one.inflate_bytes;
         stats->n_old_magic += one.n_old_magic;
         stats->bytes_consumed += one.bytes_consumed;

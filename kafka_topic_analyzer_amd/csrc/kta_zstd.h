@@ -1,0 +1,648 @@
+// kta_zstd.h — Zstandard inflate for compressed Kafka record batches (attributes codec 4, KIP-110).
+// Same code on the host (index: size bound, literal scratch; CPU tests against libzstd's output) and on
+// the device (one lane per batch).  Written from the format specification (RFC 8878); checksums are not
+// verified (the batch CRC-32C covers the compressed bytes), dictionaries are not supported (Kafka does
+// not use them), skippable frames are refused.
+//
+// Frame: magic FD2FB528 (LE) | Frame_Header_Descriptor | [Window_Descriptor] | [Dictionary_ID] |
+//   [Frame_Content_Size] | blocks | [checksum 4].  Block: 3-byte LE header (last 1 bit, type 2 bits:
+//   raw / RLE / compressed / reserved, size 21 bits).  A compressed block is a literals section (raw, RLE,
+//   or Huffman coded in 1 or 4 backward bit streams; the Huffman weights are direct 4-bit values or FSE
+//   coded) and a sequences section (count, three FSE tables for literal-length / offset / match-length
+//   codes — predefined, RLE, described, or repeated from the previous block — and one backward bit
+//   stream of interleaved FSE states and extra bits).  A sequence copies `literal_length` literals, then
+//   `match_length` bytes from `offset` back; offset values 1..3 name the three most recent offsets.
+//
+// Backward bit streams: the last byte carries a final 1 marker; bits are consumed from just below it
+// towards the first byte.  Reading before the first byte yields zeros (the format relies on it for the
+// last state refills), and the final position is checked.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define KTA_ZSTD_HD __host__ __device__ inline
+#else
+#define KTA_ZSTD_HD inline
+#endif
+
+namespace kta {
+
+constexpr uint32_t ZS_BLOCK_MAX = 128u << 10;
+
+// Per-batch scratch of the decoder (plain memory: global on the device).  FSE entries are
+// symbol | nbits << 8 | base << 16; Huffman entries symbol | nbits << 8.
+struct ZsWork {
+    uint32_t ll[1 << 9], of[1 << 8], ml[1 << 9];
+    uint32_t wfse[1 << 6];     // FSE table of the Huffman weights
+    uint16_t huf[1 << 11];
+    int16_t norm[64];          // normalized counts of the table being built
+    uint16_t next[64];         // per-symbol state counters while building
+    uint8_t weights[256];
+    uint8_t ll_log, of_log, ml_log, huf_log;
+    uint8_t have_ll, have_of, have_ml, have_huf;
+};
+
+KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
+{
+    return 31u - (uint32_t)__builtin_clz(v);
+}
+
+// ---- forward (LSB first) bit reader: FSE table descriptions --------------------------------------------
+struct ZsFwd {
+    const uint8_t *p;
+    uint64_t n;
+    uint64_t bit;   // next bit
+    bool bad;
+};
+
+KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd &f, uint32_t nb)   // nb <= 16
+{
+    uint32_t v = 0;
+    for (uint32_t got = 0; got < nb;) {
+        const uint64_t byte = f.bit >> 3;
+        if (byte >= f.n) { f.bad = true; return 0; }
+        const uint32_t sh = (uint32_t)(f.bit & 7), take = (8 - sh) < (nb - got) ? (8 - sh) : (nb - got);
+        v |= (((uint32_t)f.p[byte] >> sh) & ((1u << take) - 1u)) << got;
+        got += take;
+        f.bit += take;
+    }
+    return v;
+}
+
+// ---- backward bit reader ---------------------------------------------------------------------------------
+struct ZsBack {
+    const uint8_t *p;
+    uint64_t n;
+    int64_t off;    // bits [0, off) are unread; may go negative (zeros)
+};
+
+KTA_ZSTD_HD bool zs_back_init(ZsBack &b, const uint8_t *p, uint64_t n)
+{
+    if (n == 0 || p[n - 1] == 0) return false;
+    b.p = p;
+    b.n = n;
+    b.off = (int64_t)(8 * (n - 1)) + (int64_t)zs_highbit(p[n - 1]);
+    return true;
+}
+
+KTA_ZSTD_HD uint64_t zs_back(ZsBack &b, uint32_t nb)   // nb <= 32
+{
+    b.off -= (int64_t)nb;
+    if (nb == 0) return 0;
+    int64_t lo = b.off;
+    uint32_t want = nb, shift_out = 0;
+    if (lo < 0) {                                  // (partly) before the first byte: those bits are zero
+        if (-lo >= (int64_t)nb) return 0;
+        shift_out = (uint32_t)(-lo);
+        want = nb - shift_out;
+        lo = 0;
+    }
+    const uint64_t byte = (uint64_t)lo >> 3;
+    const uint32_t sh = (uint32_t)(lo & 7);
+    uint64_t v = 0;
+    const uint32_t nbytes = (want + sh + 7) >> 3;  // <= 5
+    for (uint32_t i = 0; i < nbytes; i++)
+        if (byte + i < b.n) v |= (uint64_t)b.p[byte + i] << (8 * i);
+    v = (v >> sh) & ((1ull << want) - 1ull);
+    return v << shift_out;
+}
+
+// ---- FSE ----------------------------------------------------------------------------------------------------
+// Reads a table description (normalized counts) into w.norm; returns the accuracy log, 0 on error.
+KTA_ZSTD_HD uint32_t zs_read_norm(ZsFwd &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
+{
+    const uint32_t log = 5 + zs_fwd(f, 4);
+    if (f.bad || log > max_log) return 0;
+    int32_t remaining = 1 << log;
+    uint32_t s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        const uint32_t bits = zs_highbit((uint32_t)remaining + 1) + 1;
+        uint32_t val = zs_fwd(f, bits);
+        if (f.bad) return 0;
+        const uint32_t lower = (1u << (bits - 1)) - 1u;
+        const uint32_t threshold = (1u << bits) - 1u - ((uint32_t)remaining + 1u);
+        if ((val & lower) < threshold) {            // small values take one bit less
+            f.bit -= 1;
+            val &= lower;
+        } else if (val > lower) {
+            val -= threshold;
+        }
+        const int32_t proba = (int32_t)val - 1;     // -1: "less than one"
+        remaining -= proba < 0 ? 1 : proba;
+        w.norm[s++] = (int16_t)proba;
+        if (proba == 0) {                           // runs of zero probabilities: 2-bit repeat counts
+            uint32_t rep = zs_fwd(f, 2);
+            while (true) {
+                for (uint32_t i = 0; i < rep && s <= max_sym; i++) w.norm[s++] = 0;
+                if (rep != 3) break;
+                rep = zs_fwd(f, 2);
+                if (f.bad) return 0;
+            }
+        }
+    }
+    if (f.bad || remaining != 0 || s > max_sym + 1) return 0;
+    f.bit = (f.bit + 7) & ~7ull;                    // the description ends on a byte boundary
+    *n_sym = s;
+    return log;
+}
+
+// Spreads w.norm[0 .. n_sym) into the decoding table `t` of 1 << log entries.
+KTA_ZSTD_HD bool zs_build_fse(ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
+{
+    const uint32_t size = 1u << log, mask = size - 1u;
+    uint32_t high = size;
+    for (uint32_t s = 0; s < n_sym; s++)
+        if (w.norm[s] == -1) {
+            t[--high] = s;
+            w.next[s] = 1;
+        }
+    const uint32_t step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t pos = 0;
+    for (uint32_t s = 0; s < n_sym; s++) {
+        if (w.norm[s] <= 0) continue;
+        w.next[s] = (uint16_t)w.norm[s];
+        for (int32_t i = 0; i < w.norm[s]; i++) {
+            t[pos] = s;
+            do pos = (pos + step) & mask;
+            while (pos >= high);
+        }
+    }
+    if (pos != 0) return false;
+    for (uint32_t i = 0; i < size; i++) {
+        const uint32_t s = t[i], x = w.next[s]++;
+        const uint32_t nb = log - zs_highbit(x);
+        t[i] = s | (nb << 8) | (((x << nb) - size) << 16);
+    }
+    return true;
+}
+
+KTA_ZSTD_HD void zs_build_rle(uint32_t *t, uint32_t sym) { t[0] = sym; }   // log 0: one state, no bits
+
+// Predefined distributions (RFC 8878 3.1.1.3.2.2.1-3): literal lengths and match lengths accuracy 6, offsets 5.
+KTA_ZSTD_HD void zs_default_norm(ZsWork &w, int which)
+{
+    if (which == 0) {   // literal length codes 0..35
+        const int8_t d[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+        for (int i = 0; i < 36; i++) w.norm[i] = d[i];
+    } else if (which == 1) {   // offset codes 0..28
+        const int8_t d[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+        for (int i = 0; i < 29; i++) w.norm[i] = d[i];
+    } else {   // match length codes 0..52
+        const int8_t d[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+        for (int i = 0; i < 53; i++) w.norm[i] = d[i];
+    }
+}
+
+// One of the three sequence tables.  mode: 0 predefined, 1 RLE, 2 described, 3 repeat.
+KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, const uint8_t *p, uint64_t n, uint64_t *pos)
+{
+    uint32_t *t = which == 0 ? w.ll : (which == 1 ? w.of : w.ml);
+    uint8_t &log = which == 0 ? w.ll_log : (which == 1 ? w.of_log : w.ml_log);
+    uint8_t &have = which == 0 ? w.have_ll : (which == 1 ? w.have_of : w.have_ml);
+    const uint32_t max_log = which == 1 ? 8 : 9, max_sym = which == 0 ? 35 : (which == 1 ? 31 : 52);
+    if (mode == 0) {
+        zs_default_norm(w, which);
+        log = which == 1 ? 5 : 6;
+        have = 1;
+        return zs_build_fse(w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53));
+    }
+    if (mode == 1) {
+        if (*pos >= n || p[*pos] > max_sym) return false;
+        zs_build_rle(t, p[(*pos)++]);
+        log = 0;
+        have = 1;
+        return true;
+    }
+    if (mode == 2) {
+        ZsFwd f{p + *pos, n - *pos, 0, false};
+        uint32_t n_sym = 0;
+        const uint32_t l = zs_read_norm(f, w, max_log, max_sym, &n_sym);
+        if (!l) return false;
+        *pos += f.bit >> 3;
+        log = (uint8_t)l;
+        have = 1;
+        return zs_build_fse(w, t, l, n_sym);
+    }
+    return have != 0;   // repeat: the previous block's table
+}
+
+// ---- Huffman ------------------------------------------------------------------------------------------------
+// Tree description at p[0 .. n): fills w.huf / w.huf_log; returns the bytes consumed, 0 on error.
+KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, const uint8_t *p, uint64_t n)
+{
+    if (n < 1) return 0;
+    const uint32_t hb = p[0];
+    uint32_t n_w = 0;
+    uint64_t used;
+    if (hb >= 128) {                                  // direct: 4 bits per weight
+        n_w = hb - 127;
+        used = 1 + (n_w + 1) / 2;
+        if (used > n) return 0;
+        for (uint32_t i = 0; i < n_w; i++) w.weights[i] = (uint8_t)((i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4));
+    } else {                                          // FSE coded weights, two interleaved states
+        used = 1 + hb;
+        if (hb == 0 || used > n) return 0;
+        ZsFwd f{p + 1, hb, 0, false};
+        uint32_t n_sym = 0;
+        const uint32_t log = zs_read_norm(f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
+        if (!log || !zs_build_fse(w, w.wfse, log, n_sym)) return 0;
+        const uint64_t at = f.bit >> 3;
+        if (at >= hb) return 0;
+        ZsBack b;
+        if (!zs_back_init(b, p + 1 + at, hb - at)) return 0;
+        uint32_t s1 = (uint32_t)zs_back(b, log), s2 = (uint32_t)zs_back(b, log);
+        if (b.off < 0) return 0;
+        while (true) {
+            if (n_w >= 254) return 0;
+            w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF);
+            s1 = (w.wfse[s1] >> 16) + (uint32_t)zs_back(b, (w.wfse[s1] >> 8) & 0xFF);
+            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF); break; }
+            w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF);
+            s2 = (w.wfse[s2] >> 16) + (uint32_t)zs_back(b, (w.wfse[s2] >> 8) & 0xFF);
+            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF); break; }
+        }
+    }
+    // the last weight is implied: the code space must add up to a power of two
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < n_w; i++) {
+        if (w.weights[i] > 11) return 0;
+        sum += w.weights[i] ? 1u << (w.weights[i] - 1) : 0u;
+    }
+    if (sum == 0) return 0;
+    const uint32_t log = zs_highbit(sum) + 1;
+    if (log > 11) return 0;
+    const uint32_t left = (1u << log) - sum;
+    if (left & (left - 1)) return 0;                  // not a power of two
+    w.weights[n_w++] = (uint8_t)(zs_highbit(left) + 1);
+    // table: the symbols of weight 1 (longest codes) come first, each weight's symbols in symbol order
+    uint32_t rank_start[13];
+    uint32_t at = 0;
+    for (uint32_t wt = 1; wt <= log; wt++) {
+        rank_start[wt] = at;
+        for (uint32_t s = 0; s < n_w; s++)
+            if (w.weights[s] == wt) at += 1u << (wt - 1);
+    }
+    if (at != (1u << log)) return 0;
+    for (uint32_t s = 0; s < n_w; s++) {
+        const uint32_t wt = w.weights[s];
+        if (!wt) continue;
+        const uint32_t len = 1u << (wt - 1), nb = log + 1 - wt;
+        for (uint32_t i = 0; i < len; i++) w.huf[rank_start[wt] + i] = (uint16_t)(s | (nb << 8));
+        rank_start[wt] += len;
+    }
+    w.huf_log = (uint8_t)log;
+    w.have_huf = 1;
+    return used;
+}
+
+KTA_ZSTD_HD bool zs_huf_stream(const ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t count)
+{
+    ZsBack b;
+    if (!zs_back_init(b, p, n)) return false;
+    const uint32_t log = w.huf_log, mask = (1u << log) - 1u;
+    uint32_t state = (uint32_t)zs_back(b, log);
+    for (uint64_t i = 0; i < count; i++) {
+        if (b.off <= -(int64_t)log) return false;    // more symbols wanted than the stream holds
+        const uint32_t e = w.huf[state], nb = e >> 8;
+        out[i] = (uint8_t)e;
+        state = ((state << nb) | (uint32_t)zs_back(b, nb)) & mask;
+    }
+    return b.off == -(int64_t)log;                    // every bit consumed, none invented
+}
+
+// ---- literals and sequences ------------------------------------------------------------------------------
+struct ZsLit {
+    const uint8_t *p;   // raw / decoded literals (nullptr for RLE)
+    uint64_t n;
+    uint8_t rle;
+};
+
+// Parses the literals section header at p: type, regenerated and compressed sizes, header bytes (0 = error).
+KTA_ZSTD_HD uint32_t zs_lit_header(const uint8_t *p, uint64_t n, uint32_t *type, uint32_t *regen, uint32_t *comp,
+                                   uint32_t *streams)
+{
+    if (n < 1) return 0;
+    const uint32_t b0 = p[0], sf = (b0 >> 2) & 3;
+    *type = b0 & 3;
+    *comp = 0;
+    *streams = 1;
+    if (*type < 2) {                                  // raw / RLE
+        if (sf == 0 || sf == 2) { *regen = b0 >> 3; return 1; }
+        if (sf == 1) { if (n < 2) return 0; *regen = (b0 >> 4) | ((uint32_t)p[1] << 4); return 2; }
+        if (n < 3) return 0;
+        *regen = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
+        return 3;
+    }
+    *streams = sf == 0 ? 1 : 4;
+    if (sf < 2) {                                     // 10 + 10 bits
+        if (n < 3) return 0;
+        const uint32_t v = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
+        *regen = v & 0x3FF;
+        *comp = v >> 10;
+        return 3;
+    }
+    if (sf == 2) {                                    // 14 + 14 bits
+        if (n < 4) return 0;
+        const uint32_t v = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12) | ((uint32_t)p[3] << 20);
+        *regen = v & 0x3FFF;
+        *comp = v >> 14;
+        return 4;
+    }
+    if (n < 5) return 0;                              // 18 + 18 bits
+    const uint64_t v = (b0 >> 4) | ((uint64_t)p[1] << 4) | ((uint64_t)p[2] << 12) | ((uint64_t)p[3] << 20) | ((uint64_t)p[4] << 28);
+    *regen = (uint32_t)(v & 0x3FFFF);
+    *comp = (uint32_t)(v >> 18);
+    return 5;
+}
+
+KTA_ZSTD_HD void zs_copy(uint8_t *dst, uint64_t op, uint64_t dist, uint64_t len)   // overlapping match copy
+{
+    uint64_t k = 0;
+    if (dist >= 8)
+        for (; k + 8 <= len; k += 8) {
+            uint64_t v;
+            __builtin_memcpy(&v, dst + op - dist + k, 8);
+            __builtin_memcpy(dst + op + k, &v, 8);
+        }
+    for (; k < len; k++) dst[op + k] = dst[op - dist + k];
+}
+
+// One compressed block p[0 .. n) appended at dst[*op ..).  `total` = bytes of the frame before this block.
+KTA_ZSTD_HD bool zs_block(ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *dst, uint64_t *op_io, uint64_t cap,
+                          uint64_t frame_start, uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap)
+{
+    uint64_t op = *op_io;
+    const uint64_t block_start = op;
+    uint32_t type, regen, comp, streams;
+    const uint32_t hdr = zs_lit_header(p, n, &type, &regen, &comp, &streams);
+    if (!hdr || regen > ZS_BLOCK_MAX) return false;
+    uint64_t pos = hdr;
+    ZsLit lit{nullptr, regen, 0};
+    if (type == 0) {                                  // raw: used in place
+        if (pos + regen > n) return false;
+        lit.p = p + pos;
+        pos += regen;
+    } else if (type == 1) {                           // RLE
+        if (pos + 1 > n) return false;
+        lit.rle = p[pos++];
+    } else {                                          // Huffman coded (2) / with the previous tree (3)
+        if (pos + comp > n || regen > lit_cap) return false;
+        const uint8_t *q = p + pos;
+        uint64_t qn = comp;
+        if (type == 2) {
+            const uint64_t used = zs_read_huffman(w, q, qn);
+            if (!used) return false;
+            q += used;
+            qn -= used;
+        } else if (!w.have_huf) {
+            return false;
+        }
+        if (streams == 1) {
+            if (!zs_huf_stream(w, q, qn, lit_buf, regen)) return false;
+        } else {
+            if (qn < 6) return false;
+            const uint64_t s1 = (uint64_t)q[0] | ((uint64_t)q[1] << 8), s2 = (uint64_t)q[2] | ((uint64_t)q[3] << 8),
+                           s3 = (uint64_t)q[4] | ((uint64_t)q[5] << 8);
+            if (6 + s1 + s2 + s3 > qn) return false;
+            const uint64_t s4 = qn - 6 - s1 - s2 - s3, each = ((uint64_t)regen + 3) / 4;
+            if (3 * each > regen) return false;
+            if (!zs_huf_stream(w, q + 6, s1, lit_buf, each) || !zs_huf_stream(w, q + 6 + s1, s2, lit_buf + each, each) ||
+                !zs_huf_stream(w, q + 6 + s1 + s2, s3, lit_buf + 2 * each, each) ||
+                !zs_huf_stream(w, q + 6 + s1 + s2 + s3, s4, lit_buf + 3 * each, regen - 3 * each))
+                return false;
+        }
+        lit.p = lit_buf;
+        pos += comp;
+    }
+    // sequences section
+    if (pos >= n) return false;
+    uint32_t n_seq = p[pos++];
+    if (n_seq >= 128) {
+        if (n_seq < 255) {
+            if (pos >= n) return false;
+            n_seq = ((n_seq - 128) << 8) + p[pos++];
+        } else {
+            if (pos + 2 > n) return false;
+            n_seq = (uint32_t)p[pos] + ((uint32_t)p[pos + 1] << 8) + 0x7F00u;
+            pos += 2;
+        }
+    }
+    uint64_t lit_at = 0;
+    auto put_literals = [&](uint64_t cnt) -> bool {
+        if (cnt > lit.n - lit_at || op + cnt > cap || op + cnt - block_start > ZS_BLOCK_MAX) return false;
+        if (lit.p) for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit.p[lit_at + k];
+        else for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit.rle;
+        lit_at += cnt;
+        op += cnt;
+        return true;
+    };
+    if (n_seq) {
+        if (pos >= n) return false;
+        const uint32_t modes = p[pos++];
+        if (modes & 3u) return false;                 // reserved bits
+        if (!zs_seq_table(w, 0, modes >> 6, p, n, &pos) || !zs_seq_table(w, 1, (modes >> 4) & 3u, p, n, &pos) ||
+            !zs_seq_table(w, 2, (modes >> 2) & 3u, p, n, &pos))
+            return false;
+        if (pos >= n) return false;
+        ZsBack b;
+        if (!zs_back_init(b, p + pos, n - pos)) return false;
+        uint32_t sl = (uint32_t)zs_back(b, w.ll_log), so = (uint32_t)zs_back(b, w.of_log), sm = (uint32_t)zs_back(b, w.ml_log);
+        if (b.off < 0) return false;
+        for (uint32_t i = 0; i < n_seq; i++) {
+            const uint32_t el = w.ll[sl], eo = w.of[so], em = w.ml[sm];
+            const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
+            if (oc > 31) return false;
+            const uint64_t ov = (1ull << oc) + zs_back(b, oc);
+            // match length: codes 0..31 are 3 + code; then baselines with 1,1,1,1,2,2,3,3,4,4,5,7,8,...,16 extra bits
+            uint32_t ml_base, ml_bits;
+            if (mc < 32) { ml_base = mc + 3; ml_bits = 0; }
+            else {
+                const uint8_t bits[21] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+                const uint32_t base[21] = {35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195,
+                                           16387, 32771, 65539};
+                if (mc > 52) return false;
+                ml_base = base[mc - 32];
+                ml_bits = bits[mc - 32];
+            }
+            const uint64_t mlen = ml_base + zs_back(b, ml_bits);
+            uint32_t ll_base, ll_bits;
+            if (lc < 16) { ll_base = lc; ll_bits = 0; }
+            else {
+                const uint8_t bits[20] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+                const uint32_t base[20] = {16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384,
+                                           32768, 65536};
+                if (lc > 35) return false;
+                ll_base = base[lc - 16];
+                ll_bits = bits[lc - 16];
+            }
+            const uint64_t llen = ll_base + zs_back(b, ll_bits);
+            if (i + 1 < n_seq) {                      // state updates: literal length, match length, offset
+                sl = (el >> 16) + (uint32_t)zs_back(b, (el >> 8) & 0xFF);
+                sm = (em >> 16) + (uint32_t)zs_back(b, (em >> 8) & 0xFF);
+                so = (eo >> 16) + (uint32_t)zs_back(b, (eo >> 8) & 0xFF);
+            }
+            if (b.off < 0) return false;
+            uint64_t offset;
+            if (ov > 3) {
+                offset = ov - 3;
+                rep[2] = rep[1];
+                rep[1] = rep[0];
+                rep[0] = offset;
+            } else {
+                uint32_t idx = (uint32_t)ov - 1 + (llen == 0 ? 1u : 0u);
+                if (idx == 0) offset = rep[0];
+                else {
+                    offset = idx < 3 ? rep[idx] : rep[0] - 1;
+                    if (idx > 1) rep[2] = rep[1];
+                    rep[1] = rep[0];
+                    rep[0] = offset;
+                }
+            }
+            if (!put_literals(llen)) return false;
+            if (offset == 0 || offset > op - frame_start || op + mlen > cap || op + mlen - block_start > ZS_BLOCK_MAX) return false;
+            zs_copy(dst, op, offset, mlen);
+            op += mlen;
+        }
+        if (b.off != 0) return false;                 // the stream is consumed exactly
+    } else if (pos != n) {
+        return false;
+    }
+    if (!put_literals(lit.n - lit_at)) return false;  // the literals after the last sequence
+    *op_io = op;
+    return true;
+}
+
+struct ZsFrame {
+    uint64_t header;       // bytes of magic + frame header
+    uint64_t window;       // window size (content size for single-segment frames)
+    uint64_t content;      // frame content size, ~0 if absent
+    bool checksum;
+};
+
+KTA_ZSTD_HD bool zs_frame_header(const uint8_t *p, uint64_t n, ZsFrame *f)
+{
+    if (n < 6 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return false;
+    const uint32_t fhd = p[4], fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    if (fhd & 0x08) return false;                     // reserved bit
+    if (did) return false;                            // dictionaries are not supported
+    uint64_t pos = 5;
+    f->window = 0;
+    if (!single) {
+        if (pos >= n) return false;
+        const uint32_t wd = p[pos++], wlog = 10 + (wd >> 3);
+        if (wlog > 31) return false;
+        f->window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+    }
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+    if (pos + fcs_bytes > n) return false;
+    f->content = ~0ull;
+    if (fcs_bytes) {
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < fcs_bytes; i++) v |= (uint64_t)p[pos + i] << (8 * i);
+        if (fcs_bytes == 2) v += 256;
+        f->content = v;
+        pos += fcs_bytes;
+    }
+    if (single) f->window = f->content;
+    f->checksum = (fhd >> 2) & 1;
+    f->header = pos;
+    return true;
+}
+
+// Walks the frames and block headers of a batch payload.  *bound: an upper bound of the inflated size (the
+// content sizes where present, else blocks x block maximum); *lit: the largest regenerated size of a
+// Huffman-coded literals section (the scratch the decoder needs).  false if the framing is malformed.
+KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64_t *lit)
+{
+    uint64_t pos = 0, total = 0, max_lit = 0;
+    if (n == 0) return false;
+    while (pos < n) {
+        ZsFrame f;
+        if (!zs_frame_header(p + pos, n - pos, &f)) return false;
+        pos += f.header;
+        const uint64_t block_max = f.window < ZS_BLOCK_MAX ? f.window : ZS_BLOCK_MAX;
+        uint64_t frame_bound = 0;
+        while (true) {
+            if (pos + 3 > n) return false;
+            const uint32_t h = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16);
+            pos += 3;
+            const uint32_t type = (h >> 1) & 3, size = h >> 3;
+            if (type == 3 || size > ZS_BLOCK_MAX) return false;
+            if (type == 1) {                          // RLE: one byte, `size` copies
+                if (pos + 1 > n) return false;
+                pos += 1;
+                frame_bound += size;
+            } else {
+                if (pos + size > n) return false;
+                if (type == 2) {
+                    uint32_t lt, regen, comp, streams;
+                    if (!zs_lit_header(p + pos, size, &lt, &regen, &comp, &streams)) return false;
+                    if (lt >= 2 && regen > max_lit) max_lit = regen;
+                    frame_bound += block_max ? block_max : ZS_BLOCK_MAX;
+                } else {
+                    frame_bound += size;
+                }
+                pos += size;
+            }
+            if (h & 1) break;
+        }
+        if (f.checksum) {
+            if (pos + 4 > n) return false;
+            pos += 4;
+        }
+        total += f.content < frame_bound ? f.content : frame_bound;   // (an absent content size is ~0)
+    }
+    *bound = total;
+    *lit = max_lit;
+    return true;
+}
+
+// Inflates the frames of one batch payload into dst[0 .. cap).  `lit`: scratch of at least the size
+// zstd_scan reported.  Returns the bytes produced or -1.
+KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWork *w, uint8_t *lit,
+                                 uint64_t lit_cap)
+{
+    uint64_t pos = 0, op = 0;
+    if (n == 0) return -1;
+    while (pos < n) {
+        ZsFrame f;
+        if (!zs_frame_header(src + pos, n - pos, &f)) return -1;
+        pos += f.header;
+        const uint64_t frame_start = op;
+        uint64_t rep[3] = {1, 4, 8};
+        w->have_ll = w->have_of = w->have_ml = w->have_huf = 0;
+        while (true) {
+            if (pos + 3 > n) return -1;
+            const uint32_t h = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+            pos += 3;
+            const uint32_t type = (h >> 1) & 3, size = h >> 3;
+            if (type == 3 || size > ZS_BLOCK_MAX) return -1;
+            if (type == 0) {
+                if (pos + size > n || op + size > cap) return -1;
+                for (uint32_t k = 0; k < size; k++) dst[op + k] = src[pos + k];
+                op += size;
+                pos += size;
+            } else if (type == 1) {
+                if (pos + 1 > n || op + size > cap) return -1;
+                for (uint32_t k = 0; k < size; k++) dst[op + k] = src[pos];
+                op += size;
+                pos += 1;
+            } else {
+                if (pos + size > n) return -1;
+                if (!zs_block(*w, src + pos, size, dst, &op, cap, frame_start, rep, lit, lit_cap)) return -1;
+                pos += size;
+            }
+            if (h & 1) break;
+        }
+        if (f.checksum) {
+            if (pos + 4 > n) return -1;
+            pos += 4;
+        }
+        if (f.content != ~0ull && op - frame_start != f.content) return -1;
+    }
+    return (int64_t)op;
+}
+
+}  // namespace kta

@@ -63,7 +63,8 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (b[16] != 2) { st->old_magic_batches++; pos += total; continue; }
         uint16_t attrs = (uint16_t)rd_be(b + 21, 2);
         if (attrs & 0x20) { st->control_batches++; pos += total; continue; }
-        if ((attrs & 0x07) > 3) { st->compressed_batches++; pos += total; continue; }   /* zstd: not decoded */
+        if ((attrs & 0x07) > 3) { st->compressed_batches++; pos += total; continue; }   /* zstd arrives here only when the
+                                                                                        * test could not transcode it (tests/oracle_c.py) */
         int64_t base_offset = (int64_t)rd_be(b, 8);
         int64_t base_ts = (int64_t)rd_be(b + 27, 8), max_ts = (int64_t)rd_be(b + 35, 8);
         int32_t count = (int32_t)rd_be(b + 57, 4);

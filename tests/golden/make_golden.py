@@ -126,7 +126,7 @@ def kafka_fixture():
     blob = K.encode_batch(100, b1, 1600000000000)
     blob += K.encode_batch(104, [(0, b"ctl", b"ctl")], 1600000000100, attributes=0x30)          # control batch
     blob += K.encode_batch(105, b2, 1600000001000, attributes=0x08, max_ts=1600000009999)       # LogAppendTime
-    blob += K.encode_batch(106, [(0, b"z", b"z")], 1600000002000, attributes=0x04)              # zstd: skipped
+    blob += K.encode_batch(106, [(0, b"z", b"z")], 1600000002000, attributes=0x05)              # unknown codec: skipped
     blob += K.encode_batch(107, [(0, b"old", b"old")], 1600000003000, magic=1)                  # magic 1: skipped
     b3 = [(0, b"snappy-key-a", b"abcabcabcabcabcabcabcabc" * 8), (7, b"snappy-key-a", None), (9, None, b"x" * 300)]
     blob += K.encode_batch(108, b3, 1600000005000, compression="snappy")                        # Snappy, bare block
@@ -134,13 +134,14 @@ def kafka_fixture():
     blob += K.encode_batch(114, b3, 1600000007000, compression="lz4")                           # LZ4 frame, linked blocks
     blob += K.encode_batch(117, b3, 1600000008000, compression="lz4-indep")                     # LZ4, all optional fields
     blob += K.encode_batch(120, b3, 1600000009000, compression="gzip")                          # gzip member (zlib, level 6)
-    blob += K.encode_batch(123, [(0, b"tail", b"tail")], 1600000004000)[:30]                    # partial tail
-    keys = [b"k", b"", b"key-\xff", b"second-batch"] + [b"snappy-key-a"] * 10
-    expect = {"partition": [9] * 20, "key_len": [1, -1, 0, 5, 12] + [12, 12, -1] * 5,
-              "val_len": [1, -1, 0, 200, -1] + [192, -1, 300] * 5,
+    blob += K.encode_batch(123, b3, 1600000010000, compression="zstd")                          # zstd frame (libzstd, level 3)
+    blob += K.encode_batch(126, [(0, b"tail", b"tail")], 1600000004000)[:30]                    # partial tail
+    keys = [b"k", b"", b"key-\xff", b"second-batch"] + [b"snappy-key-a"] * 12
+    expect = {"partition": [9] * 23, "key_len": [1, -1, 0, 5, 12] + [12, 12, -1] * 6,
+              "val_len": [1, -1, 0, 200, -1] + [192, -1, 300] * 6,
               "ts_ms": [1600000000000, 1600000000005, 1599999999997, 1600000070000, 1600000009999] +
-                       [1600000005000 + 1000 * b + d for b in range(5) for d in (0, 7, 9)],
-              "offset": [100, 101, 102, 103, 105] + list(range(108, 123)), "key_bytes_hex": b"".join(keys).hex(),
+                       [1600000005000 + 1000 * b + d for b in range(6) for d in (0, 7, 9)],
+              "offset": [100, 101, 102, 103, 105] + list(range(108, 126)), "key_bytes_hex": b"".join(keys).hex(),
               "control_batches": 1, "compressed_batches": 1, "old_magic_batches": 1, "trailing_bytes": 30}
     return {"partition": 9, "blob_hex": blob.hex(), "expect": expect}
 

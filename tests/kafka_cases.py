@@ -37,7 +37,7 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
             attrs = 0x20 | 0x10  # control batch (transactional marker): skipped
             info["control"] += 1
         elif kind < 0.10:
-            attrs = 4  # zstd: skipped (payload is not really compressed)
+            attrs = int(rng.choice([5, 6, 7]))  # an unknown codec: skipped
             info["compressed"] += 1
         elif kind < 0.2:
             attrs = 0x08  # LogAppendTime: every record carries maxTimestamp
@@ -50,11 +50,11 @@ def random_record_set(rng, n_batches, max_records=40, partition=3, key_space=50,
         comp = None
         if snappy and attrs & 0x27 == 0 and rng.random() < 0.6:  # gzip / Snappy / LZ4 batches, all framings
             comp = str(rng.choice(["snappy", "snappy-xerial", "lz4", "lz4-indep", "gzip", "gzip-fixed", "gzip-stored",
-                                   "gzip-named"]))
+                                   "gzip-named", "zstd", "zstd-stream", "zstd-19"]))
             kind_key = comp.split("-")[0]
             info[kind_key] = info.get(kind_key, 0) + 1
         blob += K.encode_batch(offset, recs, base_ts, attributes=attrs, max_ts=mt, compression=comp)
-        codec = 0 if not comp else {"gzip": 1, "snappy": 2, "lz4": 3}[comp.split("-")[0]]
+        codec = 0 if not comp else {"gzip": 1, "snappy": 2, "lz4": 3, "zstd": 4}[comp.split("-")[0]]
         batches.append((base_ts, attrs | codec, mt, recs))
         offset += n
         if with_noise and rng.random() < 0.03:  # an old-format (magic 1) message set: skipped

@@ -64,7 +64,9 @@ def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, produ
     as the Java client's KafkaLZ4BlockOutputStream can) -> codec 3; "snappy-lib" / "lz4-lib": the same
     two codecs from the real libraries (Google snappy, lz4 frame) through pyarrow; "gzip" (zlib level 6:
     dynamic Huffman blocks), "gzip-fixed" (Z_FIXED), "gzip-stored" (level 0), "gzip-named" (GzipFile with
-    a file name in the header) -> codec 1.  The records section is compressed."""
+    a file name in the header) -> codec 1; "zstd" (libzstd level 3, one-shot: content size in the frame
+    header), "zstd-19", "zstd-stream" (streaming API: no content size) through pyarrow -> codec 4.
+    The records section is compressed."""
     recs = b"".join(encode_record(i, r[0], r[1], r[2], r[3] if len(r) > 3 else ()) for i, r in enumerate(records)) \
         if raw_records is None else raw_records
     if compression in ("snappy", "snappy-xerial"):
@@ -86,6 +88,16 @@ def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, produ
             co = zlib.compressobj(level, zlib.DEFLATED, 15 + 16, 8, strategy)
             recs = co.compress(recs) + co.flush()
         attributes = (attributes & ~0x07) | 1
+    elif compression in ("zstd", "zstd-stream", "zstd-19"):
+        import pyarrow as pa
+        if compression == "zstd-stream":         # streaming API: no Frame_Content_Size, a window descriptor instead
+            sink = pa.BufferOutputStream()
+            with pa.CompressedOutputStream(sink, "zstd") as o:
+                o.write(recs)
+            recs = sink.getvalue().to_pybytes()
+        else:
+            recs = pa.Codec("zstd", compression_level=19 if compression == "zstd-19" else 3).compress(recs, asbytes=True)
+        attributes = (attributes & ~0x07) | 4
     elif compression in ("snappy-lib", "lz4-lib"):
         import pyarrow as pa
         recs = pa.compress(recs, codec=compression[:-4], asbytes=True)
@@ -108,7 +120,7 @@ def expected_columns(partition, batches):
     """batches: [(base_ts, attributes, max_ts, records)] -> the columns a consumer would deliver."""
     part, klen, vlen, ts, keys = [], [], [], [], []
     for base_ts, attributes, max_ts, records in batches:
-        if attributes & 0x20 or (attributes & 0x07) not in (0, 1, 2, 3):   # control, or a codec that is not decoded
+        if attributes & 0x20 or (attributes & 0x07) > 4:   # control, or an unknown codec
             continue
         for r in records:
             part.append(partition)

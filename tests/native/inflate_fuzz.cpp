@@ -1,9 +1,9 @@
-// inflate_fuzz.cpp — TEST HARNESS: the product's inflaters (csrc/kta_snappy.h, kta_lz4.h, kta_gzip.h — the
+// inflate_fuzz.cpp — TEST HARNESS: the product's inflaters (csrc/kta_snappy.h, kta_lz4.h, kta_gzip.h, kta_zstd.h — the
 // very functions the device kernels run, compiled here for the host) under AddressSanitizer on mutated
 // streams.  Input and output live in exact-size heap blocks, so any read past the input or write past
 // `cap` aborts.  A malformed batch on the GPU must be "reported, never mis-decoded" — and must never
 // fault the device.
-//   inflate_fuzz <codec: snappy|lz4|gzip> <seed-file>... ; prints "<codec> ok=<n> refused=<n>"
+//   inflate_fuzz <codec: snappy|lz4|gzip|zstd> <seed-file>... ; prints "<codec> ok=<n> refused=<n>"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +15,7 @@
 #include "kta_gzip.h"
 #include "kta_lz4.h"
 #include "kta_snappy.h"
+#include "kta_zstd.h"
 
 namespace {
 
@@ -35,7 +36,17 @@ int64_t run(const std::string &codec, const std::vector<uint8_t> &in, uint64_t c
     int64_t got;
     if (codec == "snappy") got = kta::snappy_inflate(src, in.size(), dst, cap);
     else if (codec == "lz4") got = kta::lz4_inflate(src, in.size(), dst, cap);
-    else {
+    else if (codec == "zstd") {
+        uint64_t bound = 0, lit = 0;
+        if (!kta::zstd_scan(src, in.size(), &bound, &lit)) got = -1;
+        else {
+            kta::ZsWork *w = (kta::ZsWork *)malloc(sizeof(kta::ZsWork));
+            uint8_t *l = (uint8_t *)malloc(lit ? lit : 1);        // exactly what the scan asked for
+            got = kta::zstd_inflate(src, in.size(), dst, cap, w, l, lit);
+            free(w);
+            free(l);
+        }
+    } else {
         uint16_t work[kta::GZ_WORK];
         got = kta::gzip_inflate(src, in.size(), dst, cap, work, 1);
     }
@@ -65,6 +76,7 @@ int main(int argc, char **argv)
         memcpy(&want, seed.data(), 8);
         seed.erase(seed.begin(), seed.begin() + 8);
         if (run(codec, seed, want) != (int64_t)want) { fprintf(stderr, "seed %s does not inflate\n", argv[a]); return 66; }
+        // a buffer one byte short must be refused (LZ4 excepted: it takes cap as a bound and reports the size)
         if (want && run(codec, seed, want - 1) >= 0 && codec != "lz4") { fprintf(stderr, "short buffer accepted\n"); return 67; }
         for (int it = 0; it < 1500; it++) {
             std::vector<uint8_t> m = seed;

@@ -155,9 +155,43 @@ class KafkaStats(C.Structure):
                 ("trailing_bytes", C.c_uint64), ("bad_batches", C.c_uint64), ("batches", C.c_uint64)]
 
 
+def _zstd_batches_to_plain(blob: bytes) -> bytes:
+    """zstd batches (codec 4) inflated by libzstd itself (through pyarrow) and re-framed as uncompressed
+    batches, so that the C oracle — which has no zstd of its own: no zstd.h in the image — decodes them.
+    A batch libzstd refuses becomes a batch whose records overrun it (the oracle reports it as corrupt,
+    like the product).  Without pyarrow the blob is returned unchanged (zstd batches count as skipped)."""
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return blob
+    L = lib()
+    L.kto_crc32c.restype = C.c_uint32
+    L.kto_crc32c.argtypes = [C.c_char_p, C.c_uint64]
+    out, pos = bytearray(), 0
+    while pos + 12 <= len(blob):
+        length = int.from_bytes(blob[pos + 8:pos + 12], "big", signed=True)
+        total = 12 + length
+        if length < 49 or pos + total > len(blob):
+            break
+        b = blob[pos:pos + total]
+        attrs = int.from_bytes(b[21:23], "big")
+        if b[16] == 2 and not attrs & 0x20 and attrs & 7 == 4:
+            try:
+                recs = pa.input_stream(pa.BufferReader(b[61:]), compression="zstd").read()
+            except Exception:
+                recs = b""
+            after_crc = (attrs & ~7).to_bytes(2, "big") + b[23:61] + recs
+            crc = L.kto_crc32c(after_crc, len(after_crc))
+            b = b[0:8] + (49 + len(recs)).to_bytes(4, "big") + b[12:17] + crc.to_bytes(4, "big") + after_crc
+        out += b
+        pos += total
+    return bytes(out) + blob[pos:]
+
+
 def kafka_decode(blob: bytes, partition: int):
     """The oracle's sequential decode of one Kafka v2 record set -> (columns dict, stats)."""
     L = lib()
+    blob = _zstd_batches_to_plain(blob)
     L.kto_kafka_decode.restype = C.c_int64
     L.kto_kafka_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_int32] + [C.c_void_p] * 7 + [C.POINTER(C.c_uint64),
                                                                                           C.POINTER(KafkaStats)]

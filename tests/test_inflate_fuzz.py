@@ -1,4 +1,4 @@
-"""Memory safety of the inflaters the device kernels run (csrc/kta_snappy.h, kta_lz4.h, kta_gzip.h):
+"""Memory safety of the inflaters the device kernels run (csrc/kta_snappy.h, kta_lz4.h, kta_gzip.h, kta_zstd.h):
 compiled for the host with AddressSanitizer and driven with thousands of mutated streams from the
 real libraries (zlib, and Google snappy / liblz4 through pyarrow when present) and from the test
 compressors.  A corrupt batch must be refused or decoded to *something* inside its slice — never read
@@ -45,7 +45,7 @@ def _write(d, name, data, stream):
     return p
 
 
-@pytest.mark.parametrize("codec", ["snappy", "lz4", "gzip"])
+@pytest.mark.parametrize("codec", ["snappy", "lz4", "gzip", "zstd"])
 def test_inflaters_are_memory_safe_on_mutated_streams(fuzzer, codec):
     exe, d = fuzzer
     try:
@@ -65,6 +65,15 @@ def test_inflaters_are_memory_safe_on_mutated_streams(fuzzer, codec):
                                                                          block_checksum=True, content_checksum=True)))
             if pa:
                 seeds.append(_write(d, f"l{i}c", data, pa.compress(data, codec="lz4", asbytes=True)))
+        elif codec == "zstd":
+            if not pa:
+                pytest.skip("zstd seeds come from libzstd through pyarrow")
+            for level in (1, 3, 19):
+                seeds.append(_write(d, f"z{i}{level}", data, pa.Codec("zstd", compression_level=level).compress(data, asbytes=True)))
+            sink = pa.BufferOutputStream()
+            with pa.CompressedOutputStream(sink, "zstd") as o:
+                o.write(data)
+            seeds.append(_write(d, f"z{i}s", data, sink.getvalue().to_pybytes()))
         else:
             for j, (level, strategy) in enumerate([(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY),
                                                    (9, zlib.Z_HUFFMAN_ONLY)]):

@@ -303,19 +303,24 @@ def test_host_index_sizes_compressed_batches():
     blob, expected, info = random_record_set(rng, 60, snappy=True)
     rc, descs, st = index_host(blob, 3)
     assert rc == N.KTA_OK and st.n_snappy == info["snappy"] > 0 and st.n_lz4 == info["lz4"] > 0
-    assert st.n_gzip == info["gzip"] > 0
+    assert st.n_gzip == info["gzip"] > 0 and st.n_zstd == info["zstd"] > 0
     cols, ost = kafka_decode(blob, 3)
     assert_columns(cols, expected)
     inflate_at = (len(blob) + 127) & ~63
     run = 0
     for i in range(st.n_batches):
         d = descs[i]
-        if d.flags & (4 | 8 | 16):  # KTA_KB_SNAPPY / _LZ4 / _GZIP: a 64-byte aligned slice of the inflate area
+        if d.flags & (4 | 8 | 16 | 32):  # KTA_KB_SNAPPY / _LZ4 / _GZIP / _ZSTD: a 64-byte aligned slice of the inflate area
             assert d.payload_off == inflate_at + run and d.payload_off % 64 == 0
             if d.flags & 8:    # LZ4 frames do not carry their size: the slice is a bound (<= 255x per block)
                 clen = d.batch_bytes - 61
                 assert 0 < d.payload_end - d.payload_off <= 255 * clen + 64 * (clen // 4)
             run += (d.payload_end - d.payload_off + 63) & ~63
+            if d.flags & 32:   # zstd: the decoder's tables and literals follow the slice
+                assert d.scratch_end > ((d.payload_end + 63) & ~63) + 10000
+                run += (d.scratch_end - ((d.payload_end + 63) & ~63) + 63) & ~63
+            else:
+                assert d.scratch_end == d.payload_end
         else:
             assert (d.payload_off, d.payload_end) == (d.byte_off + 61, d.byte_off + d.batch_bytes)
     assert run == st.inflate_bytes
@@ -409,6 +414,50 @@ def test_gzip_inflate_host_against_zlib():
     assert refused > 50
 
 
+def test_zstd_inflate_host_against_libzstd():
+    """The product's Zstandard decoder (the function the device runs, compiled for the host) on frames
+    written by libzstd (through pyarrow): one-shot frames at levels -5..22 (content size, single segment),
+    streaming frames (window descriptor, no content size, flushed mid-way), multi-block inputs, raw and
+    RLE blocks; refusals for truncated / corrupted frames."""
+    pa = pytest.importorskip("pyarrow")
+    import ctypes as C2
+    lib = N.load()
+    rng = np.random.default_rng(8)
+    cases = _library_cases() + [bytes(rng.integers(0, 16, size=400000, dtype=np.uint8)),
+                                b"".join(bytes([int(x)]) * int(y) for x, y in zip(rng.integers(0, 256, 3000), rng.integers(1, 300, 3000)))]
+
+    def check(comp, d):
+        out = C2.create_string_buffer(len(d) + 1)
+        assert lib.kta_zstd_inflate_host(comp, len(comp), out, len(d)) == len(d), (len(d), len(comp))
+        assert out.raw[:len(d)] == d
+
+    for d in cases:
+        for level in (-5, 1, 3, 9, 19, 22):
+            check(pa.Codec("zstd", compression_level=level).compress(d, asbytes=True), d)
+        sink = pa.BufferOutputStream()
+        with pa.CompressedOutputStream(sink, "zstd") as o:
+            o.write(d[:len(d) // 2])
+            o.flush()
+            o.write(d[len(d) // 2:])
+        check(sink.getvalue().to_pybytes(), d)
+    d = cases[6]
+    good = pa.Codec("zstd", compression_level=3).compress(d, asbytes=True)
+    check(good + good, d + d)                                  # concatenated frames
+    out = C2.create_string_buffer(len(d) + 64)
+    assert lib.kta_zstd_inflate_host(good[:-7], len(good) - 7, out, len(d)) == -1
+    assert lib.kta_zstd_inflate_host(b"\x28\xb5\x2f\xfe" + good[4:], len(good), out, len(d)) == -1
+    assert lib.kta_zstd_inflate_host(good, len(good), out, len(d) - 1) == -1
+    refused = 0
+    for _ in range(300):                                       # flipped bits never crash and never write past `cap`
+        bad = bytearray(good)
+        bad[int(rng.integers(4, len(good)))] ^= 1 << int(rng.integers(0, 8))
+        guard = C2.create_string_buffer(len(d) + 64)
+        got = lib.kta_zstd_inflate_host(bytes(bad), len(bad), guard, len(d))
+        assert -1 <= got <= len(d) and guard.raw[len(d):] == bytes(64)
+        refused += got == -1
+    assert refused > 100
+
+
 def _library_cases():
     rng = np.random.default_rng(17)
     text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(40000))
@@ -465,7 +514,7 @@ def test_device_inflates_streams_of_the_real_libraries():
 def test_device_decodes_snappy_batches(variant):
     rng = np.random.default_rng(33)
     blob, expected, info = random_record_set(rng, 160, max_records=120, snappy=True)
-    assert info["snappy"] > 10 and info["lz4"] > 10 and info["gzip"] > 20
+    assert info["snappy"] > 8 and info["lz4"] > 8 and info["gzip"] > 15 and info["zstd"] > 10
     want, _ = kafka_decode(blob, 3)
     lib = N.load()
     lib.kta_kafka_set_variant(variant)
@@ -473,6 +522,7 @@ def test_device_decodes_snappy_batches(variant):
         h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))   # the CRC covers the compressed bytes
         cols, st, bad = _decode_on_device(h, blob, 3, True)
         assert bad == 0 and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"] and st.n_gzip == info["gzip"]
+        assert st.n_zstd == info["zstd"]
         assert_columns(cols, expected, key_check=True)
         for k in ("partition", "key_len", "val_len", "ts_ms"):
             assert np.array_equal(cols[k], want[k]), k
@@ -552,7 +602,7 @@ def test_consume_snappy_record_sets_end_to_end():
             h._check(lib.kta_kafka_consume(h._ctx, blob, len(blob), part, C.byref(st)))
             cols, _ = kafka_decode(blob, part)
             assert st.n_records == len(cols["partition"]) and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"]
-            assert st.n_gzip == info.get("gzip", 0)
+            assert st.n_gzip == info.get("gzip", 0) and st.n_zstd == info.get("zstd", 0)
             o.run_soa({k: v for k, v in cols.items() if k != "offset"})
         res, c = h.finish()
         assert np.array_equal(c, o.counters(P))
