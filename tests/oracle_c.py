@@ -188,10 +188,13 @@ def _zstd_batches_to_plain(blob: bytes) -> bytes:
     return bytes(out) + blob[pos:]
 
 
-def kafka_decode(blob: bytes, partition: int):
-    """The oracle's sequential decode of one Kafka v2 record set -> (columns dict, stats)."""
+def kafka_decode(blob: bytes, partition: int, transcode_zstd: bool = True):
+    """The oracle's sequential decode of one Kafka v2 record set -> (columns dict, stats).
+    transcode_zstd=False skips the Python walk that hands zstd batches to libzstd (bench.py times the C
+    decoder alone on a blob it knows to be uncompressed)."""
     L = lib()
-    blob = _zstd_batches_to_plain(blob)
+    if transcode_zstd:
+        blob = _zstd_batches_to_plain(blob)
     L.kto_kafka_decode.restype = C.c_int64
     L.kto_kafka_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_int32] + [C.c_void_p] * 7 + [C.POINTER(C.c_uint64),
                                                                                           C.POINTER(KafkaStats)]
