@@ -131,6 +131,12 @@ int kta_kafka_configure(kta_ctx *ctx, uint64_t blob_capacity, int n_stages);  /*
 int kta_kafka_blob_acquire(kta_ctx *ctx, uint8_t **host_ptr, uint64_t *capacity);
 int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kafka_index_stats *stats);
 
+/* Compressed batches of a blob are inflated in groups whose slices of the inflate area span at most
+ * `bytes` (0 = default, 1 GiB): the slices are sized by per-batch bounds, so this caps the device memory a
+ * blob of many small compressed batches can ask for and keeps key offsets inside 32 bits.  A single batch
+ * larger than the limit still goes through alone. */
+int kta_kafka_set_inflate_limit(kta_ctx *ctx, uint64_t bytes);
+
 /* Convenience for hosts that hold the raw bytes in ordinary memory: memcpy into the staging ring
  * (chunked at batch boundaries) and submit (records get consecutive sequence numbers). */
 int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t partition,

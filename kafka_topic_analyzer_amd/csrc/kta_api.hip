@@ -227,10 +227,6 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         if ((ctx->alive_variant == 8 || ctx->alive_variant == 9) && ctx->hash_scratch_cap < n) {
             KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
             if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
-    if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
-    if (ctx->d_exp_slots) (void)hipFree(ctx->d_exp_slots);
-    if (ctx->d_exp_vals) (void)hipFree(ctx->d_exp_vals);
-    if (ctx->d_exp_count) (void)hipFree(ctx->d_exp_count);
             ctx->d_hash_scratch = nullptr;
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;

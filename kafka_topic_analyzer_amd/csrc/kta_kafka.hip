@@ -866,6 +866,7 @@ struct KafkaState {
     bool check_crcs = false;
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
+    uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1298,17 +1299,51 @@ int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kaf
     if (rc != KTA_OK) return rc;
     if (stats->n_batches == 0) return KTA_OK;
     const bool keys = kta_internal_count_alive(ctx);
-    const uint64_t used = stats->bytes_consumed, nrec = stats->n_records;
-    if (inflate_at + stats->inflate_bytes + 128 > g.d_cap) {   // compressed batches: grow the device buffer (stage is idle)
+    const uint64_t used = stats->bytes_consumed, nrec = stats->n_records, nb = stats->n_batches;
+    // Compressed batches inflate into an area behind the raw bytes.  Its size is a bound per batch (zstd /
+    // LZ4 frames without a content size: blocks x block maximum), so a blob of many small batches could ask
+    // for far more than it will use — and keys are addressed with 32-bit offsets into this one buffer.  The
+    // batches are therefore processed in groups whose inflate span stays under a limit; the groups reuse
+    // the area, which is safe because everything of a group (inflate, decode, both handlers) is enqueued on
+    // the compute stream before the next group's inflate.
+    uint64_t limit = st->inflate_limit ? st->inflate_limit : (1ull << 30);
+    const uint64_t addressable = (1ull << 32) - (128ull << 20);
+    if (keys && inflate_at + limit > addressable) limit = addressable > inflate_at + (64ull << 20) ? addressable - inflate_at : (64ull << 20);
+    auto inflate_lo = [&](uint64_t i) { return g.h_descs[i].payload_off; };   // compressed batches only
+    auto is_comp = [&](uint64_t i) { return (g.h_descs[i].flags & (KTA_KB_SNAPPY | KTA_KB_LZ4 | KTA_KB_GZIP | KTA_KB_ZSTD)) != 0; };
+    auto inflate_hi = [&](uint64_t i) {
+        const uint64_t e = g.h_descs[i].scratch_end > g.h_descs[i].payload_end ? g.h_descs[i].scratch_end : g.h_descs[i].payload_end;
+        return (e + 63) & ~63ull;
+    };
+    std::vector<uint64_t> cut{0};                         // group k = batches [cut[k], cut[k+1])
+    uint64_t max_span = 0;
+    {
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint64_t i = 0; i < nb; i++) {
+            if (!is_comp(i)) continue;
+            if (lo != ~0ull && inflate_hi(i) - lo > limit) {   // would exceed: close the group before batch i
+                cut.push_back(i);
+                if (hi - lo > max_span) max_span = hi - lo;
+                lo = ~0ull;
+            }
+            if (lo == ~0ull) lo = inflate_lo(i);
+            hi = inflate_hi(i);
+        }
+        if (lo != ~0ull && hi - lo > max_span) max_span = hi - lo;
+        cut.push_back(nb);
+    }
+    if (inflate_at + max_span + 128 > g.d_cap) {   // grow the device buffer (the stage is idle here)
         (void)hipFree(g.d_blob);
         g.d_blob = nullptr;
-        g.d_cap = inflate_at + stats->inflate_bytes + stats->inflate_bytes / 4 + 4096;
+        g.d_cap = inflate_at + max_span + max_span / 4 + 4096;
         KK(ctx, hipMalloc((void **)&g.d_blob, g.d_cap));
     }
-    // 2. decoded columns of this stage (grown on demand; the stage is idle here)
-    if (g.out_cap < nrec || (keys && !g.out.key_off)) {
+    // 2. decoded columns of this stage (grown on demand; the stage is idle here).  Every group is submitted
+    // as its own batch, whose columns must start 16-byte aligned: a group's records start at a multiple of 4.
+    const uint64_t ncol = nrec + 4 * (cut.size() - 1);
+    if (g.out_cap < ncol || (keys && !g.out.key_off)) {
         free_out(g.out);
-        g.out_cap = nrec + nrec / 4 + 1024;
+        g.out_cap = ncol + ncol / 4 + 1024;
         KK(ctx, hipMalloc((void **)&g.out.partition, g.out_cap * 4 + 16));
         KK(ctx, hipMalloc((void **)&g.out.key_len, g.out_cap * 4 + 16));
         KK(ctx, hipMalloc((void **)&g.out.val_len, g.out_cap * 4 + 16));
@@ -1317,16 +1352,43 @@ int kta_kafka_blob_submit(kta_ctx *ctx, uint64_t len, int32_t partition, kta_kaf
         g.out.capacity = g.out_cap;
     }
     g.out.key_bytes = keys ? g.d_blob : nullptr; // zero-copy: keys are hashed in place in the raw log
-    g.out.key_bytes_capacity = keys ? inflate_at + stats->inflate_bytes : 0;
+    g.out.key_bytes_capacity = keys ? inflate_at + max_span : 0;
     // 3. raw log over PCIe on the copy stream; decode + metric handlers on the compute stream
     KK(ctx, hipMemcpyAsync(g.d_blob, g.h_blob, (used + 63) & ~63ull, hipMemcpyHostToDevice, cs));
     KK(ctx, hipEventRecord(g.copied, cs));
     KK(ctx, hipStreamWaitEvent(s, g.copied, 0));
-    rc = kta_kafka_decode_device(ctx, g.d_blob, used, g.h_descs, stats->n_batches, nrec, &g.out, nullptr, nullptr);
-    if (rc != KTA_OK) return rc;
     const uint64_t base = kta_internal_take_seq(ctx, nrec);
-    rc = kta_submit_device(ctx, &g.out, nrec, base);
-    if (rc != KTA_OK) return rc;
+    for (size_t k = 0; k + 1 < cut.size(); k++) {
+        const uint64_t b0 = cut[k], b1 = cut[k + 1];
+        if (b0 == b1) continue;
+        uint64_t shift = 0;                               // this group's inflate slices start at inflate_at
+        for (uint64_t i = b0; i < b1; i++)
+            if (is_comp(i)) { shift = inflate_lo(i) - inflate_at; break; }
+        if (shift)
+            for (uint64_t i = b0; i < b1; i++)
+                if (is_comp(i)) {
+                    g.h_descs[i].payload_off -= shift;
+                    g.h_descs[i].payload_end -= shift;
+                    g.h_descs[i].scratch_end -= shift;
+                }
+        const uint64_t r0 = g.h_descs[b0].record_base;                       // consumption index of the group's first record
+        const uint64_t r1 = b1 < nb ? g.h_descs[b1].record_base : nrec;
+        const uint64_t c0 = (r0 + 4 * k + 3) & ~3ull;                         // its place in the columns: aligned, past group k-1
+        if (c0 != r0)
+            for (uint64_t i = b0; i < b1; i++) g.h_descs[i].record_base += c0 - r0;
+        rc = kta_kafka_decode_device(ctx, g.d_blob, used, g.h_descs + b0, b1 - b0, ncol, &g.out, nullptr, nullptr);
+        if (rc != KTA_OK) return rc;
+        kta_batch view = g.out;                           // this group's records: [c0, c0 + r1 - r0) of the stage's columns
+        view.partition += c0;
+        view.key_len += c0;
+        view.val_len += c0;
+        view.ts_ms += c0;
+        if (view.key_off) view.key_off += c0;
+        if (view.seq) view.seq += c0;
+        view.capacity = r1 - r0;
+        rc = kta_submit_device(ctx, &view, r1 - r0, base + r0);
+        if (rc != KTA_OK) return rc;
+    }
     KK(ctx, hipEventRecord(g.done, s));
     g.busy = true;
     st->cur = (st->cur + 1) % (int)st->stages.size();
@@ -1376,6 +1438,13 @@ int kta_kafka_consume(kta_ctx *ctx, const uint8_t *bytes, uint64_t len, int32_t 
         pos += one.bytes_consumed;
         stats->trailing_bytes = len - pos;
     }
+    return KTA_OK;
+}
+
+int kta_kafka_set_inflate_limit(kta_ctx *ctx, uint64_t bytes)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    state_of(ctx)->inflate_limit = bytes;
     return KTA_OK;
 }
 

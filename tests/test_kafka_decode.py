@@ -589,12 +589,16 @@ def test_device_inflate_far_matches_and_long_literals():
 
 
 @pytest.mark.gpu
-def test_consume_snappy_record_sets_end_to_end():
+@pytest.mark.parametrize("inflate_limit", [0, 150_000])
+def test_consume_snappy_record_sets_end_to_end(inflate_limit):
+    """All codecs through the staging pipeline; with a small inflate limit the batches of a blob are
+    processed in many groups that reuse the inflate area (keys are hashed in place there)."""
     lib = N.load()
     rng = np.random.default_rng(44)
     P = 3
     o = Oracle(NOW, True)
     with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+        h._check(lib.kta_kafka_set_inflate_limit(h._ctx, inflate_limit))
         for fetch in range(5):
             part = fetch % P
             blob, expected, info = random_record_set(rng, 40, partition=part, key_space=60, snappy=True)
