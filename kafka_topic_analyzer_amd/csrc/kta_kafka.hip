@@ -1,13 +1,19 @@
-// kta_kafka.hip — Kafka record-batch v2 decode (include/kta_kafka.h): host header index +
-// gfx950 kernels that parse the varint-framed records of every batch into the struct-of-arrays
-// columns the metric kernels consume.
+// kta_kafka.hip — Kafka record-batch v2 decode (include/kta_kafka.h): host header index + gfx950 kernels
+// that turn raw record sets into the struct-of-arrays columns the metric kernels consume.
 //
-// Parallelisation: batches are independent (each carries its own base timestamp and record count),
-// records inside a batch form a linked list (record length prefixes), so the unit of parallelism is
-// the batch: one lane walks one batch.  A broker segment holds tens of thousands of batches per GB
-// (producer batch.size defaults to 16 KiB), so a fetch blob keeps every SIMD busy; the walk touches
-// only the record headers and the keys — value bytes are skipped, exactly as the reference's
-// handlers never read them (src/metric.rs:233-245).
+//   host    kta_kafka_index_host      walks the 61-byte batch headers, sizes the inflate slices
+//   device  kafka_crc32c              optional CRC-32C check (librdkafka's check.crcs), one wave per batch
+//           kafka_snappy_inflate_coop / kafka_lz4_inflate_coop   wave-cooperative inflate (64 bytes per step)
+//           kafka_gzip_inflate / kafka_zstd_inflate              bit-serial entropy stages: one lane per batch
+//           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows
+//           kafka_decode / kafka_inflate_lane                    one-lane-per-batch forms kept for comparison
+//   host    kta_kafka_blob_acquire / _submit / kta_kafka_consume   pinned staging ring -> PCIe -> the above ->
+//                                                                  kta_submit_device (both handlers)
+//
+// Batches are independent (each carries its own base timestamp and record count); the records inside a
+// batch form a linked list (length prefixes).  Value bytes are never needed — the reference's handlers
+// only take their length (src/metric.rs:233-245) — and keys stay where they are (key_off points into the
+// raw blob / inflate area).
 #include "../../include/kta_kafka.h"
 #include "../../include/kta_synth.h"
 #include "kta_snappy.h"
