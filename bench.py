@@ -100,13 +100,16 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     h = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
     b = h.device_batch_alloc(n_records, n_records * 16)
     kb = h.synth_fill_device(spec, 0, n_records, b)
-    for _ in range(warmup):
-        h.submit_device(b, n_records, 0, which=2)
+    # Every pass presents the records with LATER sequence numbers than the table holds (a topic keeps
+    # growing): replaying identical sequence numbers would let the pre-read of the default kernel skip
+    # every record after the first pass.
+    for k in range(warmup):
+        h.submit_device(b, n_records, k * n_records, which=2)
     h.sync()
     h.set_timing(True)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        h.submit_device(b, n_records, 0, which=2)
+    for k in range(steps):
+        h.submit_device(b, n_records, (warmup + k) * n_records, which=2)
     h.sync()
     wall = time.perf_counter() - t0
     avg_ms, cnt = h.kernel_time_stats()
@@ -118,12 +121,12 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     out = {"workload": f"c3 shape: 64 partitions, {n_records} records, 16 B keys, 10M distinct, 10% tombstones",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
            "alive_keys": int(res.alive_keys),
-           "roofline": {"bound": "hbm", "kernel": "kta_alive_update",
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_update_filtered",
                         "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": _traffic("kta_alive_update", n_records),
-                        "note": "random 8-byte atomicMax RMWs into the 32 GiB last-writer table dominate; "
+                        "traffic": _traffic("kta_alive_update_filtered", n_records),
+                        "note": "random 8-byte reads and atomicMax RMWs of the 32 GiB last-writer table dominate; "
                                 "their traffic is not part of the algorithmic bytes"}}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)

@@ -279,7 +279,9 @@ int kta_render_report(const char *topic, uint64_t duration_secs, const uint64_t 
  * (avg -1 when none). */
 int kta_set_timing(kta_ctx *ctx, int enable);
 int kta_kernel_time_stats(kta_ctx *ctx, float avg_ms[3], uint64_t launches[3]);
-/* Launch-geometry knobs (0 = default): scan workgroups, LDS replication log2, alive WGs. */
+/* Launch-geometry knobs (0 = default): scan workgroups, scan kernel flavour (16 = non-temporal loads),
+ * alive workgroups, alive kernel: 0 plain atomicMax, 1 returning atomicMax + running alive count (default),
+ * 2 the same walked backwards with a pre-read that skips superseded records, 8 / 9 ablation halves. */
 int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups,
                    int alive_variant);
 

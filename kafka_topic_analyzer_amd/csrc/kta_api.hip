@@ -54,7 +54,7 @@ struct kta_ctx {
     uint64_t fill_n = 0, fill_kb = 0; // kta_handle_message fill state
     uint64_t next_seq = 0;
     // tuning / profiling
-    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 1; // 16: non-temporal loads; 1: running alive count
+    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 2; // 16: non-temporal loads; 2: filtered counting kernel
     bool timing = false;
     // HIP-event pairs recorded around each kernel on the compute stream (no host sync while
     // recording); drained by kta_kernel_time_stats.  kind: 0 scan, 1 fold, 2 alive update.
@@ -231,7 +231,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;
         }
-        if (ctx->alive_variant != 1) ctx->running_valid = false;
+        if (ctx->alive_variant != 1 && ctx->alive_variant != 2) ctx->running_valid = false;   // non-counting kernels
         KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
                                               ctx->alive_variant, ctx->d_hash_scratch, ctx->d_alive_running,
                                               ctx->s_compute));
@@ -548,7 +548,7 @@ int kta_finish_device(kta_ctx *ctx)
     if (rc != KTA_OK) return rc;
     if (ctx->alive) {
         uint64_t *dst = ctx->d_vec + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
-        if (ctx->running_valid && ctx->alive_variant == 1)  // exact running count, no table scan
+        if (ctx->running_valid)  // exact running count (every update so far ran a counting kernel): no table scan
             KTA_HIP(ctx, hipMemcpyAsync(dst, ctx->d_alive_running, sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                         ctx->s_compute));
         else

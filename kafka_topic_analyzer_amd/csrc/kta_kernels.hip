@@ -596,6 +596,42 @@ __global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c,
     }
 }
 
+// Variant 2: the counting kernel with a pre-read and the batch walked from its END.  A record only needs
+// the table if no later record owns its slot yet; walking the batch backwards lets the LAST record of a
+// key arrive first, so the earlier ones (a compacted topic repeats its keys) find a larger entry with a
+// plain load and skip the memory-side atomic, which is the scarce resource (section 3.3 of DESIGN.md).
+// Exactness does not depend on the order or on what the load sees: entries only grow, so `seen >= v`
+// proves that a later record has already been applied, and a stale smaller value merely costs the atomic.
+__global__ __launch_bounds__(kWG) void kta_alive_update_filtered(AliveColumns c, uint64_t n, uint64_t base_seq,
+                                                                 unsigned long long *__restrict__ table,
+                                                                 long long *__restrict__ running)
+{
+    __shared__ long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    long long delta = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * kWG + threadIdx.x; j < n; j += stride) {
+        const uint64_t i = n - 1 - j;                      // highest sequence numbers first
+        const int32_t kl = c.key_len[i];
+        if (kl < 0) continue;
+        const uint32_t h = fnv32_global(c.key_bytes + c.key_off[i], (uint32_t)kl);
+        const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
+        const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
+        const unsigned long long seen = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= v) continue;
+        const unsigned long long old = atomicMax(&table[h], v);
+        if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) delta += __shfl_xor(delta, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = delta;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(running), (unsigned long long)t);
+    }
+}
+
 // Ablation kernels (alive_variant 8 / 9): hash only (h -> scratch) and table update only
 // (h <- scratch).  Used to attribute time; the pair is also a valid two-phase implementation.
 __global__ __launch_bounds__(kWG) void kta_alive_hash_only(AliveColumns c, uint64_t n, uint32_t *__restrict__ hout)
@@ -869,6 +905,9 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
         hipLaunchKernelGGL(kta_alive_hash_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, scratch);
     } else if (variant == 9 && scratch) {
         hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t);
+    } else if (variant == 2 && running) {
+        hipLaunchKernelGGL(kta_alive_update_filtered, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
+                           reinterpret_cast<long long *>(running));
     } else if (variant == 1 && running) {
         hipLaunchKernelGGL(kta_alive_update_counting, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
                            reinterpret_cast<long long *>(running));

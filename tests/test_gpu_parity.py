@@ -247,10 +247,11 @@ def test_running_alive_count_equals_table_scan(hc):
     assert r3.alive_keys == o.alive_keys()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_alive_kernels_under_heavy_slot_contention(hc, variant):
-    """Both alive-update kernels (plain atomicMax; returning atomicMax + running count) leave exactly the
-    table sequential BitSet semantics leaves — 40 keys over 120k records is heavy same-slot contention."""
+    """Every alive-update kernel (plain atomicMax; returning atomicMax + running count; the same walked
+    backwards with a pre-read that skips superseded records) leaves exactly the table sequential BitSet
+    semantics leaves — 40 keys over 120k records is heavy same-slot contention."""
     rng = np.random.default_rng(500 + variant)
     o = Oracle(NOW, True)
     hc.reset()
@@ -376,6 +377,15 @@ def test_full_size_properties_alive_pass(hc):
     hc.submit_device(b, n, 0, which=2)  # idempotent under replay with identical sequence numbers
     r2, _ = hc.finish()
     assert r1.alive_keys == r2.alive_keys and 0 < r1.alive_keys <= 10_000_000
+    words1 = hc.export_alive_bitmap()
+    hc.reset()
+    hc.set_tuning(alive_variant=2)      # the filtered kernel (backwards walk + pre-read): same set, same count
+    hc.submit_device(b, n, 0, which=2)
+    rf, _ = hc.finish()
+    hc.set_tuning()
+    assert rf.alive_keys == r1.alive_keys and np.array_equal(hc.export_alive_bitmap(), words1)
+    hc.alive_table_modified()
+    assert hc.finish()[0].alive_keys == r1.alive_keys       # its running count equals a recount
     # kill everything: same keys, later sequence numbers, all tombstones
     sp2, _ = kta.synth_preset("c3")
     sp2.tombstone_permille = 1000
