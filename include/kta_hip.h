@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 1
+#define KTA_ABI_VERSION 2   /* 2: kta_kafka_batch_desc.scratch_end, kta_kafka_index_stats.n_gzip / n_zstd */
 
 /* status codes */
 #define KTA_OK 0

@@ -161,6 +161,9 @@ SIGNATURES = {
 _lib = None
 
 
+KTA_ABI_VERSION = 2  # include/kta_hip.h
+
+
 def load() -> C.CDLL:
     """Load libkta_hip.so; raise loudly when it has not been built."""
     global _lib
@@ -175,7 +178,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kta_abi_version() != 1:
-        raise ImportError("libkta_hip.so ABI version mismatch")
+    if lib.kta_abi_version() != KTA_ABI_VERSION:   # struct layouts below must match the library's
+        raise ImportError(f"libkta_hip.so has ABI version {lib.kta_abi_version()}, this package expects "
+                          f"{KTA_ABI_VERSION}: rebuild with `python -m kafka_topic_analyzer_amd.build`")
     _lib = lib
     return lib

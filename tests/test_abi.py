@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libkta_hip.so does not export {name}"
     assert declared == set(N.SIGNATURES.keys())
-    assert lib.kta_abi_version() == 1
+    assert lib.kta_abi_version() == N.KTA_ABI_VERSION == int(re.search(r"#define KTA_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "kta_hip.h")).read()).group(1))
 
 
 def test_library_is_gfx950_code_object():
