@@ -989,7 +989,7 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
             stats->n_old_magic++;
         } else {
             const uint16_t attrs = be16(bytes + pos + 21);
-            const int32_t count = (int32_t)be32(bytes + pos + 57);
+            int32_t count = (int32_t)be32(bytes + pos + 57);
             const uint32_t codec = attrs & 0x07u;
             int64_t inflated = 0;
             if (codec == 2) {
@@ -1017,12 +1017,19 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
             else if (codec > 4) stats->n_compressed++;                    // unknown codecs (5..7): not decoded here
             else if (count > 0) {
+                // A record occupies at least 7 bytes (length, attributes, timestamp delta, offset delta, key
+                // length, value length, header count).  A header that announces more records than its payload
+                // can hold is corrupt: the batch is reported, and the count is clamped so that a forged
+                // header cannot ask for billions of output slots.
+                const uint64_t payload_bytes = codec == 0 ? total - KTA_KAFKA_BATCH_HEADER : (uint64_t)(inflated > 0 ? inflated : 0);
+                const bool forged = (uint64_t)count > payload_bytes / 7 + 1;
+                if (forged) count = (int32_t)(payload_bytes / 7 + 1);
                 if (nb < cap) {
                     kta_kafka_batch_desc &d = descs[nb];
                     d.byte_off = blob_offset + pos;
                     d.record_base = rec;
                     d.crc = be32(bytes + pos + 17);
-                    d.status = 0;
+                    d.status = forged ? KTA_KB_BAD_FRAMING : 0u;
                     d.base_offset = (int64_t)be64(bytes + pos);
                     d.base_ts_ms = (int64_t)be64(bytes + pos + 27);
                     d.max_ts_ms = (int64_t)be64(bytes + pos + 35);

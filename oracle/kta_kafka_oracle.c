@@ -72,6 +72,12 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         st->batches++;
         const uint8_t *p = b + 61;
         int bad = 0;
+        /* a record takes at least 7 bytes: an uncompressed batch announcing more records than fit is
+         * corrupt as a whole (the product clamps the count the same way and delivers none of them) */
+        if ((attrs & 0x07) == 0 && (uint64_t)count > (total - 61) / 7 + 1) {
+            count = (int32_t)((total - 61) / 7 + 1);
+            bad = 1;
+        }
         uint8_t *inflated = NULL;
         if ((attrs & 0x07) != 0) { /* gzip / Snappy / LZ4: the records section is compressed as a whole */
             uint64_t cap = (total - 61) * 1100 + (1u << 22);

@@ -97,6 +97,28 @@ def test_oracle_marks_corrupt_batches():
     assert st.bad_batches == 1 and list(cols["partition"]) == [0, 0, 0, 0, -1]
 
 
+def _forged_count_blob():
+    good = K.encode_batch(0, [(0, b"a", b"b"), (1, b"c", None)], 1000)
+    forged = K.encode_batch(10, [(0, b"k%d" % i, b"v") for i in range(5)], 1000, count=2**31 - 1)
+    return good + forged + good, len(forged) - 61
+
+
+def test_forged_record_count_is_clamped_and_reported():
+    """A header announcing more records than its payload can hold (a record takes >= 7 bytes) is corrupt:
+    the count is clamped — no billions of output slots — and none of the batch is delivered.  Index and
+    oracle agree on what comes out."""
+    blob, payload = _forged_count_blob()
+    rc, descs, st = index_host(blob, 5)
+    assert rc == N.KTA_OK and st.n_batches == 3
+    assert [descs[i].status for i in range(3)] == [0, 2, 0]                  # KTA_KB_BAD_FRAMING
+    assert descs[1].n_records == payload // 7 + 1 and st.n_records == 4 + descs[1].n_records
+    assert descs[2].record_base == 2 + descs[1].n_records
+    cols, ost = kafka_decode(blob, 5)
+    assert ost.bad_batches == 1 and len(cols["partition"]) == st.n_records
+    assert list(cols["partition"][:2]) == [5, 5] and (cols["partition"][2:-2] == -1).all()
+    assert list(cols["partition"][-2:]) == [5, 5]
+
+
 # --------------------------------------------------------------------------------------------- GPU
 def _decode_on_device(h, blob, partition, with_keys):
     lib = N.load()
@@ -158,6 +180,20 @@ def test_device_decode_reports_corrupt_batches():
             cols, st, nbad = _decode_on_device(h, blob, 0, True)
             assert nbad == 1 == ost.bad_batches
             assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
+    N.load().kta_kafka_set_variant(0)
+
+
+@pytest.mark.gpu
+def test_device_does_not_deliver_a_batch_with_a_forged_record_count():
+    blob, _ = _forged_count_blob()
+    want, ost = kafka_decode(blob, 5)
+    for variant in (0, 1):
+        N.load().kta_kafka_set_variant(variant)
+        with kta.HipMetricHandler(8, now=NOW) as h:
+            cols, st, nbad = _decode_on_device(h, blob, 5, True)
+            assert nbad == 1 == ost.bad_batches
+            for k in ("partition", "key_len", "val_len", "ts_ms"):
+                assert np.array_equal(cols[k], want[k]), k
     N.load().kta_kafka_set_variant(0)
 
 
