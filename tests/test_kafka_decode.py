@@ -119,6 +119,48 @@ def test_forged_record_count_is_clamped_and_reported():
     assert list(cols["partition"][-2:]) == [5, 5]
 
 
+def test_host_index_invariants_on_mutated_blobs():
+    """The header walk on corrupted record sets: never crashes, and whatever it describes stays inside the
+    blob / the inflate area it sized — the device trusts these descriptors."""
+    rng = np.random.default_rng(123)
+    base, _, _ = random_record_set(rng, 40, max_records=30, snappy=True)
+    checked = 0
+    for it in range(400):
+        blob = bytearray(base)
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 3))
+            at = int(rng.integers(0, len(blob)))
+            if kind == 0:
+                blob[at] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                blob[at] = int(rng.integers(0, 256))
+            else:
+                del blob[at:at + int(rng.integers(1, 40))]
+        blob = bytes(blob)
+        inflate_at = (len(blob) + 127) & ~63
+        rc, descs, st = index_host(blob, 1)
+        assert rc == N.KTA_OK
+        assert st.bytes_consumed + st.trailing_bytes == len(blob)
+        rec, hi = 0, inflate_at
+        for i in range(st.n_batches):
+            d = descs[i]
+            assert d.byte_off + d.batch_bytes <= st.bytes_consumed and d.batch_bytes >= 61
+            assert d.record_base == rec and 0 < d.n_records
+            rec += d.n_records
+            if d.flags & (4 | 8 | 16 | 32):
+                assert inflate_at <= d.payload_off <= d.payload_end <= d.scratch_end
+                assert d.payload_off >= hi - 0 and d.payload_off % 64 == 0     # slices do not overlap
+                hi = (d.scratch_end + 63) & ~63
+                payload = d.payload_end - d.payload_off
+            else:
+                assert (d.payload_off, d.payload_end) == (d.byte_off + 61, d.byte_off + d.batch_bytes)
+                payload = d.batch_bytes - 61
+            assert d.n_records <= payload // 7 + 1                            # forged counts are clamped
+            checked += 1
+        assert rec == st.n_records and hi - inflate_at <= st.inflate_bytes
+    assert checked > 5000
+
+
 # --------------------------------------------------------------------------------------------- GPU
 def _decode_on_device(h, blob, partition, with_keys):
     lib = N.load()
