@@ -1020,8 +1020,18 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                 // A record occupies at least 7 bytes (length, attributes, timestamp delta, offset delta, key
                 // length, value length, header count).  A header that announces more records than its payload
                 // can hold is corrupt: the batch is reported, and the count is clamped so that a forged
-                // header cannot ask for billions of output slots.
-                const uint64_t payload_bytes = codec == 0 ? total - KTA_KAFKA_BATCH_HEADER : (uint64_t)(inflated > 0 ? inflated : 0);
+                // header cannot ask for billions of output slots.  The payload of an uncompressed batch is
+                // its own bytes; of a compressed one, at most the codec's maximum expansion of its bytes
+                // (a rule that depends on the header alone, never on the size probe: a batch whose stream
+                // is corrupt keeps its announced records, all of them flagged).  zstd has no useful
+                // expansion limit (an RLE block is 4 bytes for 128 KiB), so there the frame's own bound
+                // is used when the scan found one.
+                const uint64_t clen = total - KTA_KAFKA_BATCH_HEADER;
+                const uint64_t payload_bytes = codec == 0 ? clen
+                                             : codec == 1 ? clen * 1032 + 64
+                                             : codec == 2 ? clen * 22 + 64
+                                             : codec == 3 ? clen * 255 + 64
+                                             : (inflated > 0 ? (uint64_t)inflated : clen * 1032 + 64);
                 const bool forged = (uint64_t)count > payload_bytes / 7 + 1;
                 if (forged) count = (int32_t)(payload_bytes / 7 + 1);
                 if (nb < cap) {

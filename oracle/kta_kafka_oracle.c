@@ -72,11 +72,18 @@ int64_t kto_kafka_decode(const uint8_t *bytes, uint64_t len, int32_t partition, 
         st->batches++;
         const uint8_t *p = b + 61;
         int bad = 0;
-        /* a record takes at least 7 bytes: an uncompressed batch announcing more records than fit is
-         * corrupt as a whole (the product clamps the count the same way and delivers none of them) */
-        if ((attrs & 0x07) == 0 && (uint64_t)count > (total - 61) / 7 + 1) {
-            count = (int32_t)((total - 61) / 7 + 1);
-            bad = 1;
+        /* a record takes at least 7 bytes: a batch announcing more records than its payload can hold is
+         * corrupt as a whole (the product clamps the count the same way and delivers none of them).  The
+         * payload bound depends on the header alone: the batch's own bytes when uncompressed, the codec's
+         * maximum expansion of them otherwise (gzip 1032x, Snappy 22x, LZ4 255x) -- so a compressed batch
+         * whose stream turns out corrupt keeps its announced count, every record flagged. */
+        {
+            uint64_t clen = total - 61, codec = attrs & 0x07;
+            uint64_t payload = codec == 0 ? clen : codec == 1 ? clen * 1032 + 64 : codec == 2 ? clen * 22 + 64 : clen * 255 + 64;
+            if ((uint64_t)count > payload / 7 + 1) {
+                count = (int32_t)(payload / 7 + 1);
+                bad = 1;
+            }
         }
         uint8_t *inflated = NULL;
         if ((attrs & 0x07) != 0) { /* gzip / Snappy / LZ4: the records section is compressed as a whole */

@@ -119,6 +119,37 @@ def test_forged_record_count_is_clamped_and_reported():
     assert list(cols["partition"][-2:]) == [5, 5]
 
 
+def test_corrupt_compressed_batch_keeps_its_announced_records():
+    """A compressed batch whose size probe fails (here: a Snappy preamble claiming 34 GB) has no known
+    payload size, so the >= 7 bytes-per-record clamp must not cut its record count: every record the
+    header announces comes out flagged, and the record bases of the later batches do not move.  (CPU
+    twin of the assertion in test_device_decodes_snappy_batches.)"""
+    rng = np.random.default_rng(33)
+    blob, _, info = random_record_set(rng, 160, max_records=120, snappy=True)
+    rc, descs, st = index_host(blob, 3)
+    assert rc == N.KTA_OK
+    want, _ost = kafka_decode(blob, 3)
+    for flag in (4, 8, 16):                                                    # Snappy, LZ4, gzip
+        victim = next(i for i in range(st.n_batches) if descs[i].flags & flag)
+        p = descs[victim].byte_off
+        broken = bytearray(blob)
+        broken[p + 61:p + 66] = b"\xff\xff\xff\xff\x7f"
+        rc2, descs2, st2 = index_host(bytes(broken), 3)
+        assert rc2 == N.KTA_OK and st2.n_batches == st.n_batches and st2.n_records == st.n_records
+        assert [descs2[i].n_records for i in range(st.n_batches)] == [descs[i].n_records for i in range(st.n_batches)]
+        assert [descs2[i].record_base for i in range(st.n_batches)] == [descs[i].record_base for i in range(st.n_batches)]
+        if flag != 8:      # an LZ4 frame is sized from its block maximum, its corruption is found on the device
+            assert descs2[victim].status == 2 and descs2[victim].payload_end == descs2[victim].payload_off
+        got, ost = kafka_decode(bytes(broken), 3)                              # the oracle states the same rule
+        lo, n = descs[victim].record_base, descs[victim].n_records
+        assert ost.bad_batches == 1 and len(got["partition"]) == st.n_records
+        assert (got["partition"][lo:lo + n] == -1).all() and (got["partition"] == -1).sum() == n
+        keep = np.ones(st.n_records, dtype=bool)
+        keep[lo:lo + n] = False
+        for k in ("partition", "key_len", "val_len", "ts_ms"):
+            assert np.array_equal(got[k][keep], want[k][keep]), k
+
+
 def test_host_index_invariants_on_mutated_blobs():
     """The header walk on corrupted record sets: never crashes, and whatever it describes stays inside the
     blob / the inflate area it sized — the device trusts these descriptors."""
@@ -151,7 +182,9 @@ def test_host_index_invariants_on_mutated_blobs():
                 assert inflate_at <= d.payload_off <= d.payload_end <= d.scratch_end
                 assert d.payload_off >= hi - 0 and d.payload_off % 64 == 0     # slices do not overlap
                 hi = (d.scratch_end + 63) & ~63
-                payload = d.payload_end - d.payload_off
+                clen = d.batch_bytes - 61                                      # bound from the header alone:
+                k = 1032 if d.flags & 16 else (22 if d.flags & 4 else (255 if d.flags & 8 else None))
+                payload = clen * k + 64 if k else max(d.payload_end - d.payload_off, clen * 1032 + 64)
             else:
                 assert (d.payload_off, d.payload_end) == (d.byte_off + 61, d.byte_off + d.batch_bytes)
                 payload = d.batch_bytes - 61
