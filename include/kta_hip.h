@@ -112,7 +112,8 @@ typedef struct kta_analytics {
  *   key_len[i]    m.key():  -1 == None, >= 0 == Some(k).len()            i32
  *   val_len[i]    m.payload(): -1 == None (tombstone), >= 0 == len       i32
  *   key_off[i]    offset of the key's bytes in key_bytes (if key_len>0)  u32  (-c only)
- *   key_bytes     concatenated key bytes                                  u8   (-c only)
+ *   key_bytes     concatenated key bytes; device buffers must be readable  u8   (-c only)
+ *                 for 16 bytes past the last key (kta_device_batch_alloc pads)
  *   seq[i]        optional global consumption index; NULL => base_seq+i  u64  (-c only)
  * Value bytes are never read by the reference path (only their length). */
 typedef struct kta_batch {
@@ -280,8 +281,11 @@ int kta_render_report(const char *topic, uint64_t duration_secs, const uint64_t 
 int kta_set_timing(kta_ctx *ctx, int enable);
 int kta_kernel_time_stats(kta_ctx *ctx, float avg_ms[3], uint64_t launches[3]);
 /* Launch-geometry knobs (0 = default): scan workgroups, scan kernel flavour (16 = non-temporal loads),
- * alive workgroups, alive kernel: 0 plain atomicMax, 1 returning atomicMax + running alive count (default),
- * 2 the same walked backwards with a pre-read that skips superseded records, 8 / 9 ablation halves. */
+ * alive workgroups, alive kernel: 0 plain atomicMax, 1 returning atomicMax + running alive count, 2 the
+ * same walked backwards with a pre-read that skips superseded records, 3 (default) / 4 the partitioned
+ * pass (hash + partition by the hash's top 10 / 9 bits, then per-bucket merge in LDS) for batches of 2^21
+ * records and more without a seq column — kernel 2 otherwise, and for the batches that follow one whose
+ * keys were mostly unique; 13 / 14 the partitioned pass for every batch (tests); 8 / 9 ablation halves. */
 int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups,
                    int alive_variant);
 

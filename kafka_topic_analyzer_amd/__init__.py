@@ -329,7 +329,7 @@ class HipMetricHandler:
     def last_kernel_ms(self):
         return self.kernel_time_stats()[0]
 
-    def set_tuning(self, scan_workgroups=0, scan_variant=16, alive_workgroups=0, alive_variant=2) -> None:
+    def set_tuning(self, scan_workgroups=0, scan_variant=16, alive_workgroups=0, alive_variant=3) -> None:
         self._check(self._lib.kta_set_tuning(self._ctx, scan_workgroups, scan_variant, alive_workgroups,
                                              alive_variant))
 

@@ -21,7 +21,7 @@ CLI = os.path.join(HERE, "kta-analyzer")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libkta_oracle.so")
 
-HIP_SOURCES = ["kta_kernels.hip", "kta_api.hip", "kta_synth.hip", "kta_kafka.hip"]
+HIP_SOURCES = ["kta_kernels.hip", "kta_alive.hip", "kta_api.hip", "kta_synth.hip", "kta_kafka.hip"]
 LIB_HOST_SOURCES = ["host/metric.cpp", "host/report.cpp", "host/kafka_encode.cpp"]  # C++ host mirror, inside libkta_hip.so
 HOST_SOURCES = ["host/main.cpp", "host/rdkafka_source.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

@@ -47,6 +47,18 @@ struct kta_ctx {
     uint64_t exp_cap = 0;
     uint32_t *d_hash_scratch = nullptr; // ablation variants only
     uint64_t hash_scratch_cap = 0;
+    uint64_t *d_pairs = nullptr;        // partitioned alive pass: (hash, local seq, alive) pairs by [workgroup][bucket]
+    uint32_t *d_pair_counts = nullptr;  //   and the fill of every segment, [bucket][workgroup]
+    uint64_t pairs_cap = 0, pair_counts_cap = 0;
+    // Feedback for the automatic choice (alive_variant 3 / 4): the partitioned pass pays when records die in
+    // LDS (a compacted topic repeats its keys inside a batch); a batch of mostly unique keys is cheaper in
+    // the single-kernel update.  Every partitioned batch reports [pairs, entries claimed]; a batch that
+    // claimed more than kAliveUniqueNum / kAliveUniqueDen of its pairs sends the next kAliveBackoff batches
+    // down the single-kernel path before the partitioned pass is tried again.
+    uint64_t *d_alive_stats = nullptr, *h_alive_stats = nullptr;
+    hipEvent_t ev_alive_stats = nullptr;
+    bool alive_stats_pending = false;
+    int alive_backoff = 0;
     std::vector<Stage> stages;
     uint64_t batch_capacity = 0, key_bytes_capacity = 0;
     int cur = 0;
@@ -54,7 +66,7 @@ struct kta_ctx {
     uint64_t fill_n = 0, fill_kb = 0; // kta_handle_message fill state
     uint64_t next_seq = 0;
     // tuning / profiling
-    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 2; // 16: non-temporal loads; 2: filtered counting kernel
+    int scan_wgs = 0, scan_variant = 16, alive_wgs = 0, alive_variant = 3; // 16: non-temporal loads; 3: partitioned pass for large batches
     bool timing = false;
     // HIP-event pairs recorded around each kernel on the compute stream (no host sync while
     // recording); drained by kta_kernel_time_stats.  kind: 0 scan, 1 fold, 2 alive update.
@@ -150,6 +162,8 @@ void free_host_batch(kta_batch *b)
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr size_t kMaxTimedPairs = 2048;
+constexpr uint64_t kAliveUniqueNum = 2, kAliveUniqueDen = 5;   // > 40 % of a batch's pairs claimed an entry: mostly unique keys
+constexpr int kAliveBackoff = 7;
 
 int drain_timers(kta_ctx *ctx)
 {
@@ -231,10 +245,70 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;
         }
-        if (ctx->alive_variant != 1 && ctx->alive_variant != 2) ctx->running_valid = false;   // non-counting kernels
-        KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs,
-                                              ctx->alive_variant, ctx->d_hash_scratch, ctx->d_alive_running,
-                                              ctx->s_compute));
+        // 3 / 4: the partitioned pass with 2^10 / 2^9 buckets (13 / 14: the same for batches of any size —
+        // tests).  It needs the batch-local index as the sequence number (no explicit seq column) and enough
+        // records to fill its segments; anything else runs the single-kernel filtered update, which is
+        // exact on the same table.
+        const int pv = ctx->alive_variant >= 13 && ctx->alive_variant <= 14 ? ctx->alive_variant - 10 : ctx->alive_variant;
+        const bool part_kind = pv >= 3 && pv <= 4;
+        const bool partitioned = part_kind && !c->seq && (n >= kta::kAlivePartitionMin || pv != ctx->alive_variant);
+        if (ctx->alive_variant != 1 && ctx->alive_variant != 2 && !part_kind) ctx->running_valid = false;   // non-counting kernels
+        bool use_partitioned = partitioned;
+        if (partitioned && ctx->alive_variant == pv) {          // automatic choice only (13 / 14 force it)
+            if (ctx->alive_stats_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
+                ctx->alive_stats_pending = false;
+                const uint64_t pairs = ctx->h_alive_stats[0], claims = ctx->h_alive_stats[1];
+                if (pairs && claims * kAliveUniqueDen > pairs * kAliveUniqueNum) ctx->alive_backoff = kAliveBackoff;
+            }
+            if (ctx->alive_backoff > 0) {
+                ctx->alive_backoff--;
+                use_partitioned = false;
+            }
+        }
+        if (use_partitioned) {
+            const int blog2 = pv == 4 ? 9 : 10;
+            if (!ctx->d_alive_stats) {
+                KTA_HIP(ctx, hipMalloc((void **)&ctx->d_alive_stats, 2 * sizeof(uint64_t)));
+                KTA_HIP(ctx, hipHostMalloc((void **)&ctx->h_alive_stats, 2 * sizeof(uint64_t), hipHostMallocDefault));
+                KTA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_alive_stats, hipEventDisableTiming));
+            }
+            const bool report = !ctx->alive_stats_pending;       // one report in flight at a time
+            if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 2 * sizeof(uint64_t), ctx->s_compute));
+            for (uint64_t at = 0; at < n;) {
+                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, blog2, ctx->alive_wgs, ctx->cu_count);
+                const uint64_t take = n - at < pl.max_records ? n - at : pl.max_records;
+                if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words) {
+                    KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+                    if (ctx->d_alive_stats) (void)hipFree(ctx->d_alive_stats);
+    if (ctx->h_alive_stats) (void)hipHostFree(ctx->h_alive_stats);
+    if (ctx->ev_alive_stats) (void)hipEventDestroy(ctx->ev_alive_stats);
+    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
+                    if (ctx->d_pair_counts) (void)hipFree(ctx->d_pair_counts);
+                    ctx->d_pairs = nullptr;
+                    ctx->d_pair_counts = nullptr;
+                    ctx->pairs_cap = ctx->pair_counts_cap = 0;
+                    KTA_HIP(ctx, hipMalloc((void **)&ctx->d_pairs, pl.pair_words * sizeof(uint64_t)));
+                    KTA_HIP(ctx, hipMalloc((void **)&ctx->d_pair_counts, pl.count_words * sizeof(uint32_t)));
+                    ctx->pairs_cap = pl.pair_words;
+                    ctx->pair_counts_cap = pl.count_words;
+                }
+                kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes, nullptr};
+                KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, ctx->d_table, ctx->d_alive_running, pl,
+                                                           ctx->d_pairs, ctx->d_pair_counts,
+                                                           report ? ctx->d_alive_stats : nullptr, ctx->s_compute));
+                at += take;
+            }
+            if (report) {
+                KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats, ctx->d_alive_stats, 2 * sizeof(uint64_t),
+                                            hipMemcpyDeviceToHost, ctx->s_compute));
+                KTA_HIP(ctx, hipEventRecord(ctx->ev_alive_stats, ctx->s_compute));
+                ctx->alive_stats_pending = true;
+            }
+        } else {
+            const int v = part_kind ? 2 : ctx->alive_variant;
+            KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs > 2048 ? 0 : ctx->alive_wgs,
+                                                  v, ctx->d_hash_scratch, ctx->d_alive_running, ctx->s_compute));
+        }
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     return KTA_OK;
@@ -346,6 +420,11 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_avec) (void)hipFree(ctx->d_avec);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
+    if (ctx->d_alive_stats) (void)hipFree(ctx->d_alive_stats);
+    if (ctx->h_alive_stats) (void)hipHostFree(ctx->h_alive_stats);
+    if (ctx->ev_alive_stats) (void)hipEventDestroy(ctx->ev_alive_stats);
+    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
+    if (ctx->d_pair_counts) (void)hipFree(ctx->d_pair_counts);
     if (ctx->d_alive_running) (void)hipFree(ctx->d_alive_running);
     if (ctx->d_exp_slots) (void)hipFree(ctx->d_exp_slots);
     if (ctx->d_exp_vals) (void)hipFree(ctx->d_exp_vals);

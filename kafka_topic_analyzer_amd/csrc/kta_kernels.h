@@ -68,6 +68,25 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *analytics_vec
 // (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
                                int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s);
+// K2'+K3' (kta_alive.hip): the same update as two kernels — hash + partition the batch's (hash, sequence, alive)
+// pairs by the hash's top bits into workgroup-private segments, then one workgroup per bucket merges its
+// pairs in LDS and applies the survivors to the table region it alone writes.  Batches without an explicit
+// seq column only (the pair carries the batch-local index).
+constexpr uint64_t kAlivePartitionMin = 1ull << 21;   // below this the segments stay nearly empty
+constexpr uint64_t kAlivePartitionMax = 1ull << 26;   // records per launch pair: larger batches are sliced
+struct AlivePartitionPlan {
+    uint32_t bucket_log2;   // buckets = table regions = apply workgroups
+    uint32_t segment_wgs;   // partition workgroups = segments per bucket
+    uint32_t cap;           // pairs per segment
+    uint64_t max_records;   // records one launch pair takes (larger batches are sliced)
+    uint64_t pair_words;    // u64 words of the pair workspace
+    uint64_t count_words;   // u32 words of the segment-count workspace
+};
+AlivePartitionPlan plan_alive_partition(uint64_t n, int bucket_log2, int req_wgs, int cu_count);
+hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
+                                    int64_t *running, const AlivePartitionPlan &plan, uint64_t *pairs,
+                                    uint32_t *counts, uint64_t *stats /* [pairs, claims] += ; may be null */,
+                                    hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 // compact (slot, value) export / import of the entries ever written: what sharded GPUs exchange

@@ -64,9 +64,14 @@ def random_cols(rng, n, P, key_space=1000, null_key=0.1, empty_key=0.02, tomb=0.
     # key bytes are a function of the key id (same id -> same bytes)
     key_seed = rng.integers(0, 256, size=(key_space, max_key), dtype=np.uint8)
     blob = np.zeros(max(total, 1), np.uint8)
-    idx = np.nonzero(kl)[0]
-    for i in idx:  # fine for the sizes the tests use
-        blob[off[i]:off[i] + kl[i]] = key_seed[key_id[i], :kl[i]]
+    step = 1 << 18  # records per gather (bounds the temporaries)
+    for lo in range(0, n, step):
+        k = kl[lo:lo + step]
+        if not k.any():
+            continue
+        rec = np.repeat(np.arange(lo, lo + len(k)), k)
+        within = np.arange(len(rec)) - np.repeat(off[lo:lo + len(k)] - off[lo], k)
+        blob[off[lo]:off[lo] + len(rec)] = key_seed[key_id[rec], within]
     return {"partition": part, "key_len": key_len, "val_len": val_len, "ts_ms": ts,
             "key_off": off.astype(np.uint32), "key_bytes": blob[:total]}
 

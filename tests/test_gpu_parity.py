@@ -247,11 +247,13 @@ def test_running_alive_count_equals_table_scan(hc):
     assert r3.alive_keys == o.alive_keys()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 13, 14])
 def test_alive_kernels_under_heavy_slot_contention(hc, variant):
     """Every alive-update kernel (plain atomicMax; returning atomicMax + running count; the same walked
-    backwards with a pre-read that skips superseded records) leaves exactly the table sequential BitSet
-    semantics leaves — 40 keys over 120k records is heavy same-slot contention."""
+    backwards with a pre-read that skips superseded records; the partitioned pass with 2^10 / 2^9
+    buckets, forced onto small batches) leaves exactly the table sequential BitSet semantics leaves — 40
+    keys over 120k records is heavy same-slot contention (and, partitioned, overflows the 16-pair
+    rings of the hot keys' buckets into the direct path)."""
     rng = np.random.default_rng(500 + variant)
     o = Oracle(NOW, True)
     hc.reset()
@@ -265,6 +267,63 @@ def test_alive_kernels_under_heavy_slot_contention(hc, variant):
     assert res.alive_keys == o.alive_keys()
     assert np.array_equal(c[:32], o.counters(32)) and not c[32:].any()
     assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+
+
+@pytest.mark.parametrize("variant,wgs", [(3, 0), (14, 100), (13, 37)])
+def test_partitioned_alive_pass_across_batches_vs_oracle(hc, variant, wgs):
+    """The partitioned pass (kta_alive_partition + kta_alive_apply) over several batches that revisit each
+    other's keys — tombstones killing earlier batches' keys, re-insertions, empty and null keys, key
+    lengths 0..40 at every alignment — against the oracle's BitSet: count, running count and all 2^32 bits.
+    Batches below the partitioning threshold take the single-kernel path on the same table, and so do (variant 3,
+    the automatic choice) the batches after one whose keys were mostly unique; 13 / 14 partition every batch."""
+    rng = np.random.default_rng(900 + variant + wgs)
+    o = Oracle(NOW, True)
+    hc.reset()
+    hc.set_tuning(alive_workgroups=wgs, alive_variant=variant)
+    consumed = 0
+    for key_space, n, tomb in ((3_000_000, 2_400_000, 0.3), (50, 2_200_000, 0.5), (3_000_000, 2_300_000, 0.6),
+                               (200_000, 300_000, 0.2)):
+        cols = random_cols(rng, n, 16, key_space=key_space, tomb=tomb)
+        o.run_soa(cols)
+        b, nb = hc.upload_batch(cols, with_keys=True)
+        hc.submit_device(b, nb, consumed, which=2)   # base_seq = records consumed before this batch
+        consumed += nb
+        hc.device_batch_free(b)
+    res, _ = hc.finish()
+    hc.set_tuning()
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+    hc.alive_table_modified()
+    assert hc.finish()[0].alive_keys == o.alive_keys()       # the running count equals a recount of the table
+
+
+@pytest.mark.parametrize("preset,log2n", [("c3", 25), ("c5", 25)])
+def test_partitioned_alive_pass_at_scale_vs_oracle(hc, preset, log2n):
+    """2^25 records of the config-3 topic (10 M distinct keys: everything merges in LDS) and of the config-5
+    key law (100 M distinct: the buckets hold more distinct slots than the LDS table, so the overflow of
+    the table into the direct path carries most of the batch), in two submissions, against the
+    single-threaded BitSet oracle on the same records: alive count and every bit of the set."""
+    sp, _ = kta.synth_preset(preset)
+    n = 1 << log2n
+    host = kta.synth_fill_host(sp, 0, n, with_keys=True)
+    o = Oracle(NOW, True)
+    o.run_soa(host)
+    hc.reset()
+    hc.set_tuning(alive_variant=13)      # partitioned whatever the previous batch looked like
+    b = hc.device_batch_alloc(n, n * 16)
+    assert hc.synth_fill_device(sp, 0, n, b) == host["n_key_bytes"]
+    half = n // 2 + 12345
+    hc.submit_device(b, half, 0, which=2)
+    rest = kta.KtaBatch()
+    for f, sz in (("key_len", 4), ("val_len", 4), ("key_off", 4)):
+        setattr(rest, f, getattr(b, f) + half * sz)
+    rest.key_bytes = b.key_bytes
+    hc.submit_device(rest, n - half, half, which=2)
+    res, _ = hc.finish()
+    hc.set_tuning()
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+    hc.device_batch_free(b)
 
 
 def test_max_partitions_uses_large_dynamic_lds():
