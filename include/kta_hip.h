@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 2   /* 2: kta_kafka_batch_desc.scratch_end, kta_kafka_index_stats.n_gzip / n_zstd */
+#define KTA_ABI_VERSION 3   /* 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
 
 /* status codes */
 #define KTA_OK 0
@@ -45,6 +45,7 @@ extern "C" {
 #define KTA_ERR_BAD_PARTITION (-5) /* a record's partition id was outside [0, P)     */
 #define KTA_ERR_CAPACITY (-6)      /* batch / key-byte capacity exceeded             */
 #define KTA_ERR_DIV_BY_ZERO (-7)   /* where the reference panics (metric.rs:135,144,153) */
+#define KTA_ERR_COMM (-8)          /* RCCL missing or a collective failed (see kta_last_error) */
 
 /* Per-partition counters, in the field order of `struct MessageMetrics`
  * (metric.rs:13-19). */
@@ -68,7 +69,8 @@ enum {
  * so that every extremum is a MAX. */
 enum {
     KTA_G_BAD_PARTITION = 0, /* SUM: records whose partition id was out of range (ignored)      */
-    KTA_G_ALIVE_KEYS = 1,    /* SUM: filled by kta_finish when count_alive_keys                  */
+    KTA_G_ALIVE_KEYS = 1,    /* SUM: alive keys of this context's table (kta_finish); in an exchange, of the
+                                hash range this rank owns — disjoint ranges, so the SUM is the job's count */
     KTA_G_RECORDS = 2,       /* SUM: records scanned (== overall_count, metric.rs:25)            */
     KTA_G_RESERVED = 3,      /* SUM: reserved, zero                                              */
     KTA_NSUM_GLOBALS = 4,
@@ -203,11 +205,38 @@ int kta_sync(kta_ctx *ctx);
  * KTA_ERR_BAD_PARTITION (results still filled in) if any record was out of range.
  * Non-destructive: more batches may follow and kta_finish may be called again. */
 int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out);
-/* Device pointer and length (in u64) of the counter vector, for collectives over
- * partition-sharded GPUs.  Valid after kta_finish_device. */
+/* Device pointer and length (in u64) of the SNAPSHOT of the counter vector that kta_finish_device
+ * takes: collectives may reduce it in place, the live accumulator is never touched (so kta_finish and
+ * further batches after an exchange stay correct). */
 int kta_result_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
-/* As kta_finish but leaves the vector on the device (no D2H, asynchronous). */
+/* As kta_finish but leaves the snapshot on the device (no D2H, asynchronous). */
 int kta_finish_device(kta_ctx *ctx);
+
+/* ---- multi-GPU exchange: one context = one rank = one GPU, RCCL over xGMI --------------------------- */
+/* The reference is one process, one MessageMetrics, one BitSet (main.rs:77-82).  Kafka partitions shard
+ * across GPUs with no data-path collective (every per-partition counter depends on its own partition's
+ * records only, metric.rs:74-100); what replaces "the report reads the handlers" (main.rs:121-179) is ONE
+ * exchange step.  Records of a sharded -c run carry GLOBAL sequence numbers (kta_batch.seq / base_seq).
+ *   kta_comm_unique_id  on one rank; hand the 128 bytes to the others out of band
+ *   kta_comm_create     every rank, collectively (ncclCommInitRank); nranks == 1 needs no id and no RCCL
+ *   kta_exchange        kta_finish_device, then on the compute stream: (-c) every rank sends the table
+ *                       entries it ever wrote to the owner of their hash range (rank r owns the slots
+ *                       [ceil(r 2^32 / R), ceil((r+1) 2^32 / R)); one grouped ncclSend / ncclRecv), the
+ *                       owner merges by last writer and counts its range; then ONE grouped launch of
+ *                       all-reduce SUM over vec[0 : P*7+4] and all-reduce MAX over vec[P*7+4 : P*7+8]
+ *   kta_exchange_result the decoded snapshot: after kta_exchange the whole job's result on every rank
+ * RCCL is bound at run time (KTA_RCCL_LIBRARY, /opt/rocm/lib/librccl.so.1). */
+#define KTA_COMM_ID_BYTES 128
+int kta_comm_unique_id(uint8_t id[KTA_COMM_ID_BYTES]);
+int kta_comm_create(kta_ctx *ctx, int nranks, int rank, const uint8_t id[KTA_COMM_ID_BYTES]);
+int kta_comm_destroy(kta_ctx *ctx);
+int kta_exchange(kta_ctx *ctx);
+int kta_exchange_result(kta_ctx *ctx, kta_result *out, uint64_t *counters_out);
+/* Small host-side vectors of the same job (per-partition start / end offsets of the report,
+ * main.rs:155-157): all-reduce SUM (op_max 0) or MAX (1), in place, synchronous. */
+int kta_comm_allreduce_i64(kta_ctx *ctx, int64_t *host_values, size_t n, int op_max);
+/* Communicator facts and the alive entries the last kta_exchange sent / received (profiling). */
+int kta_comm_info(kta_ctx *ctx, int *nranks, int *rank, uint64_t *entries_sent, uint64_t *entries_received);
 /* Host-side decode of a (possibly all-reduced) counter vector. */
 int kta_decode_vector(const uint64_t *vec, uint32_t n_partitions, int count_alive_keys,
                       kta_result *out, uint64_t *counters_out);

@@ -244,6 +244,45 @@ class HipMetricHandler:
     def finish_device(self) -> None:
         self._check(self._lib.kta_finish_device(self._ctx))
 
+    # ------------------------------------------------------------------ multi-GPU exchange (RCCL, native)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """On one rank; hand the bytes to the other ranks out of band."""
+        buf = C.create_string_buffer(N.KTA_COMM_ID_BYTES)
+        rc = N.load().kta_comm_unique_id(buf)
+        if rc != N.KTA_OK:
+            raise KtaError(rc, "kta_comm_unique_id (RCCL not loadable?)")
+        return buf.raw
+
+    def comm_create(self, nranks: int, rank: int, unique_id: Optional[bytes] = None) -> None:
+        self._check(self._lib.kta_comm_create(self._ctx, nranks, rank, unique_id))
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.kta_comm_destroy(self._ctx))
+
+    def exchange(self) -> None:
+        """The one exchange step of a partition-sharded run (asynchronous on the compute stream but for the
+        two count read-backs of a -c run)."""
+        self._check(self._lib.kta_exchange(self._ctx))
+
+    def exchange_result(self, allow_bad_partition: bool = False):
+        """-> (KtaResult, counters[P,7]) of the snapshot vector: after exchange(), the whole job's."""
+        res = KtaResult()
+        counters = np.zeros((self.n_partitions, N.KTA_NCOUNTERS), dtype=np.uint64)
+        allow = (N.KTA_ERR_BAD_PARTITION,) if allow_bad_partition else ()
+        self._check(self._lib.kta_exchange_result(self._ctx, C.byref(res), _np_ptr(counters)), allow)
+        return res, counters
+
+    def comm_allreduce_i64(self, values: np.ndarray, op_max: bool = False) -> np.ndarray:
+        a = np.ascontiguousarray(values, dtype=np.int64).copy()
+        self._check(self._lib.kta_comm_allreduce_i64(self._ctx, _np_ptr(a), a.size, 1 if op_max else 0))
+        return a
+
+    def comm_info(self):
+        nr, rk, se, re = C.c_int(), C.c_int(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.kta_comm_info(self._ctx, C.byref(nr), C.byref(rk), C.byref(se), C.byref(re)))
+        return nr.value, rk.value, se.value, re.value
+
     def result_vector(self) -> Tuple[int, int]:
         """(device pointer, length in u64) of the counter vector (for collectives)."""
         p, n = C.c_void_p(), C.c_size_t()

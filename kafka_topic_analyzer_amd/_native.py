@@ -20,6 +20,8 @@ KTA_ERR_NO_DEVICE = -4
 KTA_ERR_BAD_PARTITION = -5
 KTA_ERR_CAPACITY = -6
 KTA_ERR_DIV_BY_ZERO = -7
+KTA_ERR_COMM = -8
+KTA_COMM_ID_BYTES = 128
 
 KTA_NCOUNTERS = 7
 KTA_NGLOBALS = 8
@@ -112,6 +114,13 @@ SIGNATURES = {
     "kta_finish": (C.c_int, [_P, C.POINTER(KtaResult), C.c_void_p]),
     "kta_result_vector": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "kta_finish_device": (C.c_int, [_P]),
+    "kta_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "kta_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p]),
+    "kta_comm_destroy": (C.c_int, [_P]),
+    "kta_exchange": (C.c_int, [_P]),
+    "kta_exchange_result": (C.c_int, [_P, C.POINTER(KtaResult), C.c_void_p]),
+    "kta_comm_allreduce_i64": (C.c_int, [_P, C.c_void_p, C.c_size_t, C.c_int]),
+    "kta_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kta_decode_vector": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(KtaResult), C.c_void_p]),
     "kta_merge_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "kta_get_analytics": (C.c_int, [_P, C.POINTER(KtaAnalytics), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -161,7 +170,7 @@ SIGNATURES = {
 _lib = None
 
 
-KTA_ABI_VERSION = 2  # include/kta_hip.h
+KTA_ABI_VERSION = 3  # include/kta_hip.h
 
 
 def load() -> C.CDLL:

@@ -21,7 +21,7 @@ CLI = os.path.join(HERE, "kta-analyzer")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libkta_oracle.so")
 
-HIP_SOURCES = ["kta_kernels.hip", "kta_alive.hip", "kta_api.hip", "kta_synth.hip", "kta_kafka.hip"]
+HIP_SOURCES = ["kta_kernels.hip", "kta_alive.hip", "kta_api.hip", "kta_comm.hip", "kta_synth.hip", "kta_kafka.hip"]
 LIB_HOST_SOURCES = ["host/metric.cpp", "host/report.cpp", "host/kafka_encode.cpp"]  # C++ host mirror, inside libkta_hip.so
 HOST_SOURCES = ["host/main.cpp", "host/rdkafka_source.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -70,7 +70,7 @@ def build_lib(force: bool = False) -> str:
             flags = [f for f in HIPCC_FLAGS if not f.startswith("--offload-arch")]
             _run([hipcc, *arch, *flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj])
         objs.append(obj)
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl",
           "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 

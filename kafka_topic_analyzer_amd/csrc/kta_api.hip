@@ -36,7 +36,9 @@ struct kta_ctx {
     hipEvent_t ev_copied = nullptr;
     bool analytics = false;
     uint64_t *d_avec = nullptr;     // analytics vector u64[2*34 + 4*P] (KTA_FLAG_ANALYTICS)
-    uint64_t *d_vec = nullptr;      // u64[P*7 + KTA_NGLOBALS]
+    uint64_t *d_vec = nullptr;      // u64[P*7 + KTA_NGLOBALS]: the live accumulator
+    uint64_t *d_vec_out = nullptr;  // its snapshot (kta_finish_device): what kta_result_vector hands out and the
+                                    // exchange reduces in place — the accumulator itself is never reduced
     uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
     uint32_t max_rows = 0;
     uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
@@ -77,6 +79,8 @@ struct kta_ctx {
     // extension state owned by another translation unit of the library (kta_kafka.hip)
     void *ext_state = nullptr;
     void (*ext_free)(void *) = nullptr;
+    void *comm_state = nullptr;     // kta_comm.hip
+    void (*comm_free)(void *) = nullptr;
     std::string err;
 };
 
@@ -385,6 +389,7 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     KTA_TRY(hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming));
     const size_t vec_words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
     KTA_TRY(hipMalloc((void **)&ctx->d_vec, vec_words * sizeof(uint64_t)));
+    KTA_TRY(hipMalloc((void **)&ctx->d_vec_out, vec_words * sizeof(uint64_t)));
     ctx->max_rows = (uint32_t)ctx->cu_count * 8u;
     KTA_TRY(hipMalloc((void **)&ctx->d_partials,
                       (size_t)ctx->max_rows * kta::scan_row_len(ctx->P, ctx->analytics) * sizeof(uint64_t)));
@@ -410,12 +415,14 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->s_compute) (void)hipStreamSynchronize(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamSynchronize(ctx->s_copy);
     if (ctx->ext_state && ctx->ext_free) ctx->ext_free(ctx->ext_state);
+    if (ctx->comm_state && ctx->comm_free) ctx->comm_free(ctx->comm_state);
     for (auto &st : ctx->stages) {
         free_host_batch(&st.host);
         free_device_batch(&st.dev);
         if (st.done) (void)hipEventDestroy(st.done);
     }
     if (ctx->d_vec) (void)hipFree(ctx->d_vec);
+    if (ctx->d_vec_out) (void)hipFree(ctx->d_vec_out);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_avec) (void)hipFree(ctx->d_avec);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
@@ -625,8 +632,11 @@ int kta_finish_device(kta_ctx *ctx)
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
+    const size_t words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
+    KTA_HIP(ctx, hipMemcpyAsync(ctx->d_vec_out, ctx->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                ctx->s_compute));
     if (ctx->alive) {
-        uint64_t *dst = ctx->d_vec + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
+        uint64_t *dst = ctx->d_vec_out + (size_t)ctx->P * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
         if (ctx->running_valid)  // exact running count (every update so far ran a counting kernel): no table scan
             KTA_HIP(ctx, hipMemcpyAsync(dst, ctx->d_alive_running, sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                         ctx->s_compute));
@@ -639,7 +649,7 @@ int kta_finish_device(kta_ctx *ctx)
 int kta_result_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
 {
     if (!ctx || !device_ptr || !n_u64) return KTA_ERR_INVALID;
-    *device_ptr = ctx->d_vec;
+    *device_ptr = ctx->d_vec_out;
     *n_u64 = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
     return KTA_OK;
 }
@@ -690,12 +700,19 @@ int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out)
     if (!ctx || !out) return KTA_ERR_INVALID;
     int rc = kta_finish_device(ctx);
     if (rc != KTA_OK) return rc;
+    return kta_exchange_result(ctx, out, counters_out);
+}
+
+int kta_exchange_result(kta_ctx *ctx, kta_result *out, uint64_t *counters_out)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    KTA_HIP(ctx, hipSetDevice(ctx->device));
     const size_t words = (size_t)ctx->P * KTA_NCOUNTERS + KTA_NGLOBALS;
     std::vector<uint64_t> host(words);
-    KTA_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_vec, words * sizeof(uint64_t), hipMemcpyDeviceToHost,
+    KTA_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_vec_out, words * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                 ctx->s_compute));
     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
-    rc = kta_decode_vector(host.data(), ctx->P, ctx->alive ? 1 : 0, out, counters_out);
+    int rc = kta_decode_vector(host.data(), ctx->P, ctx->alive ? 1 : 0, out, counters_out);
     if (rc == KTA_ERR_BAD_PARTITION) {
         char buf[128];
         snprintf(buf, sizeof buf, "%llu record(s) had a partition id outside [0, %u)",
@@ -905,6 +922,15 @@ void **kta_internal_ext_slot(kta_ctx *ctx, void (*free_fn)(void *))
     ctx->ext_free = free_fn;
     return &ctx->ext_state;
 }
+void **kta_internal_comm_slot(kta_ctx *ctx, void (*free_fn)(void *))
+{
+    ctx->comm_free = free_fn;
+    return &ctx->comm_state;
+}
+uint64_t *kta_internal_vec_out(kta_ctx *ctx) { return ctx->d_vec_out; }
+uint32_t kta_internal_partitions(kta_ctx *ctx) { return ctx->P; }
+uint64_t *kta_internal_table(kta_ctx *ctx) { return ctx->d_table; }
+int64_t *kta_internal_running(kta_ctx *ctx) { return ctx->d_alive_running; }
 uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n)
 {
     const uint64_t base = ctx->next_seq;

@@ -94,6 +94,9 @@ hipError_t launch_alive_count_span(const uint64_t *table, uint64_t lo, uint64_t 
 hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 hipError_t launch_alive_export(const uint64_t *table, uint64_t n_slots, uint32_t *out_slots, uint64_t *out_vals,
                                uint64_t *counter, uint64_t cap, hipStream_t s);
+hipError_t launch_alive_export_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint32_t *out_slots,
+                                    uint64_t *out_vals, uint64_t *counter, uint64_t cap, hipStream_t s);
+hipError_t launch_alive_count_written_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint64_t *out, hipStream_t s);
 hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint64_t n, uint64_t *table,
                                int64_t *running, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)

@@ -714,7 +714,8 @@ __global__ __launch_bounds__(kWG) void kta_alive_count_span(const uint64_t *__re
 constexpr uint32_t kExportStage = 2048;
 
 __global__ __launch_bounds__(kWG) void kta_alive_export(const unsigned long long *__restrict__ table,
-                                                        uint64_t n_slots, uint32_t *__restrict__ out_slots,
+                                                        uint64_t n_slots, uint32_t slot_base,
+                                                        uint32_t *__restrict__ out_slots,
                                                         unsigned long long *__restrict__ out_vals,
                                                         unsigned long long *__restrict__ counter, uint64_t cap)
 {
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_export(const unsigned long long
             const unsigned long long v = i < hi ? table[i] : 0ull;
             if (v) {
                 const uint32_t at = atomicAdd(&s_n, 1u);         // LDS counter; stage holds 2048 >= 4 * 256
-                s_slot[at] = (uint32_t)i;
+                s_slot[at] = slot_base + (uint32_t)i;
                 s_val[at] = v;
             }
         }
@@ -793,6 +794,25 @@ __global__ __launch_bounds__(kWG) void kta_alive_count_written(const ulonglong2 
         const ulonglong2 e = table2[i];
         cnt += (e.x != 0ull) + (e.y != 0ull);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+// entries ever written in the slots [lo, hi) (any bounds)
+__global__ __launch_bounds__(kWG) void kta_alive_count_written_span(const uint64_t *__restrict__ table, uint64_t lo,
+                                                                    uint64_t hi, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    unsigned long long cnt = 0;
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * kWG + threadIdx.x; i < hi; i += stride) cnt += table[i] != 0ull;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
@@ -936,6 +956,15 @@ hipError_t launch_alive_count_span(const uint64_t *table, uint64_t lo, uint64_t 
     return hipGetLastError();
 }
 
+hipError_t launch_alive_count_written_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint64_t *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess || lo >= hi) return e;
+    hipLaunchKernelGGL(kta_alive_count_written_span, dim3(256 * 8), dim3(kWG), 0, s, table, lo, hi,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
 hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
@@ -949,10 +978,17 @@ hipError_t launch_alive_count_written(const uint64_t *table, uint64_t n_slots, u
 hipError_t launch_alive_export(const uint64_t *table, uint64_t n_slots, uint32_t *out_slots, uint64_t *out_vals,
                                uint64_t *counter, uint64_t cap, hipStream_t s)
 {
+    return launch_alive_export_span(table, 0, n_slots, out_slots, out_vals, counter, cap, s);
+}
+
+hipError_t launch_alive_export_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint32_t *out_slots,
+                                    uint64_t *out_vals, uint64_t *counter, uint64_t cap, hipStream_t s)
+{
     hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint64_t), s);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || lo >= hi) return e;
+    const uint64_t n_slots = hi - lo;
     hipLaunchKernelGGL(kta_alive_export, dim3(256 * 16), dim3(kWG), 0, s,
-                       reinterpret_cast<const unsigned long long *>(table), n_slots, out_slots,
+                       reinterpret_cast<const unsigned long long *>(table + lo), n_slots, (uint32_t)lo, out_slots,
                        reinterpret_cast<unsigned long long *>(out_vals),
                        reinterpret_cast<unsigned long long *>(counter), cap);
     return hipGetLastError();

@@ -74,3 +74,92 @@ def test_alive_table_allreduce_on_rccl_one_rank(tmp_path):
     script.write_text(_WORKER)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+# ---- the native exchange (csrc/kta_comm.hip: RCCL behind the C ABI, no torch in the data path) ---------------
+_NATIVE_WORKER = r'''
+import os, sys, time
+root, rank, nranks, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import kafka_topic_analyzer_amd as kta
+from helpers import random_cols, NOW
+from oracle_c import Oracle
+P = 12
+rng = np.random.default_rng(77)
+cols = random_cols(rng, 300000, P, key_space=5000, tomb=0.4)       # the whole topic, identical on every rank
+o = Oracle(NOW, True); o.run_soa(cols)
+n = len(cols["partition"])
+seq = np.arange(n, dtype=np.uint64)                                # GLOBAL consumption order
+idx = np.nonzero(cols["partition"] % nranks == rank)[0]            # this rank's partitions
+kl = np.maximum(cols["key_len"][idx], 0).astype(np.int64)
+off = np.zeros(len(idx), np.int64); off[1:] = np.cumsum(kl)[:-1]
+kb = np.zeros(max(int(kl.sum()), 1), np.uint8)
+src = cols["key_off"][idx].astype(np.int64)
+pos = np.repeat(src, kl) + (np.arange(int(kl.sum())) - np.repeat(off, kl))
+kb[:int(kl.sum())] = cols["key_bytes"][pos]
+shard = {"partition": cols["partition"][idx], "key_len": cols["key_len"][idx], "val_len": cols["val_len"][idx],
+         "ts_ms": cols["ts_ms"][idx], "key_off": off.astype(np.uint32), "key_bytes": kb[:int(kl.sum())], "seq": seq[idx]}
+h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+if nranks > 1:
+    if rank == 0:
+        uid = kta.HipMetricHandler.comm_unique_id()
+        with open(idfile + ".tmp", "wb") as f: f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            assert time.time() - t0 < 120
+            time.sleep(0.05)
+        uid = open(idfile, "rb").read()
+else:
+    uid = None
+try:
+    h.comm_create(nranks, rank, uid)
+except kta.KtaError as e:
+    print("COMM_CREATE_FAILED", e); sys.exit(3)
+b, nb = h.upload_batch(shard, with_keys=True)
+h.submit_device(b, nb, 0)
+h.exchange()
+res, c = h.exchange_result()
+assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
+assert np.array_equal(c, o.counters(P))
+assert res.overall_count == n
+m = h.metrics() if False else None
+# the snapshot was reduced, the accumulator was not: a second exchange gives the same answer
+h.exchange()
+res2, c2 = h.exchange_result()
+assert res2.alive_keys == o.alive_keys() and np.array_equal(c2, c)
+ends = np.zeros(P, np.int64); ends[rank::nranks] = 1000 + np.arange(P)[rank::nranks]
+got = h.comm_allreduce_i64(ends)
+assert np.array_equal(got, 1000 + np.arange(P))
+assert np.array_equal(h.comm_allreduce_i64(np.array([rank, -rank], np.int64), op_max=True), [nranks - 1, 0])
+nr, rk, sent, recv = h.comm_info()
+assert (nr, rk) == (nranks, rank) and (nranks == 1 or sent + recv > 0)
+h.device_batch_free(b); h.comm_destroy(); h.close(); print("OK", rank, sent, recv)
+'''
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_native_exchange_over_rccl(tmp_path, nranks):
+    """kta_comm_create / kta_exchange: partition-sharded ranks with global sequence numbers, hash-range
+    exchange of the alive entries + grouped SUM / MAX all-reduce of the snapshot vector, every rank ends with
+    the unsharded oracle's result.  Two ranks share the one reachable GPU (RCCL permitting)."""
+    script = tmp_path / "w.py"
+    script.write_text(_NATIVE_WORKER)
+    idfile = str(tmp_path / "rccl_id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(nranks), idfile], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(nranks)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600) + (p.returncode,))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    if nranks > 1 and any(rc == 3 for _, _, rc in outs):
+        pytest.skip("RCCL refused two ranks on one GPU: " + " | ".join(o[-300:] for o, _, _ in outs))
+    for out, err, rc in outs:
+        assert rc == 0 and "OK" in out, (out[-2000:], err[-3000:])
