@@ -125,7 +125,6 @@ res, c = h.exchange_result()
 assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
 assert np.array_equal(c, o.counters(P))
 assert res.overall_count == n
-m = h.metrics() if False else None
 # the snapshot was reduced, the accumulator was not: a second exchange gives the same answer
 h.exchange()
 res2, c2 = h.exchange_result()
@@ -163,3 +162,77 @@ def test_native_exchange_over_rccl(tmp_path, nranks):
         pytest.skip("RCCL refused two ranks on one GPU: " + " | ".join(o[-300:] for o, _, _ in outs))
     for out, err, rc in outs:
         assert rc == 0 and "OK" in out, (out[-2000:], err[-3000:])
+
+
+_THREADED_WORKER = r'''
+import os, sys, threading
+root, nranks = sys.argv[1], int(sys.argv[2])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import kafka_topic_analyzer_amd as kta
+from helpers import random_cols, NOW
+from oracle_c import Oracle
+P = 10
+rng = np.random.default_rng(5 + nranks)
+cols = random_cols(rng, 400000, P, key_space=30000, tomb=0.35)
+o = Oracle(NOW, True); o.run_soa(cols)
+n = len(cols["partition"])
+seq = np.arange(n, dtype=np.uint64)
+def shard_of(rank):
+    idx = np.nonzero(cols["partition"] % nranks == rank)[0]
+    kl = np.maximum(cols["key_len"][idx], 0).astype(np.int64)
+    off = np.zeros(len(idx), np.int64); off[1:] = np.cumsum(kl)[:-1]
+    tot = int(kl.sum())
+    kb = np.zeros(max(tot, 1), np.uint8)
+    pos = np.repeat(cols["key_off"][idx].astype(np.int64), kl) + (np.arange(tot) - np.repeat(off, kl))
+    kb[:tot] = cols["key_bytes"][pos]
+    return {"partition": cols["partition"][idx], "key_len": cols["key_len"][idx], "val_len": cols["val_len"][idx],
+            "ts_ms": cols["ts_ms"][idx], "key_off": off.astype(np.uint32), "key_bytes": kb[:tot], "seq": seq[idx]}
+uid = kta.HipMetricHandler.comm_unique_id()
+errors, stats = [], [None] * nranks
+def run(rank):
+    try:
+        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+        h.comm_create(nranks, rank, uid)
+        b, nb = h.upload_batch(shard_of(rank), with_keys=True)
+        h.submit_device(b, nb, 0)
+        for _ in range(2):                     # the second exchange finds every owner's range already merged
+            h.exchange()
+            res, c = h.exchange_result()
+            assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
+            assert np.array_equal(c, o.counters(P)) and res.overall_count == n
+        lo, hi = -((-rank * (1 << 32)) // nranks), -((-(rank + 1) * (1 << 32)) // nranks)
+        words = h.export_alive_bitmap()        # this rank's table is the merged one on its own hash range
+        want = o.alive_words()
+        wl, wh = (lo + 31) // 32, hi // 32
+        assert np.array_equal(words[wl:wh], want[wl:wh]), rank
+        ends = np.zeros(P, np.int64); ends[rank::nranks] = 7
+        assert np.array_equal(h.comm_allreduce_i64(ends), np.full(P, 7))
+        stats[rank] = h.comm_info()
+        h.device_batch_free(b); h.comm_destroy(); h.close()
+    except BaseException as e:
+        errors.append((rank, repr(e)))
+        os._exit(2)                            # the other ranks would wait at the next rendezvous for ever
+ts = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errors, errors
+assert sum(s[2] for s in stats) == sum(s[3] for s in stats) > 0      # every entry sent was received
+print("OK", stats)
+'''
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks):
+    """The multi-rank paths of csrc/kta_comm.hip (per-owner export, count all-gather, grouped send / recv,
+    owner merge + range count, SUM / MAX all-reduce) with 2 and 3 ranks as threads of one process on the one
+    reachable GPU, RCCL replaced by tests/mock_rccl.cpp: every rank ends with the unsharded oracle's counters
+    and alive count, and with the oracle's BitSet on the hash range it owns."""
+    lib = tmp_path / "libmock_rccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
+                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    script = tmp_path / "w.py"
+    script.write_text(_THREADED_WORKER)
+    env = dict(os.environ, KTA_RCCL_LIBRARY=str(lib))
+    r = subprocess.run([sys.executable, str(script), ROOT, str(nranks)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
