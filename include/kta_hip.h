@@ -100,6 +100,10 @@ typedef struct kta_config {
  * histograms of key and value sizes and per-partition timestamp / message-size extrema,
  * accumulated by the same scan kernel in extra LDS arrays.  Opt-in: costs LDS, not bandwidth. */
 #define KTA_FLAG_ANALYTICS 1u
+/* The staging batches of kta_batch_acquire carry a `seq` column (with count_alive_keys): the producer writes
+ * every record's GLOBAL consumption index, kta_batch_submit's base_seq is ignored.  For a rank of a
+ * partition-sharded run, whose records are not consecutive in the topic's consumption order. */
+#define KTA_FLAG_SEQ_COLUMN 2u
 #define KTA_HIST_BUCKETS 34 /* [0] None, [1] length 0, [2+k] 2^k <= length < 2^(k+1), k = 0..31 */
 
 typedef struct kta_analytics {
@@ -156,6 +160,8 @@ void kta_destroy(kta_ctx *ctx);
  * on the calling thread).  Never NULL. */
 const char *kta_last_error(const kta_ctx *ctx);
 int kta_abi_version(void);
+/* HIP devices visible to the process (a sharded run places rank r on device r). */
+int kta_device_count(int *n);
 /* Zero all accumulated state (counters, extrema, alive table). */
 int kta_reset(kta_ctx *ctx);
 
@@ -168,6 +174,9 @@ int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const voi
                        int64_t key_len, int64_t val_len);
 /* Submit the partially filled staging batch, if any. */
 int kta_flush(kta_ctx *ctx);
+/* The next record of kta_handle_message / kta_kafka_consume gets this global sequence number (a rank of a
+ * sharded run positions itself at the first record of each of its partitions' stretches). */
+int kta_seek_seq(kta_ctx *ctx, uint64_t next_seq);
 
 /* ---- batch entry: a decoder that already produces columns --------------------- */
 /* Borrow the current pinned staging batch (blocks until the ring has a free one). */

@@ -100,7 +100,9 @@ SIGNATURES = {
     "kta_last_error": (C.c_char_p, [_P]),
     "kta_reset": (C.c_int, [_P]),
     "kta_handle_message": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
+    "kta_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "kta_flush": (C.c_int, [_P]),
+    "kta_seek_seq": (C.c_int, [_P, C.c_uint64]),
     "kta_batch_acquire": (C.c_int, [_P, C.POINTER(KtaBatch)]),
     "kta_batch_submit": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kta_submit_device": (C.c_int, [_P, C.POINTER(KtaBatch), C.c_uint64, C.c_uint64]),

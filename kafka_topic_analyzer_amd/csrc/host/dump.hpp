@@ -58,9 +58,17 @@ public:
         if (b->n > (1ull << 32) || b->n_key_bytes >= (1ull << 32)) return false;
         b->partition.resize(b->n); b->key_len.resize(b->n); b->val_len.resize(b->n);
         b->ts_ms.resize(b->n); b->key_off.resize(b->n); b->key_bytes.resize(b->n_key_bytes);
-        return rdp(b->partition.data(), 4 * b->n) && rdp(b->key_len.data(), 4 * b->n) &&
-               rdp(b->val_len.data(), 4 * b->n) && rdp(b->ts_ms.data(), 8 * b->n) &&
-               rdp(b->key_off.data(), 4 * b->n) && rdp(b->key_bytes.data(), b->n_key_bytes);
+        if (!(rdp(b->partition.data(), 4 * b->n) && rdp(b->key_len.data(), 4 * b->n) &&
+              rdp(b->val_len.data(), 4 * b->n) && rdp(b->ts_ms.data(), 8 * b->n) &&
+              rdp(b->key_off.data(), 4 * b->n) && rdp(b->key_bytes.data(), b->n_key_bytes)))
+            return false;
+        // the file is untrusted: every key must lie inside the batch's key bytes (the caller copies
+        // key_len bytes from key_off), lengths below -1 do not exist
+        for (uint64_t i = 0; i < b->n; i++) {
+            if (b->key_len[i] < -1 || b->val_len[i] < -1) return false;
+            if (b->key_len[i] > 0 && (uint64_t)b->key_off[i] + (uint64_t)b->key_len[i] > b->n_key_bytes) return false;
+        }
+        return true;
     }
 
 private:

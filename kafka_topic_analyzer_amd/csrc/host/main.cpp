@@ -16,8 +16,11 @@
 //     segment://<f0>[,<f1>...]           raw Kafka log segments (`*.log` files of a broker, record-batch
 //                                        v2; uncompressed, gzip, Snappy, LZ4, zstd): file k is partition k; decoded ON THE GPU
 //                                        (include/kta_kafka.h), the host only walks batch headers
-// Extra knobs travel in --librdkafka as kta.* keys (kta.device=N,
+// Extra knobs travel in --librdkafka as kta.* keys (kta.device=N, kta.gpus=N,
 // kta.batch=N, kta.write_dump=<path>, kta.per_message=1), so no flag is added or renamed.
+// kta.gpus=N (synthetic:// and segment:// sources) shards the topic's partitions over N GPUs, partition p on
+// rank p % N, one host thread + one context + one communicator rank per GPU (device (kta.device + r) mod the
+// visible devices), and replaces "the report reads the handlers" by ONE exchange step (kta_exchange: RCCL).
 // kta.per_message=1 drives the handler exactly like the reference's loop (kafka.rs:107-109): one
 // MetricHandler::handle_message call per record instead of filling columns.
 #include <stdio.h>
@@ -28,6 +31,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dump.hpp"
@@ -99,7 +103,10 @@ Args parse_args(int argc, char **argv)
         if (name == "-t" || name == "--topic") { a.topic = take(i, "--topic <TOPIC>", eq); a.has_topic = true; }
         else if (name == "-b" || name == "--bootstrap-server") { a.bootstrap = take(i, "--bootstrap-server <BOOTSTRAP_SERVER>", eq); a.has_bootstrap = true; }
         else if (name == "--librdkafka") { a.librdkafka = take(i, "--librdkafka <LIBRDKAFKA>", eq); a.has_librdkafka = true; }
-        else if (name == "-c" || name == "--count-alive-keys") a.count_alive_occurrences++;
+        else if (name == "-c" || name == "--count-alive-keys") {
+            if (++a.count_alive_occurrences > 1)   // clap 2: a flag that is not `multiple(true)` may appear once
+                usage_error("The argument '--count-alive-keys' was provided more than once, but cannot be used multiple times");
+        }
         else if (name == "-h" || name == "--help") { print_help(); exit(0); }
         else if (name == "-V" || name == "--version") { printf("%s\n", kAbout); exit(0); }
         else usage_error("Found argument '" + s + "' which wasn't expected, or isn't valid in this context");
@@ -142,16 +149,150 @@ void check(int rc, kta_ctx *ctx, const char *what)
     }
 }
 
+// ---- kta.gpus=N: one rank per GPU ------------------------------------------------------------------------
+struct ShardedJob {
+    std::string topic;
+    bool count_alive = false, synthetic = false, check_crcs = false;
+    int device = 0, nranks = 1;
+    uint64_t batch = 1ull << 20;
+    uint32_t P = 0;
+    kta_synth_spec spec{};
+    uint64_t n_records = 0;
+    std::vector<std::vector<uint8_t>> segment_bytes;   // segment:// : file k is partition k
+    std::vector<uint64_t> base_seq;                    //   global sequence number of each partition's first record
+    std::vector<int64_t> start_offsets, end_offsets;
+};
+
+// What one rank consumes: the partitions p with p % nranks == rank, every record with its GLOBAL sequence
+// number (the position the single-GPU run consumes it at), then the exchange.
+void run_rank(const ShardedJob &job, int rank, const uint8_t *uid, int ndev, kta::HipMetricHandler **out)
+{
+    try {
+        const uint32_t flags = job.synthetic && job.count_alive ? KTA_FLAG_SEQ_COLUMN : 0u;
+        kta::HipMetricHandler *h = new kta::HipMetricHandler((int32_t)job.P, job.count_alive, (job.device + rank) % ndev,
+                                                             job.batch, 0, flags);
+        kta_ctx *ctx = h->ctx();
+        h->comm_create(job.nranks, rank, uid);
+        if (job.synthetic) {
+            // every rank enumerates the whole topic in consumption order and keeps its partitions
+            std::vector<int32_t> part(job.batch), kl(job.batch), vl(job.batch);
+            std::vector<int64_t> ts(job.batch);
+            std::vector<uint32_t> ko(job.batch);
+            std::vector<uint8_t> kbuf;
+            kta_batch hb{};
+            bool open = false;
+            uint64_t fill = 0, fill_kb = 0;
+            auto submit = [&]() {
+                if (open) check(kta_batch_submit(ctx, fill, fill_kb, 0), ctx, "kta_batch_submit");
+                open = false;
+                fill = fill_kb = 0;
+            };
+            for (uint64_t at = 0; at < job.n_records;) {
+                uint64_t n = std::min<uint64_t>(job.batch, job.n_records - at), kb = 0;
+                kta_batch tmp{};
+                tmp.partition = part.data(); tmp.key_len = kl.data(); tmp.val_len = vl.data(); tmp.ts_ms = ts.data();
+                tmp.capacity = n;
+                if (job.count_alive) {
+                    check(kta_synth_fill_host(&job.spec, at, n, &tmp, &kb), ctx, "kta_synth_fill_host");   // key bytes needed
+                    kbuf.resize(kb + 16);
+                    tmp.key_off = ko.data(); tmp.key_bytes = kbuf.data(); tmp.key_bytes_capacity = kb;
+                }
+                check(kta_synth_fill_host(&job.spec, at, n, &tmp, &kb), ctx, "kta_synth_fill_host");
+                for (uint64_t i = 0; i < n; i++) {
+                    if (part[i] % job.nranks != rank) continue;
+                    const uint64_t klen = job.count_alive && kl[i] > 0 ? (uint64_t)kl[i] : 0;
+                    if (open && (fill == hb.capacity || fill_kb + klen > hb.key_bytes_capacity)) submit();
+                    if (!open) {
+                        check(kta_batch_acquire(ctx, &hb), ctx, "kta_batch_acquire");
+                        open = true;
+                    }
+                    hb.partition[fill] = part[i]; hb.key_len[fill] = kl[i]; hb.val_len[fill] = vl[i]; hb.ts_ms[fill] = ts[i];
+                    if (job.count_alive) {
+                        hb.key_off[fill] = (uint32_t)fill_kb;
+                        if (klen) memcpy(hb.key_bytes + fill_kb, kbuf.data() + ko[i], klen);
+                        fill_kb += klen;
+                        hb.seq[fill] = at + i;
+                    }
+                    fill++;
+                }
+                at += n;
+            }
+            submit();
+        } else {
+            check(kta_kafka_set_check_crcs(ctx, job.check_crcs ? 1 : 0), ctx, "kta_kafka_set_check_crcs");
+            for (uint32_t p = (uint32_t)rank; p < job.P; p += (uint32_t)job.nranks) {
+                if (job.segment_bytes[p].empty()) continue;
+                kta_kafka_index_stats ist;
+                check(kta_seek_seq(ctx, job.base_seq[p]), ctx, "kta_seek_seq");
+                check(kta_kafka_consume(ctx, job.segment_bytes[p].data(), job.segment_bytes[p].size(), (int32_t)p, &ist), ctx,
+                      "kta_kafka_consume");
+                if (ist.n_compressed || ist.n_old_magic)
+                    fprintf(stderr, "[WARN] Kafka error: partition %u: %llu unknown-codec and %llu pre-v2 batches skipped\n", p,
+                            (unsigned long long)ist.n_compressed, (unsigned long long)ist.n_old_magic);
+            }
+        }
+        h->exchange(!job.synthetic);
+        *out = h;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "rank %d: %s\n", rank, e.what());
+        exit(2);   // the other ranks would wait for this one in the exchange for ever
+    }
+}
+
+int run_sharded(ShardedJob &job, const std::chrono::steady_clock::time_point start_time)
+{
+    int ndev = 0;
+    if (kta_device_count(&ndev) != KTA_OK) {
+        fprintf(stderr, "kta_create failed: no HIP device visible (libkta_hip has no CPU fallback)\n");
+        return 2;
+    }
+    uint8_t uid[KTA_COMM_ID_BYTES];
+    if (kta_comm_unique_id(uid) != KTA_OK) {
+        fprintf(stderr, "kta.gpus=%d: RCCL is not loadable (KTA_RCCL_LIBRARY)\n", job.nranks);
+        return 2;
+    }
+    printf("Subscribing to %s\n", job.topic.c_str());                              // kafka.rs:88
+    printf("Starting message consumption...\n");                                   // kafka.rs:91
+    fflush(stdout);
+    std::vector<kta::HipMetricHandler *> handlers(job.nranks, nullptr);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < job.nranks; r++) threads.emplace_back(run_rank, std::cref(job), r, uid, ndev, &handlers[r]);
+    for (auto &t : threads) t.join();
+    fprintf(stderr, "done\n");                                                     // kafka.rs:136 (spinner)
+    kta::HipMetricHandler *h0 = handlers[0];            // after the exchange every rank holds the whole job's result
+    uint64_t undelivered = 0;
+    for (auto *h : handlers) undelivered = std::max(undelivered, h->undelivered_records());
+    if (!job.synthetic && undelivered)
+        fprintf(stderr, "[WARN] Kafka error: %llu record(s) of corrupt batches were not delivered\n", (unsigned long long)undelivered);
+    const kta::MessageMetrics &metrics = h0->metrics();
+    if (job.synthetic)
+        for (uint32_t p = 0; p < job.P; p++) job.end_offsets[p] = (int64_t)metrics.total((int32_t)p);
+    std::vector<int32_t> partitions(job.P);
+    for (uint32_t p = 0; p < job.P; p++) partitions[p] = (int32_t)p;
+    const uint64_t duration_secs = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(
+                                       std::chrono::steady_clock::now() - start_time).count();
+    try {
+        std::string text = kta::render_report(job.topic, duration_secs, metrics, h0->log_compaction(), partitions,
+                                              job.start_offsets, job.end_offsets);
+        fputs(text.c_str(), stdout);
+    } catch (const kta::RustPanic &p) {
+        rust_panic(p.what(), p.location);
+    }
+    for (auto *h : handlers) delete h;
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
 {
     Args args = parse_args(argc, argv);
     const auto start_time = std::chrono::steady_clock::now();                       // main.rs:69
-    const bool count_alive = args.count_alive_occurrences == 1;                     // main.rs:77-80 (-c -c disables)
+    const bool count_alive = args.count_alive_occurrences == 1;                     // main.rs:77-80
     std::map<std::string, std::string> cfg = parse_librdkafka(args);                // main.rs:84-92
     const int device = cfg.count("kta.device") ? atoi(cfg["kta.device"].c_str()) : 0;
     const uint64_t batch = cfg.count("kta.batch") ? strtoull(cfg["kta.batch"].c_str(), nullptr, 10) : (1ull << 20);
+    const int gpus = cfg.count("kta.gpus") ? atoi(cfg["kta.gpus"].c_str()) : 1;
 
     // ---- the record source (stands in for TopicAnalyzer, src/kafka.rs) ------------------------------
     const std::string &b = args.bootstrap;
@@ -208,19 +349,13 @@ int main(int argc, char **argv)
     }
     const uint32_t P = hdr.n_partitions;
 
-    kta::HipMetricHandler *handler = nullptr;
-    try {
-        handler = new kta::HipMetricHandler((int32_t)P, count_alive, device, batch, 0);
-    } catch (const std::exception &e) {
-        fprintf(stderr, "%s\n", e.what());
-        return 2;
-    }
-    kta_ctx *ctx = handler->ctx();
     // librdkafka options are forwarded as in the reference (kafka.rs:38-42); the one this build can
     // honour for raw segments is check.crcs (default false): verify every batch's CRC-32C on the GPU
     const bool check_crcs = cfg.count("check.crcs") && cfg["check.crcs"] == "true";
-    if (segment) check(kta_kafka_set_check_crcs(ctx, check_crcs ? 1 : 0), ctx, "kta_kafka_set_check_crcs");
-
+    if (gpus > 1 && !synthetic && !segment) {
+        fprintf(stderr, "kta.gpus=%d needs a synthetic:// or segment:// source\n", gpus);
+        return 2;
+    }
     std::vector<int64_t> start_offsets(P, 0), end_offsets(P, 0);
     if (dump) { start_offsets = hdr.start_offsets; end_offsets = hdr.end_offsets; }
     if (kafka)
@@ -229,6 +364,8 @@ int main(int argc, char **argv)
             end_offsets[(size_t)kv.first] = kv.second;
         }
     std::vector<std::vector<uint8_t>> segment_bytes;
+    std::vector<uint64_t> segment_base_seq;   // records of the partitions before each one (consumption order: file by file)
+    uint64_t segment_records = 0;
     if (segment) {  // watermarks = first / last offset found in each partition's segment (kafka.rs:60-72)
         for (uint32_t p = 0; p < P; p++) {
             std::vector<uint8_t> bytes;
@@ -255,6 +392,8 @@ int main(int argc, char **argv)
                 start_offsets[p] = descs.front().base_offset;
                 end_offsets[p] = descs.back().base_offset + descs.back().n_records;
             }
+            segment_base_seq.push_back(segment_records);
+            if (rc == KTA_OK) segment_records += ist.n_records;
             segment_bytes.push_back(std::move(bytes));
         }
     }
@@ -269,6 +408,37 @@ int main(int argc, char **argv)
     }
     std::vector<int32_t> partitions(P);                                             // main.rs:103-106
     for (uint32_t p = 0; p < P; p++) partitions[p] = (int32_t)p;
+
+    if (gpus > 1) {   // kta.gpus=N: partition p on rank p % N, one exchange step before the report
+        ShardedJob job;
+        job.topic = args.topic;
+        job.count_alive = count_alive;
+        job.synthetic = synthetic;
+        job.check_crcs = check_crcs;
+        job.device = device;
+        job.nranks = gpus;
+        job.batch = batch;
+        job.P = P;
+        job.spec = spec;
+        job.n_records = n_records;
+        job.segment_bytes = std::move(segment_bytes);
+        job.base_seq = segment_base_seq;
+        job.start_offsets = start_offsets;
+        job.end_offsets = end_offsets;
+        return run_sharded(job, start_time);
+    }
+    // the handlers are created only now: MessageMetrics::new / LogCompactionInMemoryMetrics::new come after the
+    // "no content" exit in the reference as well (main.rs:77-82 build them, but nothing is allocated there; here
+    // -c means a 32 GiB table)
+    kta::HipMetricHandler *handler = nullptr;
+    try {
+        handler = new kta::HipMetricHandler((int32_t)P, count_alive, device, batch, 0);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 2;
+    }
+    kta_ctx *ctx = handler->ctx();
+    if (segment) check(kta_kafka_set_check_crcs(ctx, check_crcs ? 1 : 0), ctx, "kta_kafka_set_check_crcs");
 
     if (!kafka) {
         printf("Subscribing to %s\n", args.topic.c_str());                          // kafka.rs:88

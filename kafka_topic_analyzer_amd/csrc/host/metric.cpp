@@ -70,7 +70,7 @@ uint64_t MessageMetrics::smallest_message() const
 }
 
 HipMetricHandler::HipMetricHandler(int32_t n_partitions, bool count_alive_keys, int device, uint64_t batch_capacity,
-                                   uint64_t key_bytes_capacity)
+                                   uint64_t key_bytes_capacity, uint32_t flags)
     : P_(n_partitions), alive_(count_alive_keys)
 {
     struct timespec ts;
@@ -82,6 +82,7 @@ HipMetricHandler::HipMetricHandler(int32_t n_partitions, bool count_alive_keys, 
     cfg.count_alive_keys = count_alive_keys ? 1 : 0;
     cfg.batch_capacity = batch_capacity;
     cfg.key_bytes_capacity = key_bytes_capacity;
+    cfg.flags = flags;
     int rc = kta_create(&cfg, &ctx_);
     if (rc != KTA_OK) throw std::runtime_error(std::string("kta_create failed: ") + kta_last_error(nullptr));
 }
@@ -105,6 +106,23 @@ void HipMetricHandler::finish(bool tolerate_undelivered)
     std::vector<uint64_t> counters((size_t)P_ * KTA_NCOUNTERS);
     const int rc = kta_finish(ctx_, &r, counters.data());
     if (!(rc == KTA_ERR_BAD_PARTITION && tolerate_undelivered)) check(rc, "kta_finish");
+    undelivered_ = r.bad_partition_records;
+    metrics_ = MessageMetrics(r, std::move(counters), now_);
+    lc_ = LogCompactionInMemoryMetrics(r);
+}
+
+void HipMetricHandler::comm_create(int nranks, int rank, const uint8_t *unique_id)
+{
+    check(kta_comm_create(ctx_, nranks, rank, unique_id), "kta_comm_create");
+}
+
+void HipMetricHandler::exchange(bool tolerate_undelivered)
+{
+    check(kta_exchange(ctx_), "kta_exchange");
+    kta_result r{};
+    std::vector<uint64_t> counters((size_t)P_ * KTA_NCOUNTERS);
+    const int rc = kta_exchange_result(ctx_, &r, counters.data());
+    if (!(rc == KTA_ERR_BAD_PARTITION && tolerate_undelivered)) check(rc, "kta_exchange_result");
     undelivered_ = r.bad_partition_records;
     metrics_ = MessageMetrics(r, std::move(counters), now_);
     lc_ = LogCompactionInMemoryMetrics(r);

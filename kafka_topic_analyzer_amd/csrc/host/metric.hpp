@@ -94,7 +94,7 @@ private:
 class HipMetricHandler : public MetricHandler {
 public:
     HipMetricHandler(int32_t n_partitions, bool count_alive_keys, int device = 0, uint64_t batch_capacity = 0,
-                     uint64_t key_bytes_capacity = 0);
+                     uint64_t key_bytes_capacity = 0, uint32_t flags = 0);
     ~HipMetricHandler() override;
     HipMetricHandler(const HipMetricHandler &) = delete;
     HipMetricHandler &operator=(const HipMetricHandler &) = delete;
@@ -105,6 +105,10 @@ public:
     // partition -1 (never counted); with true they are reported through undelivered_records()
     // instead of failing the run (the reference warns on Kafka errors and goes on, kafka.rs:95-97).
     void finish(bool tolerate_undelivered = false);
+    // A rank of a partition-sharded run (one handler per GPU): join the job's communicator, and at the end
+    // exchange() instead of finish() — afterwards metrics() / log_compaction() are the whole job's on every rank.
+    void comm_create(int nranks, int rank, const uint8_t *unique_id);
+    void exchange(bool tolerate_undelivered = false);
     uint64_t undelivered_records() const { return undelivered_; }
     const MessageMetrics &metrics() const { return metrics_; }
     const LogCompactionInMemoryMetrics *log_compaction() const { return alive_ ? &lc_ : nullptr; }

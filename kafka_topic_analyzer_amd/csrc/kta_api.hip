@@ -35,6 +35,7 @@ struct kta_ctx {
     hipStream_t s_own = nullptr;    // the context's own compute stream (s_compute may be caller-owned)
     hipEvent_t ev_copied = nullptr;
     bool analytics = false;
+    bool stage_seq = false;         // KTA_FLAG_SEQ_COLUMN
     uint64_t *d_avec = nullptr;     // analytics vector u64[2*34 + 4*P] (KTA_FLAG_ANALYTICS)
     uint64_t *d_vec = nullptr;      // u64[P*7 + KTA_NGLOBALS]: the live accumulator
     uint64_t *d_vec_out = nullptr;  // its snapshot (kta_finish_device): what kta_result_vector hands out and the
@@ -136,7 +137,7 @@ void free_device_batch(kta_batch *b)
     memset(b, 0, sizeof(*b));
 }
 
-int alloc_host_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, kta_batch *b)
+int alloc_host_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, bool seq, kta_batch *b)
 {
     memset(b, 0, sizeof(*b));
     b->capacity = cap;
@@ -149,6 +150,7 @@ int alloc_host_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, kta_b
         KTA_HIP(ctx, hipHostMalloc((void **)&b->key_off, pad16(cap * 4), hipHostMallocDefault));
         KTA_HIP(ctx, hipHostMalloc((void **)&b->key_bytes, pad16(kcap + 16), hipHostMallocDefault));
     }
+    if (seq) KTA_HIP(ctx, hipHostMalloc((void **)&b->seq, pad16(cap * 8), hipHostMallocDefault));
     return KTA_OK;
 }
 
@@ -160,6 +162,7 @@ void free_host_batch(kta_batch *b)
     if (b->ts_ms) (void)hipHostFree(b->ts_ms);
     if (b->key_off) (void)hipHostFree(b->key_off);
     if (b->key_bytes) (void)hipHostFree(b->key_bytes);
+    if (b->seq) (void)hipHostFree(b->seq);
     memset(b, 0, sizeof(*b));
 }
 
@@ -336,6 +339,16 @@ extern "C" {
 
 int kta_abi_version(void) { return KTA_ABI_VERSION; }
 
+int kta_device_count(int *n)
+{
+    if (!n) return KTA_ERR_INVALID;
+    *n = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KTA_ERR_NO_DEVICE;
+    *n = ndev;
+    return KTA_OK;
+}
+
 const char *kta_last_error(const kta_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int kta_create(const kta_config *cfg, kta_ctx **out)
@@ -365,6 +378,7 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     ctx->P = (uint32_t)cfg->n_partitions;
     ctx->alive = cfg->count_alive_keys != 0;
     ctx->analytics = (cfg->flags & KTA_FLAG_ANALYTICS) != 0;
+    ctx->stage_seq = (cfg->flags & KTA_FLAG_SEQ_COLUMN) != 0;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->batch_capacity = cfg->batch_capacity ? cfg->batch_capacity : (1ull << 22);
     ctx->key_bytes_capacity = cfg->key_bytes_capacity ? cfg->key_bytes_capacity : 64ull * ctx->batch_capacity;
@@ -455,9 +469,10 @@ int kta_reset(kta_ctx *ctx)
 static int ensure_stage(kta_ctx *ctx, Stage &st)
 {
     if (st.host.partition) return KTA_OK;
-    int rc = alloc_host_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, &st.host);
+    const bool seq = ctx->alive && ctx->stage_seq;
+    int rc = alloc_host_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, seq, &st.host);
     if (rc != KTA_OK) return rc;
-    rc = alloc_device_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, false, &st.dev);
+    rc = alloc_device_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, seq, &st.dev);
     if (rc != KTA_OK) return rc;
     KTA_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     return KTA_OK;
@@ -499,6 +514,8 @@ int kta_batch_submit(kta_ctx *ctx, uint64_t n, uint64_t n_key_bytes, uint64_t ba
         if (n_key_bytes)
             KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_bytes, st.host.key_bytes, n_key_bytes,
                                         hipMemcpyHostToDevice, cs));
+        if (st.host.seq)   // KTA_FLAG_SEQ_COLUMN: the producer wrote every record's global sequence number
+            KTA_HIP(ctx, hipMemcpyAsync(st.dev.seq, st.host.seq, n * 8, hipMemcpyHostToDevice, cs));
     }
     KTA_HIP(ctx, hipEventRecord(ctx->ev_copied, cs));
     KTA_HIP(ctx, hipStreamWaitEvent(ctx->s_compute, ctx->ev_copied, 0));
@@ -519,6 +536,15 @@ int kta_flush(kta_ctx *ctx)
     ctx->fill_n = ctx->fill_kb = 0;
     ctx->next_seq += n;
     return kta_batch_submit(ctx, n, kb, base);
+}
+
+int kta_seek_seq(kta_ctx *ctx, uint64_t next_seq)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    int rc = kta_flush(ctx);   // records already staged keep the numbers they were given
+    if (rc != KTA_OK) return rc;
+    ctx->next_seq = next_seq;
+    return KTA_OK;
 }
 
 int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const void *key, int64_t key_len,
@@ -546,6 +572,7 @@ int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const voi
     h.key_len[i] = key_len < 0 ? -1 : (int32_t)key_len;
     h.val_len[i] = val_len < 0 ? -1 : (int32_t)val_len;
     if (ctx->alive) {
+        if (h.seq) h.seq[i] = ctx->next_seq + i;
         h.key_off[i] = (uint32_t)ctx->fill_kb;
         if (kb) {
             memcpy(h.key_bytes + ctx->fill_kb, key, kb);

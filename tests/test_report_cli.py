@@ -158,10 +158,32 @@ def test_cli_end_to_end_on_topic_dump_matches_golden_report(tmp_path, with_c):
     assert r.stdout.startswith(head)
     want = open(os.path.join(GOLDEN, "report_mixed_400_%s.txt" % ("with_c" if with_c else "without_c"))).read()
     assert _normalise(r.stdout[len(head):]) == want
-    # -c given twice silently disables alive-key counting (occurrences_of == 1, main.rs:77-80)
-    if with_c:
-        r2 = run_cli(*args, "-c")
-        assert r2.returncode == 0 and "Alive keys" not in r2.stdout
+
+
+def test_cli_rejects_a_repeated_flag_like_clap():
+    """-c is not `multiple(true)` (main.rs:60-66): clap 2 refuses the second occurrence before main.rs:77-80
+    could ever see occurrences_of != 1."""
+    r = run_cli("-t", "x", "-b", "synthetic://c1", "-c", "--count-alive-keys")
+    assert r.returncode == 1 and "provided more than once" in r.stderr and "USAGE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_refuses_a_topic_dump_whose_keys_point_outside_the_batch(tmp_path):
+    """An untrusted KTADUMP1 file: key_off + key_len beyond the batch's key bytes, or a length below -1, must
+    not be copied from (a heap over-read) — the batch is refused like a truncated file (warn, go on)."""
+    g = load_golden("scenarios.json")
+    cols = records_to_cols(scenario_records(g["scenarios"]["mixed_400"]))
+    for mutate in ("off", "len"):
+        bad = {k: np.array(v, copy=True) for k, v in cols.items()}
+        keyed = np.nonzero(bad["key_len"] > 0)[0]
+        if mutate == "off":
+            bad["key_off"][keyed[3]] = np.uint32(len(bad["key_bytes"]) + 1000)
+        else:
+            bad["key_len"][keyed[3]] = -7
+        path = str(tmp_path / ("bad_%s.ktadump" % mutate))
+        write_dump(path, bad, g["n_partitions"])
+        r = run_cli("-t", "bad", "-b", "dump://" + path, "-c")
+        assert "truncated topic dump" in r.stderr and r.returncode in (0, 101), (r.returncode, r.stderr[-500:])
 
 
 @pytest.mark.gpu
@@ -230,3 +252,43 @@ def test_cli_on_raw_kafka_log_segments(tmp_path, with_c):
     assert r2.returncode == 0 and "CRC" not in r2.stderr
     tot = lambda out: sum(int(l.split("|")[4]) for l in out.split("\n") if re.match(r"^\| \d", l))
     assert tot(r2.stdout) == len(records) and tot(r1.stdout) == len(records) - n0
+
+
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    lib = tmp_path_factory.mktemp("mock") / "libmock_rccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
+                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return str(lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_cli_sharded_over_several_ranks_prints_the_single_gpu_report(tmp_path, mock_rccl, gpus):
+    """kta.gpus=N: partition p on rank p % N (one thread + context + communicator rank each; here all on the one
+    reachable GPU, RCCL replaced by tests/mock_rccl.cpp), global sequence numbers, one kta_exchange — the
+    report, alive keys included, is the single-GPU run's byte for byte (synthetic:// and segment://)."""
+    env = dict(os.environ, KTA_RCCL_LIBRARY=mock_rccl)
+    one = run_cli("-t", "c2", "-b", "synthetic://c2?records=250000", "-c")
+    many = subprocess.run([CLI, "-t", "c2", "-b", "synthetic://c2?records=250000", "-c", "--librdkafka",
+                           "kta.gpus=%d,kta.batch=32768" % gpus], capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    assert "Alive keys: " in one.stdout and _normalise(many.stdout) == _normalise(one.stdout)
+    from kafka_cases import random_record_set
+    rng = np.random.default_rng(17)
+    files = []
+    for p in range(5):
+        blob, _, _ = random_record_set(rng, 25, partition=p, key_space=30, with_noise=False, snappy=(p % 2 == 0))
+        path = tmp_path / ("%020d.log" % p)
+        path.write_bytes(blob)
+        files.append(str(path))
+    src = "segment://" + ",".join(files)
+    one = run_cli("-t", "seg", "-b", src, "-c")
+    many = subprocess.run([CLI, "-t", "seg", "-b", src, "-c", "--librdkafka", "kta.gpus=%d" % gpus], capture_output=True,
+                          text=True, timeout=300, env=env)
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    assert _normalise(many.stdout) == _normalise(one.stdout) and "Alive keys: " in many.stdout
+    r = subprocess.run([CLI, "-t", "x", "-b", "dump:///nonexistent", "--librdkafka", "kta.gpus=2"], capture_output=True, text=True,
+                       timeout=60, env=env)
+    assert r.returncode != 0
