@@ -89,6 +89,9 @@ typedef struct kta_kafka_index_stats {
     uint64_t bytes_consumed;
     uint64_t n_gzip;             /* gzip batches (codec 1): inflated on the device           */
     uint64_t n_zstd;             /* zstd batches (codec 4): inflated on the device           */
+    int64_t first_offset;        /* baseOffset of the first v2 batch, control batches included            */
+    int64_t next_offset;         /* max(baseOffset + lastOffsetDelta + 1): the log end offset / high watermark */
+    uint64_t any_offsets;        /* 0: no v2 batch, the two offsets are meaningless                       */
 } kta_kafka_index_stats;
 
 /* Host: walk the batch headers of one record set.  `record_base_start` is the output index of the
@@ -168,11 +171,11 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n);
 /* CRC-32C of host bytes (the same tables the device uses; check value of "123456789": 0xE3069283). */
 uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 
-/* Decode kernel choice (process wide): 0 = automatic (default: by the number of batches in the call and
+/* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and
  * their mean size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch
  * inflate), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
  * 5 = 8 batches per wave (1 KiB windows). */
-int kta_kafka_set_variant(int variant);
+int kta_kafka_set_variant(kta_ctx *ctx, int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);
  * launches[] the counts.  Needs kta_set_timing(ctx, 1). */

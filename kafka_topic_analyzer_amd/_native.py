@@ -88,7 +88,8 @@ class KtaKafkaIndexStats(C.Structure):
                 ("n_compressed", C.c_uint64), ("n_snappy", C.c_uint64), ("n_lz4", C.c_uint64),
                 ("inflate_bytes", C.c_uint64),
                 ("n_old_magic", C.c_uint64), ("trailing_bytes", C.c_uint64),
-                ("bytes_consumed", C.c_uint64), ("n_gzip", C.c_uint64), ("n_zstd", C.c_uint64)]
+                ("bytes_consumed", C.c_uint64), ("n_gzip", C.c_uint64), ("n_zstd", C.c_uint64),
+                ("first_offset", C.c_int64), ("next_offset", C.c_int64), ("any_offsets", C.c_uint64)]
 
 
 # every symbol include/kta_hip.h, kta_synth.h and kta_kafka.h declare: (restype, argtypes)
@@ -161,7 +162,7 @@ SIGNATURES = {
                                               C.c_uint64, C.POINTER(C.c_uint64)]),
     "kta_kafka_encode_synth_host_ex": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
-    "kta_kafka_set_variant": (C.c_int, [C.c_int]),
+    "kta_kafka_set_variant": (C.c_int, [_P, C.c_int]),
     "kta_kafka_set_inflate_limit": (C.c_int, [_P, C.c_uint64]),
     "kta_kafka_set_check_crcs": (C.c_int, [_P, C.c_int]),
     "kta_kafka_crc_errors": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -388,9 +388,9 @@ int main(int argc, char **argv)
                 descs.resize(ist.n_batches);
                 rc = kta_kafka_index_host(bytes.data(), bytes.size(), (int32_t)p, 0, 0, 0, descs.data(), descs.size(), &ist);
             }
-            if (rc == KTA_OK && ist.n_batches > 0) {
-                start_offsets[p] = descs.front().base_offset;
-                end_offsets[p] = descs.back().base_offset + descs.back().n_records;
+            if (rc == KTA_OK && ist.any_offsets) {   // what the broker would answer: log start / log end offset,
+                start_offsets[p] = ist.first_offset;  // control batches and compacted-away offsets included
+                end_offsets[p] = ist.next_offset;
             }
             segment_base_seq.push_back(segment_records);
             if (rc == KTA_OK) segment_records += ist.n_records;

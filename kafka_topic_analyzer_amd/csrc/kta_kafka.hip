@@ -40,14 +40,13 @@ hipStream_t kta_internal_copy_stream(kta_ctx *ctx);
 namespace {
 
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
-int g_decode_variant = 0;          // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..5 = wave geometries
 
 // Automatic choice (measured on MI355X, tools/explore_decode.py): sharing a wave between batches pays as
 // long as the waves still fill the chip; the smaller the batches, the smaller the windows (more waves
 // resident, fewer bytes staged for nothing).
-int decode_variant_for(uint64_t n_batches, uint64_t blob_len)
+int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 {
-    if (g_decode_variant) return g_decode_variant;
+    if (forced) return forced;
     if (n_batches < 2048) return 2;
     const uint64_t mean = blob_len / n_batches;
     return mean < 4096 ? 5 : (mean < 65536 ? 4 : 3);
@@ -873,6 +872,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..5 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -988,6 +988,13 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (magic != 2) {
             stats->n_old_magic++;
         } else {
+            // the log's extent as a consumer's watermarks see it: every v2 batch counts, control batches
+            // included, and a batch ends at baseOffset + lastOffsetDelta + 1 (compaction may have removed records)
+            const int64_t b_first = (int64_t)be64(bytes + pos);
+            const int64_t b_next = b_first + (int64_t)(int32_t)be32(bytes + pos + 23) + 1;
+            if (!stats->any_offsets || b_first < stats->first_offset) stats->first_offset = b_first;
+            if (!stats->any_offsets || b_next > stats->next_offset) stats->next_offset = b_next;
+            stats->any_offsets = 1;
             const uint16_t attrs = be16(bytes + pos + 21);
             int32_t count = (int32_t)be32(bytes + pos + 57);
             const uint32_t codec = attrs & 0x07u;
@@ -1194,7 +1201,7 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     if (any_snappy || any_lz4 || any_gzip || any_zstd) {   // inflate compressed batches into their slices of the same buffer
         uint8_t *buf = const_cast<uint8_t *>(blob_device);
         uint32_t lane_codecs = 0u;
-        if (g_decode_variant != 1) {
+        if (st->variant != 1) {
             if (any_snappy)
                 hipLaunchKernelGGL(kafka_snappy_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs,
                                    n_batches);
@@ -1223,7 +1230,7 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
                        words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
                        out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
-    switch (decode_variant_for(n_batches, blob_len)) {
+    switch (decode_variant_for(st->variant, n_batches, blob_len)) {
     case 1: // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
                            out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off, (uint64_t)0, out->seq,
@@ -1490,10 +1497,10 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
     return KTA_OK;
 }
 
-int kta_kafka_set_variant(int variant)
+int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (variant < 0 || variant > 5) return KTA_ERR_INVALID;
-    g_decode_variant = variant;
+    if (!ctx || variant < 0 || variant > 5) return KTA_ERR_INVALID;
+    state_of(ctx)->variant = variant;
     return KTA_OK;
 }
 

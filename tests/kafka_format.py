@@ -55,7 +55,7 @@ def encode_record(offset_delta, ts_delta, key, value, headers=()):
 
 
 def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, producer_id=-1, magic=2,
-                 raw_records=None, count=None, compression=None):
+                 raw_records=None, count=None, compression=None, last_offset_delta=None):
     """records: [(ts_delta, key|None, value|None, headers)]; returns the batch bytes.
     raw_records/count let tests build corrupt or compressed-looking batches.
     compression: None, "snappy" (one bare block, as librdkafka writes), "snappy-xerial" (snappy-java
@@ -110,7 +110,8 @@ def encode_batch(base_offset, records, base_ts, attributes=0, max_ts=None, produ
     n = len(records) if count is None else count
     if max_ts is None:
         max_ts = max([base_ts + r[0] for r in records], default=base_ts)
-    after_crc = struct.pack(">hiqqqhii", attributes, max(n - 1, 0), base_ts, max_ts, producer_id, -1, -1, n) + recs
+    lod = max(n - 1, 0) if last_offset_delta is None else last_offset_delta   # a compacted batch keeps its original extent
+    after_crc = struct.pack(">hiqqqhii", attributes, lod, base_ts, max_ts, producer_id, -1, -1, n) + recs
     crc = crc32c(after_crc)
     tail = struct.pack(">iBI", 0, magic, crc) + after_crc  # partitionLeaderEpoch, magic, crc
     return struct.pack(">qi", base_offset, len(tail)) + tail

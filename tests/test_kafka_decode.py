@@ -89,6 +89,22 @@ def test_host_index_matches_oracle_and_handles_partial_tail():
     assert rc == N.KTA_OK and st3.n_batches == 0 and st3.trailing_bytes == 7
 
 
+def test_host_index_reports_the_log_extent_a_consumer_sees():
+    """Watermarks (src/kafka.rs:60-72 asks the broker; segment:// asks the file): the log starts at the first
+    batch's baseOffset and ends at max(baseOffset + lastOffsetDelta + 1) — a compacted batch keeps its
+    original extent although records are gone, and control batches (never delivered) count."""
+    compacted = K.encode_batch(100, [(0, b"a", b"1"), (5, b"b", None)], 1000, last_offset_delta=9)   # offsets 100..109, 2 left
+    data = K.encode_batch(110, [(0, b"c", b"2")], 1000)
+    control = K.encode_batch(111, [(0, b"\0\0\0\0", b"")], 1000, attributes=0x30)                    # commit marker at 111
+    rc, descs, st = index_host(compacted + data + control, 0)
+    assert rc == N.KTA_OK and st.n_batches == 2 and st.n_records == 3 and st.n_control_batches == 1
+    assert (st.any_offsets, st.first_offset, st.next_offset) == (1, 100, 112)
+    rc, descs, st = index_host(control, 0)
+    assert st.n_batches == 0 and (st.any_offsets, st.first_offset, st.next_offset) == (1, 111, 112)
+    rc, descs, st = index_host(b"", 0)
+    assert st.any_offsets == 0
+
+
 def test_oracle_marks_corrupt_batches():
     good = K.encode_batch(0, [(0, b"a", b"b"), (1, b"c", None)], 1000)
     # recordsCount says 3 but only 2 records are present
@@ -231,10 +247,9 @@ def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, 
     blob, expected, _ = random_record_set(rng, 300 if max_records < 1000 else 12, max_records=max_records,
                                           big=(seed == 5))
     want, _ = kafka_decode(blob, 3)
-    N.load().kta_kafka_set_variant(variant)
     with kta.HipMetricHandler(8, now=NOW) as h:
+        h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
         cols, st, bad = _decode_on_device(h, blob, 3, with_keys)
-    N.load().kta_kafka_set_variant(0)
     assert bad == 0
     assert_columns(cols, expected, key_check=with_keys)   # keys compared by content through key_off
     for k in ("partition", "key_len", "val_len", "ts_ms"):
@@ -250,12 +265,11 @@ def test_device_decode_reports_corrupt_batches():
     blob = good + bad + good
     want, ost = kafka_decode(blob, 0)
     for variant in (0, 1, 2, 3, 4, 5):
-        N.load().kta_kafka_set_variant(variant)
         with kta.HipMetricHandler(2, now=NOW) as h:
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, nbad = _decode_on_device(h, blob, 0, True)
             assert nbad == 1 == ost.bad_batches
             assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
-    N.load().kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
@@ -263,13 +277,12 @@ def test_device_does_not_deliver_a_batch_with_a_forged_record_count():
     blob, _ = _forged_count_blob()
     want, ost = kafka_decode(blob, 5)
     for variant in (0, 1):
-        N.load().kta_kafka_set_variant(variant)
         with kta.HipMetricHandler(8, now=NOW) as h:
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, nbad = _decode_on_device(h, blob, 5, True)
             assert nbad == 1 == ost.bad_batches
             for k in ("partition", "key_len", "val_len", "ts_ms"):
                 assert np.array_equal(cols[k], want[k]), k
-    N.load().kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
@@ -608,8 +621,8 @@ def test_device_inflates_streams_of_the_real_libraries():
     want, _ = kafka_decode(blob, 2)
     lib = N.load()
     for variant in (0, 1):
-        lib.kta_kafka_set_variant(variant)
         with kta.HipMetricHandler(4, now=NOW) as h:
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, bad = _decode_on_device(h, blob, 2, True)
             assert bad == 0 and st.n_snappy == 2 and st.n_lz4 == 2
             for k in ("partition", "key_len", "val_len", "ts_ms"):
@@ -617,7 +630,6 @@ def test_device_inflates_streams_of_the_real_libraries():
             kb = cols["key_bytes"].tobytes()
             o = int(cols["key_off"][0])                       # first record of the first (snappy) batch: key, value follow
             assert kb[o:o + 2] == b"k0" and recs[0][2] in kb[o:o + len(recs[0][2]) + 16]
-    lib.kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
@@ -628,8 +640,8 @@ def test_device_decodes_snappy_batches(variant):
     assert info["snappy"] > 8 and info["lz4"] > 8 and info["gzip"] > 15 and info["zstd"] > 10
     want, _ = kafka_decode(blob, 3)
     lib = N.load()
-    lib.kta_kafka_set_variant(variant)
     with kta.HipMetricHandler(8, now=NOW) as h:
+        h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
         h._check(lib.kta_kafka_set_check_crcs(h._ctx, 1))   # the CRC covers the compressed bytes
         cols, st, bad = _decode_on_device(h, blob, 3, True)
         assert bad == 0 and st.n_snappy == info["snappy"] and st.n_lz4 == info["lz4"] and st.n_gzip == info["gzip"]
@@ -662,7 +674,6 @@ def test_device_decodes_snappy_batches(variant):
         broken[first_block + 6] = 0x00
         cols3, st3, bad3 = _decode_on_device(h, bytes(broken), 3, True)
         assert bad3 >= 1 and (cols3["partition"] == -1).sum() == descs[victim].n_records
-    lib.kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
@@ -682,8 +693,8 @@ def test_device_inflate_far_matches_and_long_literals():
     want, _ = kafka_decode(blob, 1)
     lib = N.load()
     for variant in (0, 1):
-        lib.kta_kafka_set_variant(variant)
         with kta.HipMetricHandler(2, now=NOW) as h:
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, bad = _decode_on_device(h, blob, 1, True)
             assert bad == 0 and st.n_snappy == 2 and st.n_lz4 == 2
             for k in ("partition", "key_len", "val_len", "ts_ms"):
@@ -696,7 +707,6 @@ def test_device_inflate_far_matches_and_long_literals():
                 assert kb[o:o + 3] == key
             o = int(cols["key_off"][0])
             assert far in kb[o:o + len(far) + 64]
-    lib.kta_kafka_set_variant(0)
 
 
 @pytest.mark.gpu
