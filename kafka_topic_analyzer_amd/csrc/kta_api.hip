@@ -17,9 +17,18 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
+// One staging batch = ONE pinned slab and ONE device slab with the same layout: the columns at 16-byte
+// aligned offsets in the order [partition | key_len | val_len | ts_ms | key_off | seq | key_bytes], sized for
+// the batch capacity, the variable part (key bytes) last.  A submit is then a single H2D copy of the slab's
+// used prefix (a copy per column — up to seven DMA launches per batch — was 19 % of the GPU time of a
+// host-fed run, profiles/r01).
 struct Stage {
-    kta_batch host{};  // pinned
-    kta_batch dev{};   // device staging
+    kta_batch host{};  // column pointers into host_slab (pinned)
+    kta_batch dev{};   // column pointers into dev_slab
+    uint8_t *host_slab = nullptr, *dev_slab = nullptr;
+    size_t metric_bytes = 0;      // [partition .. ts_ms]
+    size_t key_bytes_off = 0;     // where key_bytes starts (0 without -c)
+    size_t slab_bytes = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
 };
@@ -134,35 +143,6 @@ void free_device_batch(kta_batch *b)
     if (b->key_off) (void)hipFree(b->key_off);
     if (b->key_bytes) (void)hipFree(b->key_bytes);
     if (b->seq) (void)hipFree(b->seq);
-    memset(b, 0, sizeof(*b));
-}
-
-int alloc_host_batch(kta_ctx *ctx, uint64_t cap, uint64_t kcap, bool keys, bool seq, kta_batch *b)
-{
-    memset(b, 0, sizeof(*b));
-    b->capacity = cap;
-    b->key_bytes_capacity = keys ? kcap : 0;
-    KTA_HIP(ctx, hipHostMalloc((void **)&b->partition, pad16(cap * 4), hipHostMallocDefault));
-    KTA_HIP(ctx, hipHostMalloc((void **)&b->key_len, pad16(cap * 4), hipHostMallocDefault));
-    KTA_HIP(ctx, hipHostMalloc((void **)&b->val_len, pad16(cap * 4), hipHostMallocDefault));
-    KTA_HIP(ctx, hipHostMalloc((void **)&b->ts_ms, pad16(cap * 8), hipHostMallocDefault));
-    if (keys) {
-        KTA_HIP(ctx, hipHostMalloc((void **)&b->key_off, pad16(cap * 4), hipHostMallocDefault));
-        KTA_HIP(ctx, hipHostMalloc((void **)&b->key_bytes, pad16(kcap + 16), hipHostMallocDefault));
-    }
-    if (seq) KTA_HIP(ctx, hipHostMalloc((void **)&b->seq, pad16(cap * 8), hipHostMallocDefault));
-    return KTA_OK;
-}
-
-void free_host_batch(kta_batch *b)
-{
-    if (b->partition) (void)hipHostFree(b->partition);
-    if (b->key_len) (void)hipHostFree(b->key_len);
-    if (b->val_len) (void)hipHostFree(b->val_len);
-    if (b->ts_ms) (void)hipHostFree(b->ts_ms);
-    if (b->key_off) (void)hipHostFree(b->key_off);
-    if (b->key_bytes) (void)hipHostFree(b->key_bytes);
-    if (b->seq) (void)hipHostFree(b->seq);
     memset(b, 0, sizeof(*b));
 }
 
@@ -431,8 +411,8 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->ext_state && ctx->ext_free) ctx->ext_free(ctx->ext_state);
     if (ctx->comm_state && ctx->comm_free) ctx->comm_free(ctx->comm_state);
     for (auto &st : ctx->stages) {
-        free_host_batch(&st.host);
-        free_device_batch(&st.dev);
+        if (st.host_slab) (void)hipHostFree(st.host_slab);
+        if (st.dev_slab) (void)hipFree(st.dev_slab);
         if (st.done) (void)hipEventDestroy(st.done);
     }
     if (ctx->d_vec) (void)hipFree(ctx->d_vec);
@@ -468,12 +448,40 @@ int kta_reset(kta_ctx *ctx)
 
 static int ensure_stage(kta_ctx *ctx, Stage &st)
 {
-    if (st.host.partition) return KTA_OK;
-    const bool seq = ctx->alive && ctx->stage_seq;
-    int rc = alloc_host_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, seq, &st.host);
-    if (rc != KTA_OK) return rc;
-    rc = alloc_device_batch(ctx, ctx->batch_capacity, ctx->key_bytes_capacity, ctx->alive, seq, &st.dev);
-    if (rc != KTA_OK) return rc;
+    if (st.host_slab) return KTA_OK;
+    const uint64_t cap = ctx->batch_capacity, kcap = ctx->key_bytes_capacity;
+    const bool keys = ctx->alive, seq = ctx->alive && ctx->stage_seq;
+    size_t off = 0, o_part, o_klen, o_vlen, o_ts, o_koff = 0, o_seq = 0, o_kb = 0;
+    o_part = off; off += pad16(cap * 4);
+    o_klen = off; off += pad16(cap * 4);
+    o_vlen = off; off += pad16(cap * 4);
+    o_ts = off; off += pad16(cap * 8);
+    st.metric_bytes = off;
+    if (keys) {
+        o_koff = off; off += pad16(cap * 4);
+        if (seq) { o_seq = off; off += pad16(cap * 8); }
+        o_kb = off; off += pad16(kcap + 16);
+    }
+    st.key_bytes_off = o_kb;
+    st.slab_bytes = off;
+    KTA_HIP(ctx, hipHostMalloc((void **)&st.host_slab, off, hipHostMallocDefault));
+    KTA_HIP(ctx, hipMalloc((void **)&st.dev_slab, off));
+    auto point = [&](kta_batch &b, uint8_t *base) {
+        memset(&b, 0, sizeof b);
+        b.capacity = cap;
+        b.key_bytes_capacity = keys ? kcap : 0;
+        b.partition = reinterpret_cast<int32_t *>(base + o_part);
+        b.key_len = reinterpret_cast<int32_t *>(base + o_klen);
+        b.val_len = reinterpret_cast<int32_t *>(base + o_vlen);
+        b.ts_ms = reinterpret_cast<int64_t *>(base + o_ts);
+        if (keys) {
+            b.key_off = reinterpret_cast<uint32_t *>(base + o_koff);
+            b.key_bytes = base + o_kb;
+            if (seq) b.seq = reinterpret_cast<uint64_t *>(base + o_seq);
+        }
+    };
+    point(st.host, st.host_slab);
+    point(st.dev, st.dev_slab);
     KTA_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     return KTA_OK;
 }
@@ -505,17 +513,23 @@ int kta_batch_submit(kta_ctx *ctx, uint64_t n, uint64_t n_key_bytes, uint64_t ba
     ctx->acquired = false;
     if (n == 0) return KTA_OK;
     hipStream_t cs = ctx->s_copy;
-    KTA_HIP(ctx, hipMemcpyAsync(st.dev.partition, st.host.partition, n * 4, hipMemcpyHostToDevice, cs));
-    KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_len, st.host.key_len, n * 4, hipMemcpyHostToDevice, cs));
-    KTA_HIP(ctx, hipMemcpyAsync(st.dev.val_len, st.host.val_len, n * 4, hipMemcpyHostToDevice, cs));
-    KTA_HIP(ctx, hipMemcpyAsync(st.dev.ts_ms, st.host.ts_ms, n * 8, hipMemcpyHostToDevice, cs));
-    if (ctx->alive) {
-        KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_off, st.host.key_off, n * 4, hipMemcpyHostToDevice, cs));
-        if (n_key_bytes)
-            KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_bytes, st.host.key_bytes, n_key_bytes,
-                                        hipMemcpyHostToDevice, cs));
-        if (st.host.seq)   // KTA_FLAG_SEQ_COLUMN: the producer wrote every record's global sequence number
-            KTA_HIP(ctx, hipMemcpyAsync(st.dev.seq, st.host.seq, n * 8, hipMemcpyHostToDevice, cs));
+    const size_t used = ctx->alive ? st.key_bytes_off + n_key_bytes : st.metric_bytes;
+    if (n * 2 >= ctx->batch_capacity) {
+        // a batch that is at least half full (every batch of a stream but its last): ONE copy of the slab's
+        // used prefix — the unused tails of the columns travel along, the launches do not multiply
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev_slab, st.host_slab, used, hipMemcpyHostToDevice, cs));
+    } else {
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev.partition, st.host.partition, n * 4, hipMemcpyHostToDevice, cs));
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_len, st.host.key_len, n * 4, hipMemcpyHostToDevice, cs));
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev.val_len, st.host.val_len, n * 4, hipMemcpyHostToDevice, cs));
+        KTA_HIP(ctx, hipMemcpyAsync(st.dev.ts_ms, st.host.ts_ms, n * 8, hipMemcpyHostToDevice, cs));
+        if (ctx->alive) {
+            KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_off, st.host.key_off, n * 4, hipMemcpyHostToDevice, cs));
+            if (n_key_bytes)
+                KTA_HIP(ctx, hipMemcpyAsync(st.dev.key_bytes, st.host.key_bytes, n_key_bytes, hipMemcpyHostToDevice, cs));
+            if (st.host.seq)   // KTA_FLAG_SEQ_COLUMN: the producer wrote every record's global sequence number
+                KTA_HIP(ctx, hipMemcpyAsync(st.dev.seq, st.host.seq, n * 8, hipMemcpyHostToDevice, cs));
+        }
     }
     KTA_HIP(ctx, hipEventRecord(ctx->ev_copied, cs));
     KTA_HIP(ctx, hipStreamWaitEvent(ctx->s_compute, ctx->ev_copied, 0));

@@ -40,6 +40,7 @@ hipStream_t kta_internal_copy_stream(kta_ctx *ctx);
 namespace {
 
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
+constexpr uint64_t kMaxBatchInflate = 512ull << 20;   // inflated size one batch may claim
 
 // Automatic choice (measured on MI355X, tools/explore_decode.py): sharing a wave between batches pays as
 // long as the waves still fill the chip; the smaller the batches, the smaller the windows (more waves
@@ -1021,6 +1022,11 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                     inflated = -1;
                 }
             }
+            // A batch that claims to inflate to more than this is not decoded (and is reported): brokers cap a
+            // batch at message.max.bytes (1 MiB by default, rarely above 100 MiB) before compression ratios,
+            // and one absurd bound (an LZ4 frame of RLE blocks, a zstd window) must not make the whole
+            // call run out of inflate area.
+            if (inflated > (int64_t)kMaxBatchInflate) inflated = -1;
             if (attrs & 0x20) stats->n_control_batches++;                 // control batch: never delivered
             else if (codec > 4) stats->n_compressed++;                    // unknown codecs (5..7): not decoded here
             else if (count > 0) {
