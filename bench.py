@@ -40,19 +40,23 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB
 BYTES_PER_RECORD = 20        # partition i32 + key_len i32 + val_len i32 + ts_ms i64
 
 
-class _DevVec:
-    """Zero-copy torch view of the library's device counter vector (as int64)."""
-
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r02.sh, " \
+                 "not measured in this run)"
 
 
-def _traffic(kernel, records_per_launch):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or None when the
-    file has no entry for this kernel at this launch size."""
+def _traffic(kernels, records_per_launch):
+    """HBM bytes per launch, summed over `kernels`, from the committed PMC passes (profiles/traffic.json);
+    None when the file lacks one of the kernels at this launch size.  Replayed, not measured here: the
+    counters need their own rocprofv3 passes."""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-        return e["hbm_bytes_per_launch"] if e["records_per_launch"] == records_per_launch else None
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        total = 0
+        for k in ([kernels] if isinstance(kernels, str) else kernels):
+            e = table[k]
+            if e["records_per_launch"] != records_per_launch:
+                return None
+            total += e["hbm_bytes_per_launch"]
+        return total
     except Exception:
         return None
 
@@ -121,13 +125,16 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     out = {"workload": f"c3 shape: 64 partitions, {n_records} records, 16 B keys, 10M distinct, 10% tombstones",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
            "alive_keys": int(res.alive_keys),
-           "roofline": {"bound": "hbm", "kernel": "kta_alive_update_filtered",
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply",
                         "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": _traffic("kta_alive_update_filtered", n_records),
-                        "note": "random 8-byte reads and atomicMax RMWs of the 32 GiB last-writer table dominate; "
-                                "their traffic is not part of the algorithmic bytes"}}
+                        "traffic": _traffic(["kta_alive_partition", "kta_alive_apply"], n_records),
+                        "traffic_source": TRAFFIC_SOURCE,
+                        "note": "kernel_ms is the HIP-event time of the PAIR of kernels of one batch (hash + partition, "
+                                "then per-bucket merge + table update); the 8 bytes per record of partitioned pairs "
+                                "written and read back, and the reads / partial writes of the 32 GiB last-writer table, "
+                                "are traffic, not algorithmic bytes"}}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)
     passes, t_total = 0, 0.0
@@ -238,7 +245,7 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
            "roofline": {"bound": "hbm", "kernel": "kafka_decode_coop", "achieved": ln.value / (a[1] * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ln.value / (a[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": ln.value, "kernel_ms": a[1], "launches": int(c[1]),
-                        "traffic": _traffic("kafka_decode_coop", n_records),
+                        "traffic": _traffic("kafka_decode_coop", n_records), "traffic_source": TRAFFIC_SOURCE,
                         "note": "algorithmic bytes = the raw log (every window is streamed through LDS)"},
            "host_index": {"ms": t_index * 1e3, "GBps": ln.value / t_index / 1e9},
            "cpu_baseline": {"value": n_sample * passes / t_total, "unit": "records/s", "cores": 1, "kind": "port",
@@ -354,26 +361,27 @@ def main():
     h.synth_fill_device(spec, rank * n, n, batch)          # rank-disjoint record index ranges
     h.sync()
 
-    ptr, nwords = h.result_vector()
-    vec = torch.as_tensor(_DevVec(ptr, nwords), device=torch.device("cuda", local_rank))
     n_sum = D.sum_prefix_len(P)
 
     if exchange:
-        # Run the library on a torch stream: scan, fold and the two all-reduces are then stream-ordered
-        # (ProcessGroupNCCL orders its internal stream against the CURRENT torch stream with events) and a
-        # step needs no host synchronisation at all.  It must be a created stream: torch's default stream
-        # is the null stream, whose handle 0 means "restore the library's own stream" to kta_set_compute_stream.
-        stream = torch.cuda.Stream(device=local_rank)
-        assert stream.cuda_stream != 0
-        torch.cuda.set_stream(stream)
-        h.use_stream(stream.cuda_stream)
+        # The exchange is the library's own (csrc/kta_comm.hip: RCCL bound at run time, one grouped launch of
+        # all-reduce SUM + all-reduce MAX on the context's compute stream, stream-ordered behind the fold
+        # kernel: a step has no host synchronisation).  torch.distributed only carries the rendezvous (the
+        # 128-byte RCCL id), the barriers and the max-over-ranks of the elapsed time.
+        uid = torch.zeros(N.KTA_COMM_ID_BYTES, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(kta.HipMetricHandler.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        if world == 1:
+            os.environ["KTA_COMM_FORCE_RCCL"] = "1"        # forced mode: a real one-rank communicator
+        h.comm_create(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
     def step():
         """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
         h.reset()                                          # MessageMetrics::new state (tiny kernel)
         h.submit_device(batch, n, 0, which=1)              # scan + fold
         if exchange:
-            D.allreduce_counter_vector(vec, P)             # C1 SUM (counters) + C2 MAX (four extrema), same stream
+            h.exchange()                                   # snapshot + C1 SUM (counters) + C2 MAX (four extrema), same stream
 
     def barrier():
         if exchange:
@@ -408,12 +416,11 @@ def main():
         # the exchange result itself: after one more step every rank must hold the whole job's totals
         step()
         barrier()
-        totals = vec[0:P * N.KTA_NCOUNTERS:N.KTA_NCOUNTERS]
-        got = int(totals.sum().item())
-        assert got == n * world, "exchange step lost records: %d != %d" % (got, n * world)
-        assert int(vec[P * N.KTA_NCOUNTERS + N.KTA_G_RECORDS].item()) == n * world
-        h.use_stream(None)
-        torch.cuda.set_stream(torch.cuda.default_stream(local_rank))
+        xres, xc = h.exchange_result()
+        got = int(xc[:, N.KTA_C_TOTAL].sum())
+        assert got == n * world == xres.overall_count, "exchange step lost records: %d != %d" % (got, n * world)
+        assert (xc[:, N.KTA_C_TOTAL] > 0).all(), "a partition of another rank is missing from the exchanged result"
+        h.comm_destroy()
     # sanity inside the bench: a single fresh pass must count exactly n records on this rank
     h.reset()
     h.submit_device(batch, n, 0, which=1)
@@ -438,9 +445,10 @@ def main():
                        "bytes_per_record": BYTES_PER_RECORD, "parallelism": f"partition-sharded x{world}",
                        "forced_collectives": bool(force_coll),
                        "exchange": "none (1 GPU)" if not exchange else
-                                   "per step: all-reduce SUM u64[%d] + all-reduce MAX i64[4] (RCCL)" % n_sum},
+                                   "per step: kta_exchange = one grouped RCCL launch of all-reduce SUM u64[%d] + all-reduce "
+                                   "MAX i64[4] on the compute stream (csrc/kta_comm.hip)" % n_sum},
             "roofline": {"bound": "hbm", "kernel": "kta_metrics_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE,
                          "bytes_per_launch": BYTES_PER_RECORD * n, "kernel_ms": scan_ms, "launches": int(cnt[0]),
                          "fold_kernel_ms": avg_ms[1], "frac_of_measured_achievable_6290": achieved / 6290.0},
         }

@@ -266,10 +266,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 const uint64_t take = n - at < pl.max_records ? n - at : pl.max_records;
                 if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words) {
                     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
-                    if (ctx->d_alive_stats) (void)hipFree(ctx->d_alive_stats);
-    if (ctx->h_alive_stats) (void)hipHostFree(ctx->h_alive_stats);
-    if (ctx->ev_alive_stats) (void)hipEventDestroy(ctx->ev_alive_stats);
-    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
+                    if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
                     if (ctx->d_pair_counts) (void)hipFree(ctx->d_pair_counts);
                     ctx->d_pairs = nullptr;
                     ctx->d_pair_counts = nullptr;

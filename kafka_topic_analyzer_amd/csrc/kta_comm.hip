@@ -254,14 +254,21 @@ int kta_comm_create(kta_ctx *ctx, int nranks, int rank, const uint8_t id[KTA_COM
     CommState *st = new CommState();
     st->nranks = nranks;
     st->rank = rank;
-    if (nranks > 1) {
+    // KTA_COMM_FORCE_RCCL=1: a real one-rank communicator, so that a box with a single GPU still runs the
+    // collectives of the exchange (tests, bench.py's forced mode)
+    const char *force = getenv("KTA_COMM_FORCE_RCCL");
+    if (nranks > 1 || (force && *force == '1')) {
         Rccl *R = rccl();
         if (!R->lib) {
             delete st;
             return fail(ctx, KTA_ERR_COMM, R->error);
         }
         ncclUniqueId u;
-        memcpy(&u, id, sizeof u);
+        if (id) memcpy(&u, id, sizeof u);
+        else if (R->GetUniqueId(&u) != ncclSuccess) {
+            delete st;
+            return fail(ctx, KTA_ERR_COMM, "ncclGetUniqueId failed");
+        }
         int r = R->CommInitRank(&st->comm, nranks, u, rank);
         if (r != ncclSuccess) {
             delete st;
@@ -292,7 +299,7 @@ int kta_exchange(kta_ctx *ctx)
     CommState *st = static_cast<CommState *>(*slot);
     if (!st) return fail(ctx, KTA_ERR_INVALID, "kta_exchange without kta_comm_create");
     int rc = kta_finish_device(ctx);           // flush + snapshot (+ this rank's alive count)
-    if (rc != KTA_OK || st->nranks == 1) return rc;
+    if (rc != KTA_OK || !st->comm) return rc;  // one rank without a communicator: the snapshot is the job's result
     CH(ctx, hipSetDevice(kta_internal_device(ctx)));
     if (kta_internal_count_alive(ctx)) {
         rc = exchange_alive(ctx, st);
@@ -315,7 +322,7 @@ int kta_comm_allreduce_i64(kta_ctx *ctx, int64_t *host_values, size_t n, int op_
     void **slot = kta_internal_comm_slot(ctx, free_comm);
     CommState *st = static_cast<CommState *>(*slot);
     if (!st) return fail(ctx, KTA_ERR_INVALID, "kta_comm_allreduce_i64 without kta_comm_create");
-    if (st->nranks == 1 || n == 0) return KTA_OK;
+    if (!st->comm || n == 0) return KTA_OK;
     CH(ctx, hipSetDevice(kta_internal_device(ctx)));
     hipStream_t s = kta_internal_stream(ctx);
     int64_t *d = nullptr;

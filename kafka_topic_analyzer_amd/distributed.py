@@ -1,5 +1,8 @@
-"""Partition-sharded multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is
-RCCL over xGMI on ROCm, "gloo" on CPU in the tests).
+"""Partition-sharded multi-GPU plumbing over torch.distributed (backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" on CPU in the tests).  The PRODUCT path of the exchange is native — kta_comm_create / kta_exchange
+(csrc/kta_comm.hip, include/kta_hip.h) — and needs no torch; this module is the same exchange written on
+torch collectives, kept as the harness the world-size-2/3 gloo tests drive on CPU and as a cross-check of
+the native one.
 
 The reference is single-process (src/kafka.rs:92-135), but every per-partition counter depends only
 on its own partition's records (src/metric.rs:74-100) and the globals are min/max/sum, so Kafka
@@ -34,11 +37,21 @@ def sum_prefix_len(n_partitions: int) -> int:
     return n_partitions * N.KTA_NCOUNTERS + N.KTA_NSUM_GLOBALS
 
 
-def allreduce_counter_vector(vec, n_partitions: int, group=None) -> None:
-    """In-place exchange step over an int64 view of the counter vector (device or CPU tensor)."""
+def allreduce_counter_vector(vec, n_partitions: int, group=None, alive_keys: str = "share") -> None:
+    """In-place exchange step over an int64 view of the SNAPSHOT counter vector (kta_result_vector: device
+    tensor, or a CPU tensor in the tests) — the live accumulator is never reduced.
+
+    KTA_G_ALIVE_KEYS sits in the SUM prefix, so what every rank contributes must add up to the job's count:
+    "share"  — each rank's word is the count of a DISJOINT share of the slots (the hash range it owns after
+               exchange_alive_by_hash_range; what kta_exchange does natively); the default;
+    "merged" — the tables were fully merged first (exchange_alive_entries / allreduce_alive_table), every rank
+               holds the global count: all ranks but 0 contribute zero."""
     import torch.distributed as dist
     k = sum_prefix_len(n_partitions)
     assert vec.numel() == n_partitions * N.KTA_NCOUNTERS + N.KTA_NGLOBALS
+    assert alive_keys in ("share", "merged")
+    if alive_keys == "merged" and dist.get_rank(group) != 0:
+        vec[n_partitions * N.KTA_NCOUNTERS + N.KTA_G_ALIVE_KEYS] = 0
     dist.all_reduce(vec[:k], op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(vec[k:], op=dist.ReduceOp.MAX, group=group)
 

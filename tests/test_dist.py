@@ -72,6 +72,20 @@ def _worker(rank, world, port, P, seed, q):
             tbl[slot] = max(tbl[slot], val)
         tt = torch.from_numpy(tbl)
         D.allreduce_alive_table(tt, chunk_elems=1 << 14)
+        # KTA_G_ALIVE_KEYS through the SUM all-reduce: after a full merge every rank holds the global count
+        # ("merged": only rank 0 contributes); with hash-range ownership each rank counts its own share
+        ak = P * N.KTA_NCOUNTERS + N.KTA_G_ALIVE_KEYS
+        merged_count = int((tt & 1).sum())
+        t_merged = torch.from_numpy(vec.copy())
+        t_merged[ak] = merged_count
+        D.allreduce_counter_vector(t_merged, P, alive_keys="merged")
+        lo, hi = (1 << 16) * rank // world, (1 << 16) * (rank + 1) // world
+        t_share = torch.from_numpy(vec.copy())
+        t_share[ak] = int((tt[lo:hi] & 1).sum())
+        D.allreduce_counter_vector(t_share, P, alive_keys="share")
+        assert int(t_merged[ak]) == int(t_share[ak]) == merged_count, (int(t_merged[ak]), int(t_share[ak]), merged_count)
+        t_merged[ak] = 0
+        assert torch.equal(t_merged, t)                      # everything else is untouched by the mode
         q.put((rank, t.numpy().copy(), tt.numpy().copy()))
         dist.barrier()
     finally:
