@@ -253,6 +253,37 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
                                       f"({t_total:.1f} s), oracle/kta_kafka_oracle.c sequential decoder"}}
     h.device_batch_free(out)
     h.device_batch_free(d_blob)
+    # the same kernel family at other batch sizes (the geometry is chosen per call from the mean batch size):
+    # one row per size, each with its own launch time — a profile's per-kernel average mixes them
+    rep["by_batch_size"] = []
+    for rpb2, label in ((8, "~2 KiB"), (60, "~16 KiB"), (500, "~134 KiB")):
+        n2 = min(n_records, 2_000_000)
+        lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n2, rpb2, None, 0, C.byref(ln))
+        buf2 = np.zeros(ln.value + 64, np.uint8)
+        lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n2, rpb2, buf2.ctypes.data, ln.value, C.byref(ln))
+        cap2 = n2 // rpb2 + 2
+        descs2 = (N.KtaKafkaBatchDesc * cap2)()
+        st2 = N.KtaKafkaIndexStats()
+        assert lib.kta_kafka_index_host(buf2.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, 0, descs2, cap2, C.byref(st2)) == 0
+        blob2 = h.device_batch_alloc((ln.value + 3) // 4 + 32)
+        h._check(lib.kta_copy_to_device(h._ctx, blob2.partition, buf2.ctypes.data, (ln.value + 63) // 64 * 64))
+        out2 = h.device_batch_alloc(n2, 16)
+        for _ in range(2):
+            h._check(lib.kta_kafka_decode_device(h._ctx, blob2.partition, ln.value, descs2, st2.n_batches, n2, C.byref(out2), None, None))
+        h.sync()
+        h._check(lib.kta_kafka_time_stats(h._ctx, C.byref(a), C.byref(c)))      # drain
+        h.set_timing(True)
+        for _ in range(5):
+            h._check(lib.kta_kafka_decode_device(h._ctx, blob2.partition, ln.value, descs2, st2.n_batches, n2, C.byref(out2), None, None))
+        h.sync()
+        h._check(lib.kta_kafka_time_stats(h._ctx, C.byref(a), C.byref(c)))
+        h.set_timing(False)
+        rep["by_batch_size"].append({"batch": label, "records_per_batch": rpb2, "batches": int(st2.n_batches), "records": n2,
+                                     "raw_log_bytes": int(ln.value), "kernel_ms": a[1], "launches": int(c[1]),
+                                     "achieved_GBps": ln.value / (a[1] * 1e-3) / 1e9,
+                                     "frac": ln.value / (a[1] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        h.device_batch_free(out2)
+        h.device_batch_free(blob2)
     # compressed record sets: inflate + decode (wall time of the device work, keys zero-copy)
     rep["compressed"] = {}
     nc = min(n_records, 1_000_000)
