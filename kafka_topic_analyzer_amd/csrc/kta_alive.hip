@@ -181,12 +181,18 @@ struct PartKeys {
 __device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uint64_t base, PartCols &r)
 {
 #pragma unroll
+    // Unconditional loads (the index is clamped, the result masked): a load under a lane predicate becomes
+    // a branch, and the compiler then waits with vmcnt(0) wherever the value is used — which would also wait
+    // for every prefetch issued in between.
     for (int j = 0; j < kPartRecs; j++) {
         const uint64_t i = base + (uint64_t)j * kPartThreads + threadIdx.x;
         const bool in = i < n;
-        r.kl[j] = in ? c.key_len[i] : -1;
-        r.vl[j] = in ? c.val_len[i] : -1;
-        r.ko[j] = in ? c.key_off[i] : 0u;
+        const uint64_t ic = in ? i : n - 1;
+        const int32_t kl = c.key_len[ic], vl = c.val_len[ic];
+        const uint32_t ko = c.key_off[ic];
+        r.kl[j] = in ? kl : -1;
+        r.vl[j] = in ? vl : -1;
+        r.ko[j] = in ? ko : 0u;
     }
 }
 
@@ -195,8 +201,8 @@ __device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uin
 __device__ __forceinline__ void load_keys(const AliveColumns &c, const PartCols &r, PartKeys &k)
 {
 #pragma unroll
-    for (int j = 0; j < kPartRecs; j++)
-        if (r.kl[j] > 0) __builtin_memcpy(&k.k16[j], c.key_bytes + r.ko[j], 16);
+    for (int j = 0; j < kPartRecs; j++)      // unconditional as well: a keyless record loads the blob's first 16 bytes
+        __builtin_memcpy(&k.k16[j], c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u), 16);
 }
 
 // FNV of a key whose first 16 bytes are in registers
@@ -264,7 +270,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 {
     constexpr uint32_t B = 1u << BLOG2;
     KTA_PHASE_BEGIN;
-    extern __shared__ unsigned long long s_ring[];                       // B x kRing pairs
+    // 128-byte aligned whatever the static LDS before it adds up to: a ring is one 128-byte row, read back in
+    // 16-byte pieces
+    extern __shared__ __attribute__((aligned(128))) unsigned long long s_ring[];   // B x kRing pairs
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);   // arrivals of this round
     uint32_t *s_fill = s_cnt + B;                                        // pairs accepted into the segment so far
     __shared__ long long s_w[kPartThreads / 64];
@@ -284,18 +292,21 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
     if (nrounds > w) {
         int64_t rd = (int64_t)(w + ((nrounds - 1 - w) / W) * W);
         // Two-stage prefetch: the columns run two rounds ahead of the hash, the key bytes (whose addresses
-        // come from the columns) one round ahead — no load waits for another inside a round.
-        PartCols r, r_next;
-        PartKeys keys, keys_next;
-        load_cols(c, n, (uint64_t)rd * kPartRound, r);
-        load_cols(c, n, rd >= (int64_t)W ? (uint64_t)(rd - W) * kPartRound : n, r_next);
-        load_keys(c, r, keys);
+        // come from the columns) one round ahead — no load waits for another inside a round.  Two register
+        // sets alternate (the loop is unrolled by two): copying "next" into "current" at the end of a round
+        // would make the wave wait for the prefetch at the very place it was issued.
+        PartCols cols_a, cols_b;
+        PartKeys keys_a, keys_b;
+        load_cols(c, n, (uint64_t)rd * kPartRound, cols_a);
+        load_cols(c, n, rd >= (int64_t)W ? (uint64_t)(rd - W) * kPartRound : n, cols_b);
+        load_keys(c, cols_a, keys_a);
         // blocks completed in the previous round, written at the START of the next one (after its hash): the
         // stores then have a whole round to be acknowledged before this wave next waits on its memory counter
         uint32_t pend_b[kPartRecs], pend_from[kPartRecs], pend_to[kPartRecs];
 #pragma unroll
         for (int j = 0; j < kPartRecs; j++) pend_b[j] = pend_from[j] = pend_to[j] = 0u;
-        for (; rd >= 0; rd -= W) {
+        // one round: hash (r, keys), request the other set's keys and this set's columns of two rounds on
+        auto round = [&](PartCols &r, PartKeys &keys, PartCols &r_next, PartKeys &keys_next, int64_t rd) {
             const uint64_t base = (uint64_t)rd * kPartRound;
             uint32_t h[kPartRecs], alive[kPartRecs];
             bool keyed[kPartRecs];
@@ -311,16 +322,14 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             }
             KTA_PHASE(0, 0);   // waiting for the round's loads + hashing
             load_keys(c, r_next, keys_next);                      // their columns were requested a round ago
-            r = r_next;
-            keys = keys_next;
-            load_cols(c, n, rd >= 2 * (int64_t)W ? (uint64_t)(rd - 2 * W) * kPartRound : n, r_next);
+            load_cols(c, n, rd >= 2 * (int64_t)W ? (uint64_t)(rd - 2 * W) * kPartRound : n, r);   // r is spent: hashed
 #ifdef KTA_DBG_NOLDS   /* ablation build of tools/ubench_alive.hip only: stream + hash, nothing else */
             delta += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + alive[0];
 #ifdef KTA_DBG_BARRIERS
             __syncthreads();
             __syncthreads();
 #endif
-            continue;
+            return;
 #endif
             flush_blocks<BLOG2>(s_ring, pairs, W, w, cap, pend_b, pend_from, pend_to);
             __syncthreads();   // the ring entries of the flushed blocks are free again
@@ -382,6 +391,11 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                 __syncthreads();
             }
             KTA_PHASE(0, 6);   // closing the buckets
+        };
+        for (; rd >= 0; rd -= 2 * (int64_t)W) {
+            round(cols_a, keys_a, cols_b, keys_b, rd);
+            if (rd < (int64_t)W) break;
+            round(cols_b, keys_b, cols_a, keys_a, rd - W);
         }
         __syncthreads();
         flush_blocks<BLOG2>(s_ring, pairs, W, w, cap, pend_b, pend_from, pend_to);
@@ -464,6 +478,10 @@ __device__ __forceinline__ void set_merge_unit(uint32_t *s_tag, uint32_t *s_val,
 // region's only writer during this kernel (its own direct-path atomics are complete: barrier), so read /
 // compare / write needs no RMW atomic.  Loads and stores are agent-scope so that they see, and are seen
 // by, the atomics of the direct path and of other kernels.  Leaves the LDS table empty.
+// (Measured alternative, dropped: appending the survivors to a list that a third kernel applies with
+// atomicMax on a second stream, under the next batch's partition kernel — one 8-byte update of a 64-byte
+// block is a memory-side read-modify-write at 28 G/s whichever instruction asks for it, so the hope was to
+// hide it; the concurrent atomics slowed the partition kernel by more than they saved: 1.61 vs 1.43 ms.)
 template <int PBITS, int TLOG2>
 __device__ __forceinline__ long long sweep_table(uint32_t *s_tag, uint32_t *s_val, uint32_t prefix,
                                                  unsigned long long *__restrict__ table, uint64_t seq2)
@@ -513,7 +531,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // instalments: once this many entries are claimed the survivors so far are swept out and the table
     // starts empty again — exact, because the region's entries carry their sequence numbers.
     constexpr uint32_t kFlushAt = T / 2 + T / 16 + T / 32;
-    extern __shared__ uint32_t s_tag[];                    // T tags, T values, then the segment fills
+    // aligned: a set's 8 tags are read as two 16-byte pieces, and the dynamic LDS starts wherever the static
+    // LDS of the kernel ends — a misaligned ds_read_b128 is split by the hardware
+    extern __shared__ __attribute__((aligned(128))) uint32_t s_tag[];   // T tags, T values, then the segment fills
     uint32_t *s_val = s_tag + T;
     uint32_t *s_cnt = s_val + T;
     __shared__ uint32_t s_occ, s_pairs, s_claims;
@@ -550,25 +570,27 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2
     auto issue = [&](uint32_t u, ulonglong2 (&q)[kApplyUnroll], uint32_t (&qv)[kApplyUnroll]) {
         const uint32_t w = (u / chunks) * kApplyWaves + wave, r0 = (u % chunks) * kApplyUnroll;
-        const uint32_t cnt = w < W ? s_cnt[w] : 0u;
-        const unsigned long long *seg = region + (uint64_t)w * cap;
+        const uint32_t cnt = u < units && w < W ? s_cnt[w] : 0u;
+        const unsigned long long *seg = region + (uint64_t)(u < units && w < W ? w : 0u) * cap;
 #pragma unroll
         for (int x = 0; x < kApplyUnroll; x++) {
             const uint32_t k = ((r0 + (uint32_t)x) << 7) + 2u * lane;
             qv[x] = (r0 + (uint32_t)x) < loads && k < cnt ? (cnt - k >= 2u ? 2u : 1u) : 0u;
-            if (qv[x]) q[x] = *reinterpret_cast<const ulonglong2 *>(seg + k);
+            // unconditional (clamped address, masked by qv): a predicated load is a branch, and the wait for this
+            // unit's data would then be vmcnt(0) — it would wait for the NEXT unit's loads as well
+            q[x] = *reinterpret_cast<const ulonglong2 *>(seg + (qv[x] ? k : 2u * lane));
         }
     };
     issue(0, p, nv);
     uint32_t claimed = 0;
-    for (uint32_t u = 0; u < units; u++) {
-        if (u + 1 < units) issue(u + 1, pn, nvn);
+    // merge the unit held in (q, qv)
+    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll]) {
         uint32_t failed = 0;                                  // bit i: pair i of the unit was not merged
 #pragma unroll
         for (int x = 0; x < 2 * kApplyUnroll; x++) {          // one pair after the other (batching them costs registers, gains nothing)
-            const uint32_t hh[1] = {(uint32_t)((x & 1 ? p[x >> 1].y : p[x >> 1].x) >> 32)};
-            const uint32_t ll[1] = {(uint32_t)(x & 1 ? p[x >> 1].y : p[x >> 1].x)};
-            const bool vv[1] = {nv[x >> 1] > (uint32_t)(x & 1)};
+            const uint32_t hh[1] = {(uint32_t)((x & 1 ? q[x >> 1].y : q[x >> 1].x) >> 32)};
+            const uint32_t ll[1] = {(uint32_t)(x & 1 ? q[x >> 1].y : q[x >> 1].x)};
+            const bool vv[1] = {qv[x >> 1] > (uint32_t)(x & 1)};
             int ok[1];
             set_merge_unit<PBITS, TLOG2, 1>(s_tag, s_val, hh, ll, vv, ok);
             claimed += ok[0] == 2 ? 1u : 0u;
@@ -577,21 +599,17 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         if (failed) {   // once per unit: a set was full, or lost a claim to another slot's record — park for the direct path
 #pragma unroll
             for (int x = 0; x < kApplyUnroll; x++) {
-                const uint32_t h0 = (uint32_t)(p[x].x >> 32), l0 = (uint32_t)p[x].x;
-                const uint32_t h1 = (uint32_t)(p[x].y >> 32), l1 = (uint32_t)p[x].y;
+                const uint32_t h0 = (uint32_t)(q[x].x >> 32), l0 = (uint32_t)q[x].x;
+                const uint32_t h1 = (uint32_t)(q[x].y >> 32), l1 = (uint32_t)q[x].y;
                 if ((failed >> (2 * x)) & 1u)
                     if (!spill_push(s_spill, h0, seq2 + l0)) delta += direct_update(table, h0, seq2 + l0);
                 if ((failed >> (2 * x)) & 2u)
                     if (!spill_push(s_spill, h1, seq2 + l1)) delta += direct_update(table, h1, seq2 + l1);
             }
         }
-#pragma unroll
-        for (int x = 0; x < kApplyUnroll; x++) {
-            p[x] = pn[x];
-            nv[x] = nvn[x];
-        }
-        if ((u & 3u) != 3u && u + 1 < units) continue;
-        // every fourth unit: does the table need sweeping out, or the parked records draining?
+    };
+    // every fourth unit: does the table need sweeping out, or the parked records draining?
+    auto checkpoint = [&](uint32_t u) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
         if (lane == 0 && claimed) atomicAdd(&s_occ, claimed);
@@ -612,6 +630,18 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             }
             __syncthreads();
         }
+    };
+    // Two units per trip, the buffers alternating: copying the prefetched registers into the current ones at the
+    // end of an iteration would make the compiler wait for the prefetch right where it was issued.
+    // The prefetch is issued unconditionally (a unit past the end loads a clamped address and merges nothing):
+    // under a branch the compiler could not count it and would wait with vmcnt(0).
+    for (uint32_t u = 0; u < units; u += 2) {
+        issue(u + 1, pn, nvn);
+        merge(p, nv);
+        if ((u & 3u) == 3u || u + 1 >= units) checkpoint(u);
+        issue(u + 2, p, nv);
+        merge(pn, nvn);
+        if (((u + 1) & 3u) == 3u || u + 2 == units) checkpoint(u + 1);
     }
     delta += spill_drain(s_spill, table);
     __syncthreads();

@@ -26,9 +26,15 @@ def pmc(dbs):
         cur = sqlite3.connect(db).cursor()
         print(f"# rocprofv3 --pmc  ({db})")
         print(f"{'kernel':<100} {'counter':<12} {'n':>4} {'avg':>16} {'min':>16} {'max':>16}")
-        for r in cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
-                             "from counters_collection group by kernel_name, counter_name"):
-            print(f"{r[0][:100]:<100} {r[1]:<12} {r[2]:>4} {r[3]:>16.1f} {r[4]:>16.1f} {r[5]:>16.1f}")
+        try:     # one row per kernel AND launch size: a kernel's launches of different sizes must not be averaged
+            q = cur.execute("select kernel_name || ' grid=' || grid_size, counter_name, count(*), avg(value), min(value), "
+                            "max(value) from counters_collection group by kernel_name, grid_size, counter_name").fetchall()
+        except sqlite3.OperationalError:
+            q = cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
+                            "from counters_collection group by kernel_name, counter_name").fetchall()
+        for r in q:
+            name = r[0] if len(r[0]) <= 100 else r[0][:70] + " .. " + r[0][-26:]
+            print(f"{name:<100} {r[1]:<22} {r[2]:>4} {r[3]:>16.1f} {r[4]:>16.1f} {r[5]:>16.1f}")
 
 
 if __name__ == "__main__":

@@ -2,7 +2,9 @@
 // 16-byte keys, with the per-phase tick counters compiled in.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I kafka_topic_analyzer_amd/csrc tools/ubench_alive.hip -o /tmp/uba
 //   /tmp/uba [log2 n = 26] [distinct keys = 10000000] [bucket_log2 = 10] [segment workgroups = 0]
+#ifndef KTA_NO_PHASES
 #define KTA_ALIVE_PHASES 1
+#endif
 #include "../kafka_topic_analyzer_amd/csrc/kta_alive.hip"
 
 #include <stdio.h>
@@ -56,7 +58,9 @@ int main(int argc, char **argv)
     hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 4; rep++) {
         unsigned long long zero[16] = {0};
+#ifdef KTA_ALIVE_PHASES
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kta_phase), zero, sizeof zero));
+#endif
         CK(hipDeviceSynchronize());
         hipEventRecord(a);
         CK(kta::launch_alive_partitioned(c, n, (uint64_t)rep * n, table, running, pl, pairs, counts, nullptr, 0));
@@ -64,8 +68,10 @@ int main(int argc, char **argv)
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        unsigned long long ph[16];
+        unsigned long long ph[16] = {0};
+#ifdef KTA_ALIVE_PHASES
         CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_kta_phase), sizeof ph));
+#endif
         long long alive;
         CK(hipMemcpy(&alive, running, 8, hipMemcpyDeviceToHost));
         const double w1 = pl.segment_wgs, w2 = (double)(1u << pl.bucket_log2);
