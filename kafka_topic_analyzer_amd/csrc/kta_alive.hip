@@ -205,10 +205,17 @@ __device__ __forceinline__ void load_keys(const AliveColumns &c, const PartCols 
         __builtin_memcpy(&k.k16[j], c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u), 16);
 }
 
+#ifdef KTA_HASH_NOINLINE   /* experiment of tools/ubench_alive.hip: the general-length path out of line (code size) */
+__device__ __attribute__((noinline)) uint32_t fnv32_more_ool(uint32_t h, const uint8_t *k, uint32_t len) { return fnv32_more(h, k, len); }
+#else
+__device__ __forceinline__ uint32_t fnv32_more_ool(uint32_t h, const uint8_t *k, uint32_t len) { return fnv32_more(h, k, len); }
+#endif
+
 // FNV of a key whose first 16 bytes are in registers
 __device__ __forceinline__ uint32_t fnv32_prefetched(const uint4 &k16, const uint8_t *key, uint32_t len)
 {
-    if (len >= 16u) return fnv32_more(fnv_16(kFnvInit, k16), key + 16, len - 16u);
+    if (len == 16u) return fnv_16(kFnvInit, k16);
+    if (len > 16u) return fnv32_more_ool(fnv_16(kFnvInit, k16), key + 16, len - 16u);
     const uint32_t w[4] = {k16.x, k16.y, k16.z, k16.w};
     uint32_t h = kFnvInit;
 #pragma unroll
