@@ -485,10 +485,15 @@ __device__ __forceinline__ void set_merge_unit(uint32_t *s_tag, uint32_t *s_val,
 // region's only writer during this kernel (its own direct-path atomics are complete: barrier), so read /
 // compare / write needs no RMW atomic.  Loads and stores are agent-scope so that they see, and are seen
 // by, the atomics of the direct path and of other kernels.  Leaves the LDS table empty.
-// (Measured alternative, dropped: appending the survivors to a list that a third kernel applies with
-// atomicMax on a second stream, under the next batch's partition kernel — one 8-byte update of a 64-byte
-// block is a memory-side read-modify-write at 28 G/s whichever instruction asks for it, so the hope was to
-// hide it; the concurrent atomics slowed the partition kernel by more than they saved: 1.61 vs 1.43 ms.)
+// One 8-byte update of a 64-byte block is a memory-side read-modify-write at 28 G/s whichever instruction
+// asks for it (tools/ubench_scatter.hip), and that rate is what this sweep runs at (8.8 k updates per bucket
+// in 87 us).  Two ways around it were built, measured on the config-3 shape and dropped: (1) appending the
+// survivors to a list that a third kernel applies with atomicMax on a second stream, under the next batch's
+// partition kernel — the concurrent atomics slowed that kernel by more than they saved (1.61 vs 1.43 ms per
+// batch); (2) whole-line updates — the sets are chosen by table line, so the first survivor of a line in
+// its set can read the 64-byte line, apply the line's survivors and write it back whole (no partial
+// write) — 140 us per bucket instead of 87: random 64-byte read + write pairs through L2 cost more than the
+// partial writes they replace.
 template <int PBITS, int TLOG2>
 __device__ __forceinline__ long long sweep_table(uint32_t *s_tag, uint32_t *s_val, uint32_t prefix,
                                                  unsigned long long *__restrict__ table, uint64_t seq2)
