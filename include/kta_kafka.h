@@ -73,7 +73,7 @@ typedef struct kta_kafka_batch_desc {
     int32_t partition;
     int32_t n_records;
     uint32_t flags;
-    uint64_t scratch_end; /* zstd: [payload_end, scratch_end) is the decoder's scratch in the inflate area */
+    uint64_t scratch_end; /* gzip, zstd: [payload_end, scratch_end) is the decoder's scratch in the inflate area */
 } kta_kafka_batch_desc;
 
 typedef struct kta_kafka_index_stats {
@@ -109,8 +109,11 @@ int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, ui
 int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 /* zstd (one or more frames) inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
 int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
-/* gzip (one member) inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
+/* gzip (one member) inflate on the host: the code the device runs, stage by stage (Huffman decoding into
+ * literals + match tokens, then the copies).  Returns the bytes produced or -1. */
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
+/* The single-pass form (the device's one-lane-per-batch kernel, kta_kafka_set_variant 1). */
+int64_t kta_gzip_inflate_lane_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 
 /* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
  * readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).

@@ -149,6 +149,7 @@ SIGNATURES = {
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
     "kta_zstd_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_gzip_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
+    "kta_gzip_inflate_lane_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_lz4_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_snappy_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,

@@ -52,14 +52,80 @@ struct GzBits {
     bool overrun;        // consumed bits that were not there
 };
 
+// The two-stage tokenizer on the device reads the stream through a per-lane LDS window (GZ_WIN bytes, word k
+// of this lane at win[k * wstride]): a refill is then an LDS read, and the memory round trips are paid once
+// per window by all lanes of a wave together (gz_topup_all) instead of once per word — and the loop that
+// stores literals holds no memory loads whose arrival it would have to wait for.
+constexpr uint32_t GZ_WIN = 128;
+
+struct GzBitsWin : GzBits {
+    uint32_t *win;
+    uint32_t wstride;
+    uint64_t wbase;      // stream offset of the window's first byte; ~0: nothing loaded
+};
+
+KTA_GZIP_HD void gz_reset_window(GzBits &) {}
+KTA_GZIP_HD void gz_reset_window(GzBitsWin &b) { b.wbase = ~0ull; }
+
+// continue reading at byte `pos` of the stream (also the initial state)
+template <class Bits>
+KTA_GZIP_HD void gz_seek(Bits &b, uint64_t pos)
+{
+    b.pos = pos;
+    b.hold = 0;
+    b.bits = 0;
+    gz_reset_window(b);
+}
+
+// the window starts at the current position: words [pos, pos + GZ_WIN) of the stream, clamped to its last word
+KTA_GZIP_HD void gz_topup(GzBitsWin &b)
+{
+    if (b.n < 4) return;
+    uint32_t w[GZ_WIN / 4];
+#pragma unroll
+    for (uint32_t k = 0; k < GZ_WIN / 4; k++) {
+        const uint64_t at = b.pos + 4 * k;
+        __builtin_memcpy(&w[k], b.p + (at + 4 <= b.n ? at : b.n - 4), 4);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < GZ_WIN / 4; k++) b.win[k * b.wstride] = w[k];
+    b.wbase = b.pos;
+}
+
+// the four bytes at pos (pos + 4 <= n)
+KTA_GZIP_HD uint32_t gz_word(GzBits &b)
+{
+    uint32_t w;
+    __builtin_memcpy(&w, b.p + b.pos, 4);
+    return w;
+}
+
+KTA_GZIP_HD uint32_t gz_word(GzBitsWin &b)
+{
+    if (b.wbase == ~0ull || b.pos < b.wbase || b.pos - b.wbase >= GZ_WIN || ((b.pos - b.wbase) & 3u)) gz_topup(b);
+    return b.win[((b.pos - b.wbase) >> 2) * b.wstride];
+}
+
+// Device: when the window of any lane of the wave runs low (in the literal loop), all of them take a fresh
+// one — one memory round trip for the wave instead of one per lane at its own moment.
+KTA_GZIP_HD void gz_topup_all(GzBits &) {}
+KTA_GZIP_HD void gz_topup_all(GzBitsWin &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool low = b.pos + 4 <= b.n && (b.wbase == ~0ull || b.pos - b.wbase + 16 > GZ_WIN);
+    if (__builtin_amdgcn_ballot_w64(low)) gz_topup(b);
+#else
+    (void)b;
+#endif
+}
+
 // at least 32 valid bits in hold (zeros past the end of the input)
-KTA_GZIP_HD void gz_refill(GzBits &b)
+template <class Bits>
+KTA_GZIP_HD void gz_refill(Bits &b)
 {
     if (b.bits >= 32) return;
     if (b.pos + 4 <= b.n) {
-        uint32_t w;
-        __builtin_memcpy(&w, b.p + b.pos, 4);
-        b.hold |= (uint64_t)w << b.bits;
+        b.hold |= (uint64_t)gz_word(b) << b.bits;
         b.pos += 4;
         b.bits += 32;
         return;
@@ -79,7 +145,8 @@ KTA_GZIP_HD void gz_drop(GzBits &b, uint32_t k)
     if (b.pos > b.n && b.bits < 8 * (uint32_t)(b.pos - b.n)) b.overrun = true;
 }
 
-KTA_GZIP_HD uint32_t gz_get(GzBits &b, uint32_t k)   // k <= 16
+template <class Bits>
+KTA_GZIP_HD uint32_t gz_get(Bits &b, uint32_t k)   // k <= 16
 {
     gz_refill(b);
     const uint32_t v = (uint32_t)b.hold & ((1u << k) - 1u);
@@ -137,7 +204,8 @@ KTA_GZIP_HD int gz_build(GzCode &c, uint16_t *work, uint32_t stride, uint32_t le
 }
 
 // One symbol; -1 if the bits are no code of `c`.
-KTA_GZIP_HD int gz_decode(GzBits &b, const GzCode &c, const uint16_t *work, uint32_t stride, uint32_t syms)
+template <class Bits>
+KTA_GZIP_HD int gz_decode(Bits &b, const GzCode &c, const uint16_t *work, uint32_t stride, uint32_t syms)
 {
     gz_refill(b);
     const uint32_t rev = gz_rev15((uint32_t)b.hold & 0x7FFFu);
@@ -204,7 +272,8 @@ KTA_GZIP_HD void gz_copy_match(uint8_t *dst, uint64_t op, uint32_t dist, uint32_
 }
 
 // The symbols of one compressed block.  Returns false on malformed input.
-KTA_GZIP_HD bool gz_codes(GzBits &b, const GzCode &lencode, const GzCode &distcode, const uint16_t *work, uint32_t stride,
+template <class Bits>
+KTA_GZIP_HD bool gz_codes(Bits &b, const GzCode &lencode, const GzCode &distcode, const uint16_t *work, uint32_t stride,
                           uint8_t *dst, uint64_t &op, uint64_t cap)
 {
     while (true) {
@@ -244,7 +313,11 @@ KTA_GZIP_HD int64_t gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
 {
     const uint64_t start = gzip_header(src, n);
     if (!start) return -1;
-    GzBits b{src + start, n - 8 - start, 0, 0, 0, false};   // the trailer is not part of the DEFLATE stream
+    GzBits b;
+    b.p = src + start;
+    b.n = n - 8 - start;                                   // the trailer is not part of the DEFLATE stream
+    b.overrun = false;
+    gz_seek(b, 0);
     GzCode lencode, distcode;
     uint64_t op = 0;
     uint32_t last;
@@ -254,15 +327,13 @@ KTA_GZIP_HD int64_t gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
         if (b.overrun) return -1;
         if (type == 0) {                              // stored: byte aligned LEN, ~LEN, bytes
             const uint64_t at = b.pos - b.bits / 8;   // whole bytes still in `hold` are handed back
-            b.hold = 0;
-            b.bits = 0;
             if (at + 4 > b.n) return -1;
             const uint32_t len = (uint32_t)b.p[at] | ((uint32_t)b.p[at + 1] << 8);
             const uint32_t nlen = (uint32_t)b.p[at + 2] | ((uint32_t)b.p[at + 3] << 8);
             if ((len ^ 0xFFFFu) != nlen || at + 4 + len > b.n || op + len > cap) return -1;
             for (uint32_t k = 0; k < len; k++) dst[op + k] = b.p[at + 4 + k];
             op += len;
-            b.pos = at + 4 + len;
+            gz_seek(b, at + 4 + len);
         } else if (type == 1) {                       // fixed codes (RFC 1951 3.2.6)
             for (uint32_t s = 0; s < 288; s++)
                 work[(GZ_W_LENS + s) * stride] = (uint16_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
@@ -324,6 +395,267 @@ KTA_GZIP_HD int64_t gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
     const uint64_t isize = (uint64_t)src[n - 4] | ((uint64_t)src[n - 3] << 8) | ((uint64_t)src[n - 2] << 16) | ((uint64_t)src[n - 1] << 24);
     if (b.overrun || used != b.n || (op & 0xFFFFFFFFull) != isize) return -1;
     return (int64_t)op;
+}
+
+// ---- two-stage inflate ------------------------------------------------------------------------------------
+// The device splits DEFLATE where its two kinds of work separate:
+//   stage 1, gzip_tokenize   the bit-serial part, one lane per batch: Huffman decoding.  Literals are stored at
+//                            their final positions of dst; a match is not executed but recorded as a token.
+//   stage 2                  the copies: one wave per batch executes the tokens 64 bytes per step from an LDS
+//                            mirror of the output (kafka_gzip_apply in kta_kafka.hip; gz_apply_tokens below is
+//                            the same thing sequentially, for the host tests).
+// Token (u32):  literals before the match (0..254, 255 = "255 literals and no match yet") | match length
+// (0 = none, else 3..258) << 8 | (distance - 1) << 17.  Every match produces >= 3 bytes and every escape token
+// stands for 255 literals, so a member of `out` bytes needs at most out/3 + out/255 + 1 tokens
+// (gz_token_bound); the literals after the last match need no token.
+//
+// Symbols are decoded through primary lookup tables indexed with the next GZ_LBITS / GZ_DBITS stream bits
+// (entry: symbol << 4 | code length; 0 = the code is longer than the index, or no code at all: the
+// canonical search of gz_decode takes over).  Work area (u16 words, strided like GZ_WORK): the counts of the
+// code being built | literal/length symbols | distance symbols | literal/length table | distance table.  The
+// code lengths of a block live in the literal/length table's words until its codes are built (the distance
+// code first, then the literal/length code, whose table fill is the last reader of nothing).
+constexpr uint32_t GZ_LBITS = 9, GZ_DBITS = 7;
+constexpr uint32_t GZ2_W_LSYM = 16;      // 288
+constexpr uint32_t GZ2_W_DSYM = 304;     // 32
+constexpr uint32_t GZ2_W_LTAB = 336;     // 512 (code lengths: the first 320)
+constexpr uint32_t GZ2_W_DTAB = 848;     // 128
+constexpr uint32_t GZ2_WORK = 976;
+
+KTA_GZIP_HD uint64_t gz_token_bound(uint64_t out) { return out / 3 + out / 255 + 1; }
+
+struct GzTokens {
+    uint32_t *tok;
+    uint64_t n, cap;
+    uint64_t run;        // literals since the last token
+    bool full;
+};
+
+KTA_GZIP_HD void gz_emit(GzTokens &t, uint32_t len, uint32_t dist)
+{
+    while (t.run >= 255u) {
+        if (t.n >= t.cap) { t.full = true; return; }
+        t.tok[t.n++] = 255u;
+        t.run -= 255u;
+    }
+    if (t.n >= t.cap) { t.full = true; return; }
+    t.tok[t.n++] = (uint32_t)t.run | (len << 8) | ((dist - 1u) << 17);
+    t.run = 0;
+}
+
+// Fills the primary table of the code gz_build just built (its symbols at work[syms..], the per-length end
+// offsets into them still in the count words): entries of `pbits` index bits at work[tab..].
+KTA_GZIP_HD void gz_fill(uint16_t *work, uint32_t stride, uint32_t syms, uint32_t tab, uint32_t pbits)
+{
+    const uint32_t size = 1u << pbits;
+    for (uint32_t i = 0; i < size; i++) work[(tab + i) * stride] = 0;
+    uint32_t first = 0, idx = 0;
+    for (uint32_t l = 1; l <= pbits; l++) {
+        const uint32_t end = work[(GZ_W_COUNT + l) * stride];        // symbols of lengths 1..l
+        for (; idx < end; idx++, first++) {
+            const uint32_t entry = ((uint32_t)work[(syms + idx) * stride] << 4) | l;
+            // the stream carries a code starting from its most significant bit: index = the code, bit-reversed
+#if defined(__clang__)
+            const uint32_t r = __builtin_bitreverse32(first) >> (32 - l);
+#else
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < l; k++) r |= ((first >> k) & 1u) << (l - 1 - k);
+#endif
+            for (uint32_t j = r; j < size; j += 1u << l) work[(tab + j) * stride] = (uint16_t)entry;
+        }
+        first <<= 1;
+    }
+}
+
+template <class Bits>
+KTA_GZIP_HD int gz_decode_fast(Bits &b, const GzCode &c, const uint16_t *work, uint32_t stride, uint32_t tab, uint32_t pbits,
+                               uint32_t syms)
+{
+    gz_refill(b);
+    const uint32_t e = work[(tab + ((uint32_t)b.hold & ((1u << pbits) - 1u))) * stride];
+    const uint32_t l = e & 15u;
+    if (l) {
+        gz_drop(b, l);
+        return (int)(e >> 4);
+    }
+    return gz_decode(b, c, work, stride, syms);
+}
+
+// The symbols of one compressed block, tokenized.  Returns false on malformed input (or a full token area).
+template <class Bits>
+KTA_GZIP_HD bool gz_codes_tok(Bits &b, const GzCode &lencode, const GzCode &distcode, const uint16_t *work, uint32_t stride,
+                              uint8_t *dst, uint64_t &op, uint64_t cap, GzTokens &t)
+{
+    while (true) {
+        // Literals, the bulk of a member, in a loop with one exit: it runs while the stream has whole words
+        // left (so nothing can be over-read), the table resolves the code, the symbol is a literal and the
+        // output has room; whatever ends it is decoded once by the general step below.
+        while (true) {
+            gz_topup_all(b);
+            if (b.bits < 32) {
+                if (b.pos + 4 > b.n) break;
+                b.hold |= (uint64_t)gz_word(b) << b.bits;
+                b.pos += 4;
+                b.bits += 32;
+            }
+            const uint32_t e = work[(GZ2_W_LTAB + ((uint32_t)b.hold & ((1u << GZ_LBITS) - 1u))) * stride];
+            const uint32_t l = e & 15u;
+            if (l == 0 || e >= (256u << 4) || op >= cap) break;
+            b.hold >>= l;
+            b.bits -= l;
+            dst[op++] = (uint8_t)(e >> 4);
+            t.run++;
+        }
+        const int sym = gz_decode_fast(b, lencode, work, stride, GZ2_W_LTAB, GZ_LBITS, GZ2_W_LSYM);
+        if (sym < 0 || b.overrun) return false;
+        if (sym < 256) {
+            if (op >= cap) return false;
+            dst[op++] = (uint8_t)sym;
+            t.run++;
+            continue;
+        }
+        if (sym == 256) return true;                  // end of block
+        if (sym > 285) return false;
+        uint32_t len;
+        if (sym < 265) len = 3u + (uint32_t)(sym - 257);
+        else if (sym == 285) len = 258u;
+        else {
+            const uint32_t k = (uint32_t)sym - 261u, e = k >> 2;               // 265..284: 1..5 extra bits
+            len = 3u + ((4u + (k & 3u)) << e) + gz_get(b, e);
+        }
+        const int ds = gz_decode_fast(b, distcode, work, stride, GZ2_W_DTAB, GZ_DBITS, GZ2_W_DSYM);
+        if (ds < 0 || ds > 29) return false;
+        uint32_t dist;
+        if (ds < 4) dist = 1u + (uint32_t)ds;
+        else {
+            const uint32_t e = ((uint32_t)ds >> 1) - 1u;                       // 1..13 extra bits
+            dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + gz_get(b, e);
+        }
+        if (b.overrun || dist > op || op + len > cap) return false;
+        gz_emit(t, len, dist);
+        if (t.full) return false;
+        op += len;
+    }
+}
+
+// Stage 1 of one gzip member: literals into dst[0 .. cap), matches into tok[0 .. tok_cap) (*n_tok of them).
+// `work`: GZ2_WORK u16 words with `stride`; `b`: a bit reader (GzBits: straight from memory; GzBitsWin with its
+// window fields set: through the window).  Returns the bytes the member produces or -1.
+template <class Bits>
+KTA_GZIP_HD int64_t gzip_tokenize(Bits &b, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, uint32_t *tok,
+                                  uint64_t tok_cap, uint64_t *n_tok, uint16_t *work, uint32_t stride)
+{
+    const uint64_t start = gzip_header(src, n);
+    if (!start) return -1;
+    b.p = src + start;
+    b.n = n - 8 - start;
+    b.overrun = false;
+    gz_seek(b, 0);
+    GzCode lencode, distcode;
+    GzTokens t{tok, 0, tok_cap, 0, false};
+    uint64_t op = 0;
+    uint32_t last;
+    do {
+        last = gz_get(b, 1);
+        const uint32_t type = gz_get(b, 2);
+        if (b.overrun) return -1;
+        if (type == 0) {                              // stored: its bytes are literals
+            const uint64_t at = b.pos - b.bits / 8;
+            if (at + 4 > b.n) return -1;
+            const uint32_t len = (uint32_t)b.p[at] | ((uint32_t)b.p[at + 1] << 8);
+            const uint32_t nlen = (uint32_t)b.p[at + 2] | ((uint32_t)b.p[at + 3] << 8);
+            if ((len ^ 0xFFFFu) != nlen || at + 4 + len > b.n || op + len > cap) return -1;
+            uint32_t k = 0;
+            for (; k + 8 <= len; k += 8) {
+                uint64_t w;
+                __builtin_memcpy(&w, b.p + at + 4 + k, 8);
+                __builtin_memcpy(dst + op + k, &w, 8);
+            }
+            for (; k < len; k++) dst[op + k] = b.p[at + 4 + k];
+            op += len;
+            t.run += len;
+            gz_seek(b, at + 4 + len);
+            continue;
+        }
+        if (type == 3) return -1;
+        if (type == 1) {                              // fixed codes (RFC 1951 3.2.6)
+            for (uint32_t s = 0; s < 288; s++)
+                work[(GZ2_W_LTAB + s) * stride] = (uint16_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
+            for (uint32_t s = 0; s < 30; s++) work[(GZ2_W_LTAB + 288 + s) * stride] = 5;
+            (void)gz_build(distcode, work, stride, GZ2_W_LTAB + 288, GZ2_W_DSYM, 30);
+            gz_fill(work, stride, GZ2_W_DSYM, GZ2_W_DTAB, GZ_DBITS);
+            (void)gz_build(lencode, work, stride, GZ2_W_LTAB, GZ2_W_LSYM, 288);
+            gz_fill(work, stride, GZ2_W_LSYM, GZ2_W_LTAB, GZ_LBITS);
+        } else {                                      // dynamic codes (3.2.7)
+            const uint32_t nlen = gz_get(b, 5) + 257, ndist = gz_get(b, 5) + 1, ncode = gz_get(b, 4) + 4;
+            if (nlen > 286 || ndist > 30) return -1;
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            for (uint32_t i = 0; i < 19; i++)
+                work[(GZ2_W_LTAB + order[i]) * stride] = (uint16_t)(i < ncode ? gz_get(b, 3) : 0);
+            GzCode &clcode = distcode;                // the code-length code (19 symbols) borrows the storage
+            if (gz_build(clcode, work, stride, GZ2_W_LTAB, GZ2_W_DSYM, 19) != 0) return -1;
+            uint32_t i = 0;
+            while (i < nlen + ndist) {
+                const int sym = gz_decode(b, clcode, work, stride, GZ2_W_DSYM);
+                if (sym < 0 || b.overrun) return -1;
+                if (sym < 16) {
+                    work[(GZ2_W_LTAB + i++) * stride] = (uint16_t)sym;
+                    continue;
+                }
+                uint32_t prev = 0, rep;
+                if (sym == 16) {
+                    if (i == 0) return -1;
+                    prev = work[(GZ2_W_LTAB + i - 1) * stride];
+                    rep = 3 + gz_get(b, 2);
+                } else if (sym == 17) rep = 3 + gz_get(b, 3);
+                else rep = 11 + gz_get(b, 7);
+                if (i + rep > nlen + ndist) return -1;
+                while (rep--) work[(GZ2_W_LTAB + i++) * stride] = (uint16_t)prev;
+            }
+            if (work[(GZ2_W_LTAB + 256) * stride] == 0) return -1;     // no end-of-block code
+            // an incomplete code is legal only as a single 1-bit code
+            uint32_t zeros = 0, ones = 0;
+            for (uint32_t s = 0; s < ndist; s++) {
+                const uint32_t l = work[(GZ2_W_LTAB + nlen + s) * stride];
+                zeros += l == 0;
+                ones += l == 1;
+            }
+            int left = gz_build(distcode, work, stride, GZ2_W_LTAB + nlen, GZ2_W_DSYM, (int)ndist);
+            if (left < 0 || (left > 0 && zeros + ones != ndist)) return -1;
+            gz_fill(work, stride, GZ2_W_DSYM, GZ2_W_DTAB, GZ_DBITS);
+            zeros = ones = 0;
+            for (uint32_t s = 0; s < nlen; s++) {
+                const uint32_t l = work[(GZ2_W_LTAB + s) * stride];
+                zeros += l == 0;
+                ones += l == 1;
+            }
+            left = gz_build(lencode, work, stride, GZ2_W_LTAB, GZ2_W_LSYM, (int)nlen);
+            if (left < 0 || (left > 0 && zeros + ones != nlen)) return -1;
+            gz_fill(work, stride, GZ2_W_LSYM, GZ2_W_LTAB, GZ_LBITS);
+        }
+        if (!gz_codes_tok(b, lencode, distcode, work, stride, dst, op, cap, t)) return -1;
+    } while (!last);
+    const uint64_t used = b.pos - b.bits / 8;
+    const uint64_t isize = (uint64_t)src[n - 4] | ((uint64_t)src[n - 3] << 8) | ((uint64_t)src[n - 2] << 16) | ((uint64_t)src[n - 1] << 24);
+    if (b.overrun || used != b.n || (op & 0xFFFFFFFFull) != isize) return -1;
+    *n_tok = t.n;
+    return (int64_t)op;
+}
+
+// Stage 2, sequentially (host tests; the device runs kafka_gzip_apply): executes the tokens over dst[0 .. total).
+// Returns false if a token points outside the output (cannot happen for tokens gzip_tokenize accepted).
+KTA_GZIP_HD bool gz_apply_tokens(uint8_t *dst, uint64_t total, const uint32_t *tok, uint64_t n_tok)
+{
+    uint64_t op = 0;
+    for (uint64_t i = 0; i < n_tok; i++) {
+        const uint32_t tk = tok[i], len = (tk >> 8) & 511u, dist = (tk >> 17) + 1u;
+        op += tk & 255u;
+        if (!len) continue;
+        if (dist > op || op + len > total) return false;
+        for (uint32_t k = 0; k < len; k++) dst[op + k] = dst[op - dist + k];
+        op += len;
+    }
+    return op <= total;
 }
 
 }  // namespace kta

@@ -445,6 +445,142 @@ __global__ __launch_bounds__(L) void kafka_gzip_inflate(uint8_t *buffer, kta_kaf
     if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;   // the trailer told the size
 }
 
+// ---- gzip inflate in two stages (csrc/kta_gzip.h) -----------------------------------------------------
+// Stage 1, kafka_gzip_tokenize: Huffman decoding is bit-serial inside a member, so one LANE per batch, L
+// batches per workgroup; the lookup tables of a lane (1.9 KiB) are in LDS, lane-interleaved.  Literals go
+// straight to their final bytes of the batch's slice, matches become tokens in the batch's scratch (the
+// host index placed it behind the slice: [u32 count, u32 0, tokens]).  Few lanes per wave on purpose: the
+// lanes of a wave sit in different branches (literal / match / table build) most of the time, so a wave
+// costs the sum of its lanes' paths, and the LDS tables bound the batches in flight per CU either way.
+// Stage 2, kafka_gzip_apply: one WAVE per batch executes the tokens.  The output is processed in 4 KiB
+// chunks through an LDS ring of the last 16 KiB: a chunk is loaded with its literals in place, the matches
+// that start in it are copied 64 bytes per step inside LDS (a dependent step costs LDS latency, not a
+// memory round trip), and the chunk is written back in whole 16-byte units.  A match that reaches further
+// back than the ring reads the written-back output (behind a fence, past L1).
+constexpr uint32_t kGzTokLanes = 8;
+constexpr uint32_t kLzRing = 16384, kLzChunk = 4096;
+
+template <uint32_t L>
+__global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    __shared__ uint16_t s_work[kta::GZ2_WORK * L];
+    __shared__ uint32_t s_win[kta::GZ_WIN / 4 * L];            // the lanes' windows on their streams
+    const uint64_t b = (uint64_t)blockIdx.x * L + threadIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_GZIP) || d.status) return;
+    const uint8_t *src = buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    const uint64_t n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER, cap = d.payload_end - d.payload_off;
+    const uint64_t scratch = (d.payload_end + 63) & ~63ull;
+    const bool has_tokens = d.scratch_end >= scratch + 16;          // (an empty member has none and needs none)
+    if (cap && !has_tokens) { descs[b].status = KTA_KB_BAD_FRAMING; return; }
+    uint32_t *tok = reinterpret_cast<uint32_t *>(buffer + scratch);
+    uint64_t n_tok = 0;
+    kta::GzBitsWin bits;
+    bits.win = s_win + threadIdx.x;
+    bits.wstride = L;
+    const int64_t got = kta::gzip_tokenize(bits, src, n, buffer + d.payload_off, cap, tok + 2,
+                                           has_tokens ? (d.scratch_end - scratch - 8) / 4 : 0, &n_tok, s_work + threadIdx.x, L);
+    if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;   // the trailer told the size
+    else if (has_tokens) tok[0] = (uint32_t)n_tok;
+}
+
+// The last kLzRing bytes of one batch's output, mirrored in LDS and moved in chunks (one wave; see above).
+struct LzWindow {
+    uint4 *ring4;          // LDS, kLzRing bytes
+    uint8_t *dst;          // the batch's slice (64-byte aligned)
+    uint64_t total;        // bytes of output
+    uint64_t c0;           // the chunk [c0, c0 + kLzChunk) is in the ring and not yet written back
+    uint32_t lane;
+
+    __device__ uint8_t *ring() const { return reinterpret_cast<uint8_t *>(ring4); }
+    __device__ void load(uint64_t at)           // chunk `at` (literals in place) -> ring
+    {
+        c0 = at;
+        const uint64_t last = ((total + 15) & ~15ull) - 16;      // last 16-byte unit of the slice (total > 0)
+        uint4 v[kLzChunk / 1024];
+#pragma unroll
+        for (uint32_t k = 0; k < kLzChunk / 1024; k++) {
+            const uint64_t off = at + (uint64_t)(k * 64 + lane) * 16;
+            v[k] = *reinterpret_cast<const uint4 *>(dst + (off < last ? off : last));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kLzChunk / 1024; k++)
+            ring4[((at + (uint64_t)(k * 64 + lane) * 16) & (kLzRing - 1)) >> 4] = v[k];
+        __syncthreads();
+    }
+    __device__ void advance()                   // write the chunk back, take the next one
+    {
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kLzChunk / 1024; k++) {
+            const uint64_t off = c0 + (uint64_t)(k * 64 + lane) * 16;
+            if (off < total) *reinterpret_cast<uint4 *>(dst + off) = ring4[(off & (kLzRing - 1)) >> 4];
+        }
+        if (c0 + kLzChunk < total) load(c0 + kLzChunk);
+        else c0 += kLzChunk;
+    }
+    // out[op .. op + len) = out[op - dist ..), op inside or after the current chunk; dist <= op, op + len <= total
+    __device__ void match(uint64_t op, uint64_t dist, uint64_t len)
+    {
+        while (len) {
+            while (op >= c0 + kLzChunk) advance();
+            uint64_t n = c0 + kLzChunk - op;
+            n = n < len ? n : len;
+            n = n < 64 ? n : 64;
+            // byte i of the step: source index repeats with period `dist` when the copy overlaps itself
+            const uint64_t s = op - dist + (dist >= 64 ? lane : lane % (uint32_t)dist);
+            uint8_t v = 0;
+            if (op - dist + kLzRing >= c0 + kLzChunk) {            // the whole step's source is in the ring
+                if (lane < n) v = ring()[s & (kLzRing - 1)];
+            } else {                                               // further back: written back already (kLzRing >= chunk + 64)
+                __threadfence();
+                if (lane < n) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < n) ring()[(op + lane) & (kLzRing - 1)] = v;
+            op += n;
+            len -= n;
+        }
+    }
+    __device__ void finish()                    // everything up to `total` written back
+    {
+        while (c0 < total) advance();
+    }
+};
+
+__global__ __launch_bounds__(64) void kafka_gzip_apply(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    __shared__ uint4 s_ring[kLzRing / 16];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_GZIP) || d.status || d.payload_end == d.payload_off) return;
+    const uint64_t total = d.payload_end - d.payload_off;
+    const uint32_t *tok = reinterpret_cast<const uint32_t *>(buffer + ((d.payload_end + 63) & ~63ull));
+    const uint32_t n_tok = tok[0];
+    if (n_tok == 0) return;                                    // literals only: stage 1 wrote everything
+    LzWindow w{s_ring, buffer + d.payload_off, total, 0, lane};
+    w.load(0);
+    uint64_t op = 0;
+    bool bad = false;
+    for (uint32_t t0 = 0; t0 < n_tok && !bad; t0 += 64) {
+        const uint32_t mine = t0 + lane < n_tok ? tok[2 + t0 + lane] : 0u;
+        const uint32_t cnt = n_tok - t0 < 64 ? n_tok - t0 : 64;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t tk = __builtin_amdgcn_readlane(mine, i);
+            const uint32_t len = (tk >> 8) & 511u, dist = (tk >> 17) + 1u;
+            op += tk & 255u;
+            if (!len) continue;
+            if (dist > op || op + len > total) { bad = true; break; }   // (stage 1 accepted only tokens inside the output)
+            w.match(op, dist, len);
+            op += len;
+        }
+    }
+    w.finish();
+    if (bad && lane == 0) descs[b].status = KTA_KB_BAD_FRAMING;
+}
+
 // ---- zstd inflate: one lane per batch -------------------------------------------------------------
 // csrc/kta_zstd.h; the decoder's tables (10.6 KiB) and the Huffman-decoded literals of a block live in the
 // batch's scratch, which the host index placed right behind its slice of the inflate area.
@@ -1013,6 +1149,8 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
                 if (inflated > (int64_t)(clen * 1032 + 64)) inflated = -1;   // DEFLATE expands at most 1032x
             }
             uint64_t scratch = 0;
+            if (codec == 1 && inflated > 0 && inflated <= (int64_t)kMaxBatchInflate)
+                scratch = 8 + 4 * kta::gz_token_bound((uint64_t)inflated);      // the match tokens of the two-stage inflate
             if (codec == 4) {
                 uint64_t bound = 0, lit = 0;
                 if (kta::zstd_scan(bytes + pos + KTA_KAFKA_BATCH_HEADER, total - KTA_KAFKA_BATCH_HEADER, &bound, &lit)) {
@@ -1116,6 +1254,21 @@ int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
 {
     if (!src || (!dst && cap)) return -1;
+    uint16_t work[kta::GZ2_WORK];
+    std::vector<uint32_t> tok(kta::gz_token_bound(cap));
+    uint64_t n_tok = 0;
+    uint32_t window[kta::GZ_WIN / 4];                 // the device's stream window too (one lane: word stride 1)
+    kta::GzBitsWin bits;
+    bits.win = window;
+    bits.wstride = 1;
+    const int64_t got = kta::gzip_tokenize(bits, src, n, dst, cap, tok.data(), tok.size(), &n_tok, work, 1);
+    if (got < 0 || !kta::gz_apply_tokens(dst, (uint64_t)got, tok.data(), n_tok)) return -1;
+    return got;
+}
+
+int64_t kta_gzip_inflate_lane_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
     uint16_t work[kta::GZ_WORK];
     return kta::gzip_inflate(src, n, dst, cap, work, 1);
 }
@@ -1198,7 +1351,7 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
             any_gzip = any_gzip || (descs_host[i].flags & KTA_KB_GZIP);
             any_zstd = any_zstd || (descs_host[i].flags & KTA_KB_ZSTD);
             if (descs_host[i].payload_end > buffer_end) buffer_end = descs_host[i].payload_end;
-            if ((descs_host[i].flags & KTA_KB_ZSTD) && descs_host[i].scratch_end > buffer_end) buffer_end = descs_host[i].scratch_end;
+            if (descs_host[i].scratch_end > buffer_end) buffer_end = descs_host[i].scratch_end;
         }
     if (want_keys && buffer_end >= (1ull << 32)) {
         kta_internal_set_error(ctx, "blob + inflate area must be < 4 GiB when key offsets are wanted (key_off is u32)");
@@ -1217,9 +1370,14 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         } else {
             lane_codecs |= KTA_KB_SNAPPY | KTA_KB_LZ4;
         }
-        if (any_gzip)     // DEFLATE is bit-serial: always one lane per batch
+        if (any_gzip && st->variant != 1) {   // Huffman decoding one lane per batch, then the copies one wave per batch
+            hipLaunchKernelGGL((kafka_gzip_tokenize<kGzTokLanes>), dim3((uint32_t)((n_batches + kGzTokLanes - 1) / kGzTokLanes)),
+                               dim3(kGzTokLanes), 0, s, buf, st->d_descs, n_batches);
+            hipLaunchKernelGGL(kafka_gzip_apply, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs, n_batches);
+        } else if (any_gzip) {
             hipLaunchKernelGGL((kafka_gzip_inflate<kGzipLanes>), dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)),
                                dim3(kGzipLanes), 0, s, buf, st->d_descs, n_batches);
+        }
         if (any_zstd)     // bit-serial entropy stages: one lane per batch as well
             hipLaunchKernelGGL(kafka_zstd_inflate, dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)), dim3(kGzipLanes), 0,
                                s, buf, st->d_descs, n_batches);

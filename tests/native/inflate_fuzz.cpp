@@ -3,7 +3,7 @@
 // streams.  Input and output live in exact-size heap blocks, so any read past the input or write past
 // `cap` aborts.  A malformed batch on the GPU must be "reported, never mis-decoded" — and must never
 // fault the device.
-//   inflate_fuzz <codec: snappy|lz4|gzip|zstd> <seed-file>... ; prints "<codec> ok=<n> refused=<n>"
+//   inflate_fuzz <codec: snappy|lz4|gzip|gzip2|zstd> <seed-file>... ; prints "<codec> ok=<n> refused=<n>"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,6 +46,23 @@ int64_t run(const std::string &codec, const std::vector<uint8_t> &in, uint64_t c
             free(w);
             free(l);
         }
+    } else if (codec == "gzip2") {                                // the two-stage form: tokens in an exact-size block too
+        uint16_t work[kta::GZ2_WORK];
+        const uint64_t tcap = kta::gz_token_bound(cap);
+        uint32_t *tok = (uint32_t *)malloc(tcap * 4 ? tcap * 4 : 1);
+        uint64_t n_tok = 0;
+        if (rnd() & 1) {                                          // through the stream window, as on the device
+            uint32_t window[kta::GZ_WIN / 4];
+            kta::GzBitsWin bits;
+            bits.win = window;
+            bits.wstride = 1;
+            got = kta::gzip_tokenize(bits, src, in.size(), dst, cap, tok, tcap, &n_tok, work, 1);
+        } else {
+            kta::GzBits bits;
+            got = kta::gzip_tokenize(bits, src, in.size(), dst, cap, tok, tcap, &n_tok, work, 1);
+        }
+        if (got >= 0 && (n_tok > tcap || !kta::gz_apply_tokens(dst, (uint64_t)got, tok, n_tok))) { fprintf(stderr, "bad tokens accepted\n"); abort(); }
+        free(tok);
     } else {
         uint16_t work[kta::GZ_WORK];
         got = kta::gzip_inflate(src, in.size(), dst, cap, work, 1);

@@ -45,7 +45,7 @@ def _write(d, name, data, stream):
     return p
 
 
-@pytest.mark.parametrize("codec", ["snappy", "lz4", "gzip", "zstd"])
+@pytest.mark.parametrize("codec", ["snappy", "lz4", "gzip", "gzip2", "zstd"])
 def test_inflaters_are_memory_safe_on_mutated_streams(fuzzer, codec):
     exe, d = fuzzer
     try:

@@ -443,6 +443,10 @@ def test_host_index_sizes_compressed_batches():
             if d.flags & 32:   # zstd: the decoder's tables and literals follow the slice
                 assert d.scratch_end > ((d.payload_end + 63) & ~63) + 10000
                 run += (d.scratch_end - ((d.payload_end + 63) & ~63) + 63) & ~63
+            elif d.flags & 16:  # gzip: the match tokens of the two-stage inflate (count + out/3 + out/255 + 1 words)
+                out = d.payload_end - d.payload_off
+                assert d.scratch_end == ((d.payload_end + 63) & ~63) + 8 + 4 * (out // 3 + out // 255 + 1)
+                run += (d.scratch_end - ((d.payload_end + 63) & ~63) + 63) & ~63
             else:
                 assert d.scratch_end == d.payload_end
         else:
@@ -496,10 +500,11 @@ def test_gzip_inflate_host_against_zlib():
     lib = N.load()
 
     def check(comp, d):
-        out1, out2 = C2.create_string_buffer(len(d) + 1), C2.create_string_buffer(len(d) + 1)
-        assert lib.kta_gzip_inflate_host(comp, len(comp), out1, len(d)) == len(d)
+        out1, out2, out3 = (C2.create_string_buffer(len(d) + 1) for _ in range(3))
+        assert lib.kta_gzip_inflate_host(comp, len(comp), out1, len(d)) == len(d)          # two stages (tokens)
+        assert lib.kta_gzip_inflate_lane_host(comp, len(comp), out3, len(d)) == len(d)     # single pass
         assert L.kto_gzip_inflate(comp, len(comp), out2, len(d)) == len(d)
-        assert out1.raw[:len(d)] == d == out2.raw[:len(d)]
+        assert out1.raw[:len(d)] == d == out2.raw[:len(d)] and out3.raw[:len(d)] == d
 
     for d in _library_cases():
         for level in (0, 1, 6, 9):
@@ -531,9 +536,11 @@ def test_gzip_inflate_host_against_zlib():
     for _ in range(200):                                       # flipped bits never crash and never write past `cap`
         bad = bytearray(good)
         bad[int(rng.integers(10, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
-        guard = C2.create_string_buffer(len(d) + 64)
+        guard, guard2 = C2.create_string_buffer(len(d) + 64), C2.create_string_buffer(len(d) + 64)
         got = lib.kta_gzip_inflate_host(bytes(bad), len(bad), guard, len(d))
         assert got in (-1, len(d)) and guard.raw[len(d):] == bytes(64)
+        got2 = lib.kta_gzip_inflate_lane_host(bytes(bad), len(bad), guard2, len(d))
+        assert got2 == got and (got < 0 or guard.raw == guard2.raw)      # both forms accept the same streams
         refused += got == -1
     assert refused > 50
 
@@ -707,6 +714,40 @@ def test_device_inflate_far_matches_and_long_literals():
                 assert kb[o:o + 3] == key
             o = int(cols["key_off"][0])
             assert far in kb[o:o + len(far) + 64]
+
+
+@pytest.mark.gpu
+def test_device_gzip_and_zstd_copy_paths():
+    """The copy stage of the two-stage gzip inflate and of the zstd kernel, byte for byte: matches further back
+    than the 16 KiB LDS ring minus a chunk (read back from the written-back output; DEFLATE reaches 32 KiB,
+    zstd further), matches and literal runs across 4 KiB chunk borders, self-overlapping copies (distance 1,
+    7 and 70 against lengths up to 258 and beyond), stored and fixed-code blocks, batches of several hundred KiB."""
+    pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(92)
+    chunk = bytes(rng.integers(0, 256, size=9000, dtype=np.uint8))
+    far = chunk + bytes(rng.integers(0, 256, size=14000, dtype=np.uint8)) + chunk      # second copy: offsets ~23 KB
+    wide = bytes(rng.integers(0, 256, size=70000, dtype=np.uint8))
+    farther = wide + bytes(rng.integers(0, 256, size=50000, dtype=np.uint8)) + wide    # zstd: offsets ~120 KB
+    text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(9000))
+    recs = [(0, b"far", far), (1, b"rle", b"\x07" * 5000), (2, b"pat", b"abcdefg" * 900), (3, b"p70", chunk[:70] * 40),
+            (4, b"txt", text), (5, b"fth", farther), (6, b"zer", b"\0" * 300000), (7, None, text[:1000])]
+    codecs = ["gzip", "zstd", "gzip-fixed", "zstd-19", "gzip-stored", "zstd-stream", "gzip-named", None]
+    blob = b"".join(K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c) for i, c in enumerate(codecs))
+    want, _ = kafka_decode(blob, 1)
+    for variant in (0, 1):
+        with kta.HipMetricHandler(2, now=NOW) as h:
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
+            cols, st, bad = _decode_on_device(h, blob, 1, True)
+            assert bad == 0 and st.n_gzip == 4 and st.n_zstd == 3
+            for k in ("partition", "key_len", "val_len", "ts_ms"):
+                assert np.array_equal(cols[k], want[k]), k
+            kb = cols["key_bytes"].tobytes()
+            for b in range(len(codecs)):                      # every batch: every keyed record's key and value bytes
+                for i, (_, key, value) in enumerate(recs[:7]):
+                    o = int(cols["key_off"][b * len(recs) + i])
+                    assert kb[o:o + 3] == key, (variant, codecs[b], key)
+                    at = kb.find(value[:64], o + 3, o + 3 + 8 + 64)    # the value follows its varint length
+                    assert at > 0 and kb[at:at + len(value)] == value, (variant, codecs[b], key)
 
 
 @pytest.mark.gpu
