@@ -46,7 +46,7 @@ constexpr uint32_t GZ_WORK = 656;
 
 struct GzBits {
     const uint8_t *p;
-    uint64_t n, pos;     // pos: next byte to load into `hold` (may run past n: zeros)
+    uint32_t n, pos;     // pos: next byte to load into `hold` (may run past n: zeros); members are < 2 GiB
     uint64_t hold;
     uint32_t bits;
     bool overrun;        // consumed bits that were not there
@@ -61,17 +61,17 @@ constexpr uint32_t GZ_WIN = 128;
 struct GzBitsWin : GzBits {
     uint32_t *win;
     uint32_t wstride;
-    uint64_t wbase;      // stream offset of the window's first byte; ~0: nothing loaded
+    uint32_t wbase;      // stream offset of the window's first byte; ~0: nothing loaded
 };
 
 KTA_GZIP_HD void gz_reset_window(GzBits &) {}
-KTA_GZIP_HD void gz_reset_window(GzBitsWin &b) { b.wbase = ~0ull; }
+KTA_GZIP_HD void gz_reset_window(GzBitsWin &b) { b.wbase = ~0u; }
 
 // continue reading at byte `pos` of the stream (also the initial state)
 template <class Bits>
 KTA_GZIP_HD void gz_seek(Bits &b, uint64_t pos)
 {
-    b.pos = pos;
+    b.pos = (uint32_t)pos;
     b.hold = 0;
     b.bits = 0;
     gz_reset_window(b);
@@ -84,7 +84,7 @@ KTA_GZIP_HD void gz_topup(GzBitsWin &b)
     uint32_t w[GZ_WIN / 4];
 #pragma unroll
     for (uint32_t k = 0; k < GZ_WIN / 4; k++) {
-        const uint64_t at = b.pos + 4 * k;
+        const uint32_t at = b.pos + 4 * k;
         __builtin_memcpy(&w[k], b.p + (at + 4 <= b.n ? at : b.n - 4), 4);
     }
 #pragma unroll
@@ -102,21 +102,37 @@ KTA_GZIP_HD uint32_t gz_word(GzBits &b)
 
 KTA_GZIP_HD uint32_t gz_word(GzBitsWin &b)
 {
-    if (b.wbase == ~0ull || b.pos < b.wbase || b.pos - b.wbase >= GZ_WIN || ((b.pos - b.wbase) & 3u)) gz_topup(b);
+    if (b.wbase == ~0u || b.pos < b.wbase || b.pos - b.wbase >= GZ_WIN || ((b.pos - b.wbase) & 3u)) gz_topup(b);
     return b.win[((b.pos - b.wbase) >> 2) * b.wstride];
 }
 
-// Device: when the window of any lane of the wave runs low (in the literal loop), all of them take a fresh
-// one — one memory round trip for the wave instead of one per lane at its own moment.
+// The tokenizer's symbol loop keeps this invariant at the top of every iteration: a lane with a whole word left
+// in its stream (pos + 4 <= n) has the bytes [pos, pos + 16) inside its window — enough for the (at most two)
+// word refills of one iteration, which then read the window unchecked (gz_word_ready).  On the device the
+// check is a vote: when the window of any lane of the wave runs low, all of them take a fresh one — one
+// memory round trip for the wave instead of one per lane at its own moment.
 KTA_GZIP_HD void gz_topup_all(GzBits &) {}
 KTA_GZIP_HD void gz_topup_all(GzBitsWin &b)
 {
+    const bool low = b.pos + 4 <= b.n && (b.wbase == ~0u || b.pos < b.wbase || b.pos - b.wbase > GZ_WIN - 16);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const bool low = b.pos + 4 <= b.n && (b.wbase == ~0ull || b.pos - b.wbase + 16 > GZ_WIN);
     if (__builtin_amdgcn_ballot_w64(low)) gz_topup(b);
 #else
-    (void)b;
+    if (low) gz_topup(b);
 #endif
+}
+
+// the four bytes at pos, for a caller that holds the invariant above (anything if pos + 4 > n: not used then)
+KTA_GZIP_HD uint32_t gz_word_ready(GzBits &b)
+{
+    uint32_t w = 0;
+    if (b.pos + 4 <= b.n) __builtin_memcpy(&w, b.p + b.pos, 4);
+    return w;
+}
+
+KTA_GZIP_HD uint32_t gz_word_ready(GzBitsWin &b)
+{
+    return b.win[(((b.pos - b.wbase) >> 2) & (GZ_WIN / 4 - 1)) * b.wstride];
 }
 
 // at least 32 valid bits in hold (zeros past the end of the input)
@@ -142,7 +158,7 @@ KTA_GZIP_HD void gz_drop(GzBits &b, uint32_t k)
     b.hold >>= k;
     b.bits -= k;
     // bytes beyond the input were counted in pos: some were consumed iff fewer than that many bits remain
-    if (b.pos > b.n && b.bits < 8 * (uint32_t)(b.pos - b.n)) b.overrun = true;
+    if (b.pos > b.n && b.bits < 8 * (b.pos - b.n)) b.overrun = true;
 }
 
 template <class Bits>
@@ -312,10 +328,10 @@ KTA_GZIP_HD bool gz_codes(Bits &b, const GzCode &lencode, const GzCode &distcode
 KTA_GZIP_HD int64_t gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, uint16_t *work, uint32_t stride)
 {
     const uint64_t start = gzip_header(src, n);
-    if (!start) return -1;
+    if (!start || n > 0x7FFFFFFFull) return -1;
     GzBits b;
     b.p = src + start;
-    b.n = n - 8 - start;                                   // the trailer is not part of the DEFLATE stream
+    b.n = (uint32_t)(n - 8 - start);                       // the trailer is not part of the DEFLATE stream
     b.overrun = false;
     gz_seek(b, 0);
     GzCode lencode, distcode;
@@ -411,16 +427,16 @@ KTA_GZIP_HD int64_t gzip_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
 //
 // Symbols are decoded through primary lookup tables indexed with the next GZ_LBITS / GZ_DBITS stream bits
 // (entry: symbol << 4 | code length; 0 = the code is longer than the index, or no code at all: the
-// canonical search of gz_decode takes over).  Work area (u16 words, strided like GZ_WORK): the counts of the
+// canonical search over the longer lengths takes over).  Work area (u16 words, strided like GZ_WORK): the counts of the
 // code being built | literal/length symbols | distance symbols | literal/length table | distance table.  The
 // code lengths of a block live in the literal/length table's words until its codes are built (the distance
 // code first, then the literal/length code, whose table fill is the last reader of nothing).
-constexpr uint32_t GZ_LBITS = 9, GZ_DBITS = 7;
+constexpr uint32_t GZ_LBITS = 9, GZ_DBITS = 6;
 constexpr uint32_t GZ2_W_LSYM = 16;      // 288
 constexpr uint32_t GZ2_W_DSYM = 304;     // 32
 constexpr uint32_t GZ2_W_LTAB = 336;     // 512 (code lengths: the first 320)
-constexpr uint32_t GZ2_W_DTAB = 848;     // 128
-constexpr uint32_t GZ2_WORK = 976;
+constexpr uint32_t GZ2_W_DTAB = 848;     // 64
+constexpr uint32_t GZ2_WORK = 912;
 
 KTA_GZIP_HD uint64_t gz_token_bound(uint64_t out) { return out / 3 + out / 255 + 1; }
 
@@ -467,75 +483,140 @@ KTA_GZIP_HD void gz_fill(uint16_t *work, uint32_t stride, uint32_t syms, uint32_
     }
 }
 
-template <class Bits>
-KTA_GZIP_HD int gz_decode_fast(Bits &b, const GzCode &c, const uint16_t *work, uint32_t stride, uint32_t tab, uint32_t pbits,
-                               uint32_t syms)
+// hold >>= k with the over-read flag, without a branch
+KTA_GZIP_HD void gz_take(GzBits &b, uint32_t k)
 {
-    gz_refill(b);
-    const uint32_t e = work[(tab + ((uint32_t)b.hold & ((1u << pbits) - 1u))) * stride];
-    const uint32_t l = e & 15u;
-    if (l) {
-        gz_drop(b, l);
-        return (int)(e >> 4);
+    b.hold >>= k;
+    b.bits -= k;
+    b.overrun = b.overrun | (b.pos > b.n && b.bits < 8u * (b.pos - b.n));
+}
+
+// gz_refill for a caller inside the symbol loop (window unchecked, see gz_topup_all)
+template <class Bits>
+KTA_GZIP_HD void gz_refill_ready(Bits &b)
+{
+    if (b.bits >= 32) return;
+    if (b.pos + 4 <= b.n) {
+        b.hold |= (uint64_t)gz_word_ready(b) << b.bits;
+        b.pos += 4;
+        b.bits += 32;
+        return;
     }
-    return gz_decode(b, c, work, stride, syms);
+    while (b.bits < 32) {
+        if (b.pos < b.n) b.hold |= (uint64_t)b.p[b.pos] << b.bits;
+        b.pos++;
+        b.bits += 8;
+    }
+}
+
+// One symbol from the bits in hold (>= 15 of them, or the zeros of the stream's end) through the primary table
+// of PBITS index bits; a code longer than the index (entry 0) is found by the canonical search over the
+// remaining lengths only.  -1 if the bits are no code of `c`.
+template <uint32_t PBITS>
+KTA_GZIP_HD int gz_lookup(GzBits &b, const GzCode &c, const uint16_t *work, uint32_t stride, uint32_t tab, uint32_t syms)
+{
+    const uint32_t e = work[(tab + ((uint32_t)b.hold & ((1u << PBITS) - 1u))) * stride];
+    uint32_t l = e & 15u;
+    int sym = (int)(e >> 4);
+    if (!l) {
+        const uint32_t rev = gz_rev15((uint32_t)b.hold & 0x7FFFu);
+        int32_t idx = 0;
+#pragma unroll
+        for (int k = 15; k > (int)PBITS; k--)
+            if (rev < c.limit[k]) {                        // the smallest such length wins (limits never decrease)
+                l = (uint32_t)k;
+                idx = c.base[k] + (int32_t)(rev >> (15 - k));
+            }
+        if (!l) return -1;
+        sym = work[(syms + (uint32_t)idx) * stride];
+    }
+    gz_take(b, l);
+    return sym;
+}
+
+// One symbol of any kind, for the lanes the literal path below could not serve: a literal with a long code or
+// at the stream's end, a match (-> token), the end of the block.  Returns the loop state: 0 go on, 1 end of
+// block, 2 malformed.
+template <class Bits>
+KTA_GZIP_HD uint32_t gz_step(Bits &b, const GzCode &lencode, const GzCode &distcode, const uint16_t *work, uint32_t stride,
+                             uint8_t *dst, uint32_t &op, uint32_t cap, GzTokens &t)
+{
+    gz_refill_ready(b);                               // >= 32 bits: a length code and its extra bits are <= 20
+    const int sym = gz_lookup<GZ_LBITS>(b, lencode, work, stride, GZ2_W_LTAB, GZ2_W_LSYM);
+    if (sym < 0 || sym > 285 || b.overrun) return 2;
+    if (sym < 256) {
+        if (op >= cap) return 2;
+        dst[op++] = (uint8_t)sym;
+        t.run++;
+        return 0;
+    }
+    if (sym == 256) return 1;
+    const uint32_t k = (uint32_t)sym - 257u;          // 0..28
+    uint32_t eb = 0, len = 3u + k;                    // 257..264: 3..10
+    if (k >= 8) {
+        eb = (k - 4u) >> 2;                           // 265..284: 1..5 extra bits
+        len = 3u + ((4u + (k & 3u)) << eb);
+    }
+    if (k == 28) {                                    // 285
+        eb = 0;
+        len = 258u;
+    }
+    len += (uint32_t)b.hold & ((1u << eb) - 1u);
+    gz_take(b, eb);
+    gz_refill_ready(b);                               // >= 32 bits: a distance code and its extra bits are <= 28
+    const int ds = gz_lookup<GZ_DBITS>(b, distcode, work, stride, GZ2_W_DTAB, GZ2_W_DSYM);
+    if (ds < 0 || ds > 29) return 2;
+    uint32_t eb2 = 0, dist = 1u + (uint32_t)ds;
+    if (ds >= 4) {
+        eb2 = ((uint32_t)ds >> 1) - 1u;               // 1..13 extra bits
+        dist = 1u + ((2u + ((uint32_t)ds & 1u)) << eb2);
+    }
+    dist += (uint32_t)b.hold & ((1u << eb2) - 1u);
+    gz_take(b, eb2);
+    if (b.overrun || dist > op || len > cap - op) return 2;
+    gz_emit(t, len, dist);
+    if (t.full) return 2;
+    op += len;
+    return 0;
 }
 
 // The symbols of one compressed block, tokenized.  Returns false on malformed input (or a full token area).
+// One loop with one exit.  At the top of an iteration hold has >= 32 bits (or the stream is at its end); the
+// iteration reads the next stream word and the table entry of the next symbol together (one LDS round
+// trip), and then is the literal path — one byte stored, the word shifted in if hold ran low, no branch in
+// between — or, for the lanes of the wave that need it, gz_step.
 template <class Bits>
 KTA_GZIP_HD bool gz_codes_tok(Bits &b, const GzCode &lencode, const GzCode &distcode, const uint16_t *work, uint32_t stride,
-                              uint8_t *dst, uint64_t &op, uint64_t cap, GzTokens &t)
+                              uint8_t *dst, uint64_t &op_io, uint64_t cap_io, GzTokens &t)
 {
-    while (true) {
-        // Literals, the bulk of a member, in a loop with one exit: it runs while the stream has whole words
-        // left (so nothing can be over-read), the table resolves the code, the symbol is a literal and the
-        // output has room; whatever ends it is decoded once by the general step below.
-        while (true) {
-            gz_topup_all(b);
-            if (b.bits < 32) {
-                if (b.pos + 4 > b.n) break;
-                b.hold |= (uint64_t)gz_word(b) << b.bits;
-                b.pos += 4;
-                b.bits += 32;
-            }
-            const uint32_t e = work[(GZ2_W_LTAB + ((uint32_t)b.hold & ((1u << GZ_LBITS) - 1u))) * stride];
-            const uint32_t l = e & 15u;
-            if (l == 0 || e >= (256u << 4) || op >= cap) break;
-            b.hold >>= l;
-            b.bits -= l;
+    uint32_t op = (uint32_t)op_io;
+    const uint32_t cap = (uint32_t)cap_io;
+    uint32_t state = 0;                               // 0 decoding, 1 end of block, 2 malformed
+    gz_topup_all(b);
+    gz_refill_ready(b);
+    while (state == 0) {
+        gz_topup_all(b);
+        const uint32_t w = gz_word_ready(b);          // (used only if this iteration ends with a refill)
+        const uint32_t e = work[(GZ2_W_LTAB + ((uint32_t)b.hold & ((1u << GZ_LBITS) - 1u))) * stride];
+        const uint32_t l = e & 15u;
+        // a literal whose code the table resolves, all of its bits real, room for it: the common case
+        const bool fast = l != 0 && e < (256u << 4) && op < cap && b.bits >= 32 && b.pos <= b.n;
+        if (fast) {
             dst[op++] = (uint8_t)(e >> 4);
             t.run++;
+            b.hold >>= l;
+            b.bits -= l;
+            const bool need = b.bits < 32 && b.pos + 4 <= b.n;
+            b.hold |= need ? (uint64_t)w << (b.bits & 31u) : 0ull;
+            b.pos += need ? 4u : 0u;
+            b.bits += need ? 32u : 0u;
+        } else {
+            state = gz_step(b, lencode, distcode, work, stride, dst, op, cap, t);
+            gz_refill_ready(b);
         }
-        const int sym = gz_decode_fast(b, lencode, work, stride, GZ2_W_LTAB, GZ_LBITS, GZ2_W_LSYM);
-        if (sym < 0 || b.overrun) return false;
-        if (sym < 256) {
-            if (op >= cap) return false;
-            dst[op++] = (uint8_t)sym;
-            t.run++;
-            continue;
-        }
-        if (sym == 256) return true;                  // end of block
-        if (sym > 285) return false;
-        uint32_t len;
-        if (sym < 265) len = 3u + (uint32_t)(sym - 257);
-        else if (sym == 285) len = 258u;
-        else {
-            const uint32_t k = (uint32_t)sym - 261u, e = k >> 2;               // 265..284: 1..5 extra bits
-            len = 3u + ((4u + (k & 3u)) << e) + gz_get(b, e);
-        }
-        const int ds = gz_decode_fast(b, distcode, work, stride, GZ2_W_DTAB, GZ_DBITS, GZ2_W_DSYM);
-        if (ds < 0 || ds > 29) return false;
-        uint32_t dist;
-        if (ds < 4) dist = 1u + (uint32_t)ds;
-        else {
-            const uint32_t e = ((uint32_t)ds >> 1) - 1u;                       // 1..13 extra bits
-            dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + gz_get(b, e);
-        }
-        if (b.overrun || dist > op || op + len > cap) return false;
-        gz_emit(t, len, dist);
-        if (t.full) return false;
-        op += len;
     }
+    op_io = op;
+    return state == 1;
 }
 
 // Stage 1 of one gzip member: literals into dst[0 .. cap), matches into tok[0 .. tok_cap) (*n_tok of them).
@@ -546,9 +627,9 @@ KTA_GZIP_HD int64_t gzip_tokenize(Bits &b, const uint8_t *src, uint64_t n, uint8
                                   uint64_t tok_cap, uint64_t *n_tok, uint16_t *work, uint32_t stride)
 {
     const uint64_t start = gzip_header(src, n);
-    if (!start) return -1;
+    if (!start || n > 0x7FFFFFFFull || cap > 0x7FFFFFFFull) return -1;
     b.p = src + start;
-    b.n = n - 8 - start;
+    b.n = (uint32_t)(n - 8 - start);
     b.overrun = false;
     gz_seek(b, 0);
     GzCode lencode, distcode;

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(L) void kafka_gzip_inflate(uint8_t *buffer, kta_kaf
 // that start in it are copied 64 bytes per step inside LDS (a dependent step costs LDS latency, not a
 // memory round trip), and the chunk is written back in whole 16-byte units.  A match that reaches further
 // back than the ring reads the written-back output (behind a fence, past L1).
-constexpr uint32_t kGzTokLanes = 8;
+constexpr uint32_t kGzTokLanes = 16;
 constexpr uint32_t kLzRing = 16384, kLzChunk = 4096;
 
 template <uint32_t L>
@@ -527,6 +527,26 @@ struct LzWindow {
             while (op >= c0 + kLzChunk) advance();
             uint64_t n = c0 + kLzChunk - op;
             n = n < len ? n : len;
+            if (n > 64 && dist >= 64 && op - dist + kLzRing >= c0 + kLzChunk) {
+                // up to four steps whose sources are all final already (the copy does not reach into itself
+                // within them): their reads go out together, one LDS round trip instead of four
+                uint32_t m = n < 256 ? (uint32_t)n : 256u;
+                m = dist < m ? (uint32_t)dist : m;
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = lane + 64 * k;
+                    v[k] = i < m ? ring()[(op - dist + i) & (kLzRing - 1)] : (uint8_t)0;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = lane + 64 * k;
+                    if (i < m) ring()[(op + i) & (kLzRing - 1)] = v[k];
+                }
+                op += m;
+                len -= m;
+                continue;
+            }
             n = n < 64 ? n : 64;
             // byte i of the step: source index repeats with period `dist` when the copy overlaps itself
             const uint64_t s = op - dist + (dist >= 64 ? lane : lane % (uint32_t)dist);
@@ -1371,6 +1391,14 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
             lane_codecs |= KTA_KB_SNAPPY | KTA_KB_LZ4;
         }
         if (any_gzip && st->variant != 1) {   // Huffman decoding one lane per batch, then the copies one wave per batch
+            static const int lanes_env = getenv("KTA_GZIP_LANES") ? atoi(getenv("KTA_GZIP_LANES")) : 0;   // (measurement aid)
+            if (lanes_env == 8)
+                hipLaunchKernelGGL((kafka_gzip_tokenize<8>), dim3((uint32_t)((n_batches + 7) / 8)), dim3(8), 0, s, buf, st->d_descs, n_batches);
+            else if (lanes_env == 22)
+                hipLaunchKernelGGL((kafka_gzip_tokenize<22>), dim3((uint32_t)((n_batches + 21) / 22)), dim3(22), 0, s, buf, st->d_descs, n_batches);
+            else if (lanes_env == 32)
+                hipLaunchKernelGGL((kafka_gzip_tokenize<32>), dim3((uint32_t)((n_batches + 31) / 32)), dim3(32), 0, s, buf, st->d_descs, n_batches);
+            else
             hipLaunchKernelGGL((kafka_gzip_tokenize<kGzTokLanes>), dim3((uint32_t)((n_batches + kGzTokLanes - 1) / kGzTokLanes)),
                                dim3(kGzTokLanes), 0, s, buf, st->d_descs, n_batches);
             hipLaunchKernelGGL(kafka_gzip_apply, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs, n_batches);

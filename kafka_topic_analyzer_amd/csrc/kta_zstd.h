@@ -1,8 +1,20 @@
 // kta_zstd.h — Zstandard inflate for compressed Kafka record batches (attributes codec 4, KIP-110).
 // Same code on the host (index: size bound, literal scratch; CPU tests against libzstd's output) and on
-// the device (one lane per batch).  Written from the format specification (RFC 8878); checksums are not
-// verified (the batch CRC-32C covers the compressed bytes), dictionaries are not supported (Kafka does
-// not use them), skippable frames are refused.
+// the device.  Written from the format specification (RFC 8878); checksums are not verified (the batch
+// CRC-32C covers the compressed bytes), dictionaries are not supported (Kafka does not use them),
+// skippable frames are refused.
+//
+// The decoder is written against two small policies, so that one text serves three executions:
+//   S, where the compressed bytes come from:  byte(at)
+//        ZsMem         plain memory (the host; the device's one-lane-per-batch kernel; one lane of a wave on its
+//                      own Huffman stream)
+//        (kta_kafka.hip: a wave's LDS window on the batch, refilled by all 64 lanes together)
+//   O, where the output goes:  lit_src / lit_buf / lit_rle / match / huf_streams, position op
+//        ZsOutMem      plain memory, byte by byte
+//        (kta_kafka.hip: one wave moving 64 bytes per step through an LDS mirror of the output)
+// In the wave form every lane runs the parsing redundantly (it is uniform across the wave: same bytes, same
+// tables in LDS, same decisions) and the policies do the work that has width: the window refills, the copies,
+// the four Huffman streams on four lanes.
 //
 // Frame: magic FD2FB528 (LE) | Frame_Header_Descriptor | [Window_Descriptor] | [Dictionary_ID] |
 //   [Frame_Content_Size] | blocks | [checksum 4].  Block: 3-byte LE header (last 1 bit, type 2 bits:
@@ -21,7 +33,8 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define KTA_ZSTD_HD __host__ __device__ inline
+#define KTA_ZSTD_HD __host__ __device__ inline __attribute__((always_inline))   // inlined into the kernel: the address
+                                                                              // spaces (LDS tables, window) are then known
 #else
 #define KTA_ZSTD_HD inline
 #endif
@@ -48,22 +61,31 @@ KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
     return 31u - (uint32_t)__builtin_clz(v);
 }
 
-// ---- forward (LSB first) bit reader: FSE table descriptions --------------------------------------------
-struct ZsFwd {
+// ---- byte source: plain memory ------------------------------------------------------------------------------
+struct ZsMem {
     const uint8_t *p;
-    uint64_t n;
-    uint64_t bit;   // next bit
+    KTA_ZSTD_HD uint32_t byte(uint64_t at) { return p[at]; }
+    KTA_ZSTD_HD const uint8_t *memory() const { return p; }     // (a wave source hands out its global pointer here)
+};
+
+// ---- forward (LSB first) bit reader: FSE table descriptions --------------------------------------------
+template <class S>
+struct ZsFwd {
+    S *src;
+    uint64_t base, n;   // the bytes [base, base + n) of src
+    uint64_t bit;       // next bit
     bool bad;
 };
 
-KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd &f, uint32_t nb)   // nb <= 16
+template <class S>
+KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd<S> &f, uint32_t nb)   // nb <= 16
 {
     uint32_t v = 0;
     for (uint32_t got = 0; got < nb;) {
         const uint64_t byte = f.bit >> 3;
         if (byte >= f.n) { f.bad = true; return 0; }
         const uint32_t sh = (uint32_t)(f.bit & 7), take = (8 - sh) < (nb - got) ? (8 - sh) : (nb - got);
-        v |= (((uint32_t)f.p[byte] >> sh) & ((1u << take) - 1u)) << got;
+        v |= ((f.src->byte(f.base + byte) >> sh) & ((1u << take) - 1u)) << got;
         got += take;
         f.bit += take;
     }
@@ -71,46 +93,60 @@ KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd &f, uint32_t nb)   // nb <= 16
 }
 
 // ---- backward bit reader ---------------------------------------------------------------------------------
+// A 64-bit container holds the stream bits [lo, lo + 64), lo a multiple of 8 (bytes before the stream's first
+// are zeros); it is reloaded, eight bytes at once, when a read leaves it — about once per sequence or per
+// eight Huffman symbols instead of once per field.
+template <class S>
 struct ZsBack {
-    const uint8_t *p;
-    uint64_t n;
-    int64_t off;    // bits [0, off) are unread; may go negative (zeros)
+    S *src;
+    uint64_t base, n;
+    int64_t off;        // bits [0, off) are unread; may go negative (zeros)
+    uint64_t cont;
+    int64_t lo;         // bit index of the container's bit 0; off + 1 .. : nothing loaded
+    bool loaded;
 };
 
-KTA_ZSTD_HD bool zs_back_init(ZsBack &b, const uint8_t *p, uint64_t n)
+template <class S>
+KTA_ZSTD_HD bool zs_back_init(ZsBack<S> &b, S *src, uint64_t base, uint64_t n)
 {
-    if (n == 0 || p[n - 1] == 0) return false;
-    b.p = p;
+    if (n == 0) return false;
+    const uint32_t last = src->byte(base + n - 1);
+    if (last == 0) return false;
+    b.src = src;
+    b.base = base;
     b.n = n;
-    b.off = (int64_t)(8 * (n - 1)) + (int64_t)zs_highbit(p[n - 1]);
+    b.off = (int64_t)(8 * (n - 1)) + (int64_t)zs_highbit(last);
+    b.cont = 0;
+    b.lo = 0;
+    b.loaded = false;
     return true;
 }
 
-KTA_ZSTD_HD uint64_t zs_back(ZsBack &b, uint32_t nb)   // nb <= 32
+template <class S>
+KTA_ZSTD_HD uint64_t zs_back(ZsBack<S> &b, uint32_t nb)   // nb <= 32
 {
     b.off -= (int64_t)nb;
     if (nb == 0) return 0;
-    int64_t lo = b.off;
-    uint32_t want = nb, shift_out = 0;
-    if (lo < 0) {                                  // (partly) before the first byte: those bits are zero
-        if (-lo >= (int64_t)nb) return 0;
-        shift_out = (uint32_t)(-lo);
-        want = nb - shift_out;
-        lo = 0;
+    const int64_t at = b.off;                        // the bits [at, at + nb)
+    if (!b.loaded || at < b.lo || at + (int64_t)nb > b.lo + 64) {
+        // the container ends at the byte boundary at or above at + nb: reads go downwards from here
+        const int64_t byte_hi = (at + (int64_t)nb + 7) >> 3, byte_lo = byte_hi - 8;
+        uint64_t c = 0;
+        for (int i = 0; i < 8; i++) {
+            const int64_t k = byte_lo + i;
+            if (k >= 0 && (uint64_t)k < b.n) c |= (uint64_t)b.src->byte(b.base + (uint64_t)k) << (8 * i);
+        }
+        b.cont = c;
+        b.lo = byte_lo * 8;
+        b.loaded = true;
     }
-    const uint64_t byte = (uint64_t)lo >> 3;
-    const uint32_t sh = (uint32_t)(lo & 7);
-    uint64_t v = 0;
-    const uint32_t nbytes = (want + sh + 7) >> 3;  // <= 5
-    for (uint32_t i = 0; i < nbytes; i++)
-        if (byte + i < b.n) v |= (uint64_t)b.p[byte + i] << (8 * i);
-    v = (v >> sh) & ((1ull << want) - 1ull);
-    return v << shift_out;
+    return (b.cont >> (uint32_t)(at - b.lo)) & ((1ull << nb) - 1ull);
 }
 
 // ---- FSE ----------------------------------------------------------------------------------------------------
 // Reads a table description (normalized counts) into w.norm; returns the accuracy log, 0 on error.
-KTA_ZSTD_HD uint32_t zs_read_norm(ZsFwd &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
+template <class S>
+KTA_ZSTD_HD uint32_t zs_read_norm(ZsFwd<S> &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
 {
     const uint32_t log = 5 + zs_fwd(f, 4);
     if (f.bad || log > max_log) return 0;
@@ -196,7 +232,8 @@ KTA_ZSTD_HD void zs_default_norm(ZsWork &w, int which)
 }
 
 // One of the three sequence tables.  mode: 0 predefined, 1 RLE, 2 described, 3 repeat.
-KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, const uint8_t *p, uint64_t n, uint64_t *pos)
+template <class S>
+KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint64_t base, uint64_t n, uint64_t *pos)
 {
     uint32_t *t = which == 0 ? w.ll : (which == 1 ? w.of : w.ml);
     uint8_t &log = which == 0 ? w.ll_log : (which == 1 ? w.of_log : w.ml_log);
@@ -209,14 +246,14 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, const uint8_t
         return zs_build_fse(w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53));
     }
     if (mode == 1) {
-        if (*pos >= n || p[*pos] > max_sym) return false;
-        zs_build_rle(t, p[(*pos)++]);
+        if (*pos >= n || src.byte(base + *pos) > max_sym) return false;
+        zs_build_rle(t, src.byte(base + (*pos)++));
         log = 0;
         have = 1;
         return true;
     }
     if (mode == 2) {
-        ZsFwd f{p + *pos, n - *pos, 0, false};
+        ZsFwd<S> f{&src, base + *pos, n - *pos, 0, false};
         uint32_t n_sym = 0;
         const uint32_t l = zs_read_norm(f, w, max_log, max_sym, &n_sym);
         if (!l) return false;
@@ -230,28 +267,32 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, const uint8_t
 
 // ---- Huffman ------------------------------------------------------------------------------------------------
 // Tree description at p[0 .. n): fills w.huf / w.huf_log; returns the bytes consumed, 0 on error.
-KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, const uint8_t *p, uint64_t n)
+template <class S>
+KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t n)
 {
     if (n < 1) return 0;
-    const uint32_t hb = p[0];
+    const uint32_t hb = src.byte(base);
     uint32_t n_w = 0;
     uint64_t used;
     if (hb >= 128) {                                  // direct: 4 bits per weight
         n_w = hb - 127;
         used = 1 + (n_w + 1) / 2;
         if (used > n) return 0;
-        for (uint32_t i = 0; i < n_w; i++) w.weights[i] = (uint8_t)((i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4));
+        for (uint32_t i = 0; i < n_w; i++) {
+            const uint32_t pair = src.byte(base + 1 + i / 2);
+            w.weights[i] = (uint8_t)((i & 1) ? (pair & 15) : (pair >> 4));
+        }
     } else {                                          // FSE coded weights, two interleaved states
         used = 1 + hb;
         if (hb == 0 || used > n) return 0;
-        ZsFwd f{p + 1, hb, 0, false};
+        ZsFwd<S> f{&src, base + 1, hb, 0, false};
         uint32_t n_sym = 0;
         const uint32_t log = zs_read_norm(f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
         if (!log || !zs_build_fse(w, w.wfse, log, n_sym)) return 0;
         const uint64_t at = f.bit >> 3;
         if (at >= hb) return 0;
-        ZsBack b;
-        if (!zs_back_init(b, p + 1 + at, hb - at)) return 0;
+        ZsBack<S> b;
+        if (!zs_back_init(b, &src, base + 1 + at, hb - at)) return 0;
         uint32_t s1 = (uint32_t)zs_back(b, log), s2 = (uint32_t)zs_back(b, log);
         if (b.off < 0) return 0;
         while (true) {
@@ -297,10 +338,11 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, const uint8_t *p, uint64_t n)
     return used;
 }
 
-KTA_ZSTD_HD bool zs_huf_stream(const ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t count)
+template <class S>
+KTA_ZSTD_HD bool zs_huf_stream(const ZsWork &w, S &src, uint64_t base, uint64_t n, uint8_t *out, uint64_t count)
 {
-    ZsBack b;
-    if (!zs_back_init(b, p, n)) return false;
+    ZsBack<S> b;
+    if (!zs_back_init(b, &src, base, n)) return false;
     const uint32_t log = w.huf_log, mask = (1u << log) - 1u;
     uint32_t state = (uint32_t)zs_back(b, log);
     for (uint64_t i = 0; i < count; i++) {
@@ -320,134 +362,181 @@ struct ZsLit {
 };
 
 // Parses the literals section header at p: type, regenerated and compressed sizes, header bytes (0 = error).
-KTA_ZSTD_HD uint32_t zs_lit_header(const uint8_t *p, uint64_t n, uint32_t *type, uint32_t *regen, uint32_t *comp,
+template <class S>
+KTA_ZSTD_HD uint32_t zs_lit_header(S &src, uint64_t base, uint64_t n, uint32_t *type, uint32_t *regen, uint32_t *comp,
                                    uint32_t *streams)
 {
     if (n < 1) return 0;
-    const uint32_t b0 = p[0], sf = (b0 >> 2) & 3;
+    const uint32_t b0 = src.byte(base), sf = (b0 >> 2) & 3;
+    const uint32_t p1 = n > 1 ? src.byte(base + 1) : 0, p2 = n > 2 ? src.byte(base + 2) : 0;
+    const uint32_t p3 = n > 3 ? src.byte(base + 3) : 0, p4 = n > 4 ? src.byte(base + 4) : 0;
     *type = b0 & 3;
     *comp = 0;
     *streams = 1;
     if (*type < 2) {                                  // raw / RLE
         if (sf == 0 || sf == 2) { *regen = b0 >> 3; return 1; }
-        if (sf == 1) { if (n < 2) return 0; *regen = (b0 >> 4) | ((uint32_t)p[1] << 4); return 2; }
+        if (sf == 1) { if (n < 2) return 0; *regen = (b0 >> 4) | (p1 << 4); return 2; }
         if (n < 3) return 0;
-        *regen = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
+        *regen = (b0 >> 4) | (p1 << 4) | (p2 << 12);
         return 3;
     }
     *streams = sf == 0 ? 1 : 4;
     if (sf < 2) {                                     // 10 + 10 bits
         if (n < 3) return 0;
-        const uint32_t v = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
+        const uint32_t v = (b0 >> 4) | (p1 << 4) | (p2 << 12);
         *regen = v & 0x3FF;
         *comp = v >> 10;
         return 3;
     }
     if (sf == 2) {                                    // 14 + 14 bits
         if (n < 4) return 0;
-        const uint32_t v = (b0 >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12) | ((uint32_t)p[3] << 20);
+        const uint32_t v = (b0 >> 4) | (p1 << 4) | (p2 << 12) | (p3 << 20);
         *regen = v & 0x3FFF;
         *comp = v >> 14;
         return 4;
     }
     if (n < 5) return 0;                              // 18 + 18 bits
-    const uint64_t v = (b0 >> 4) | ((uint64_t)p[1] << 4) | ((uint64_t)p[2] << 12) | ((uint64_t)p[3] << 20) | ((uint64_t)p[4] << 28);
+    const uint64_t v = (b0 >> 4) | ((uint64_t)p1 << 4) | ((uint64_t)p2 << 12) | ((uint64_t)p3 << 20) | ((uint64_t)p4 << 28);
     *regen = (uint32_t)(v & 0x3FFFF);
     *comp = (uint32_t)(v >> 18);
     return 5;
 }
 
-KTA_ZSTD_HD void zs_copy(uint8_t *dst, uint64_t op, uint64_t dist, uint64_t len)   // overlapping match copy
-{
-    uint64_t k = 0;
-    if (dist >= 8)
-        for (; k + 8 <= len; k += 8) {
-            uint64_t v;
-            __builtin_memcpy(&v, dst + op - dist + k, 8);
-            __builtin_memcpy(dst + op + k, &v, 8);
-        }
-    for (; k < len; k++) dst[op + k] = dst[op - dist + k];
-}
+// ---- output sink: plain memory ----------------------------------------------------------------------------------
+// The callers have checked every bound (room in dst, literals left, offsets inside the frame); a sink moves bytes.
+struct ZsOutMem {
+    uint8_t *dst;
+    uint64_t op;
 
-// One compressed block p[0 .. n) appended at dst[*op ..).  `total` = bytes of the frame before this block.
-KTA_ZSTD_HD bool zs_block(ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *dst, uint64_t *op_io, uint64_t cap,
-                          uint64_t frame_start, uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap)
+    template <class S>
+    KTA_ZSTD_HD void lit_src(S &src, uint64_t at, uint64_t cnt)      // literals that sit in the compressed bytes
+    {
+        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = (uint8_t)src.byte(at + k);
+        op += cnt;
+    }
+    KTA_ZSTD_HD void lit_buf(const uint8_t *lit, uint64_t cnt)         // Huffman-decoded literals
+    {
+        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit[k];
+        op += cnt;
+    }
+    KTA_ZSTD_HD void lit_rle(uint8_t v, uint64_t cnt)
+    {
+        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = v;
+        op += cnt;
+    }
+    KTA_ZSTD_HD void match(uint64_t dist, uint64_t len)                // may overlap itself
+    {
+        uint64_t k = 0;
+        if (dist >= 8)
+            for (; k + 8 <= len; k += 8) {
+                uint64_t v;
+                __builtin_memcpy(&v, dst + op - dist + k, 8);
+                __builtin_memcpy(dst + op + k, &v, 8);
+            }
+        for (; k < len; k++) dst[op + k] = dst[op - dist + k];
+        op += len;
+    }
+    // the Huffman streams of a literals section (1 or 4; stream i: n[i] bytes at at[i], count[i] symbols, to
+    // out + the counts before it): one after the other
+    template <class S>
+    KTA_ZSTD_HD bool huf_streams(const ZsWork &w, S &src, uint32_t streams, const uint64_t at[4], const uint64_t n[4],
+                                 const uint64_t count[4], uint8_t *out)
+    {
+        uint64_t done = 0;
+        for (uint32_t i = 0; i < streams; i++) {
+            if (!zs_huf_stream(w, src, at[i], n[i], out + done, count[i])) return false;
+            done += count[i];
+        }
+        return true;
+    }
+};
+
+// One compressed block: the bytes [base, base + n) of src, appended through `out`.  `cap`: room of the whole
+// output; `frame_start`: output position where the frame began (offsets may not reach before it).
+template <class S, class O>
+KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, uint64_t cap, uint64_t frame_start,
+                          uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap)
 {
-    uint64_t op = *op_io;
-    const uint64_t block_start = op;
+    const uint64_t block_start = out.op;
     uint32_t type, regen, comp, streams;
-    const uint32_t hdr = zs_lit_header(p, n, &type, &regen, &comp, &streams);
+    const uint32_t hdr = zs_lit_header(src, base, n, &type, &regen, &comp, &streams);
     if (!hdr || regen > ZS_BLOCK_MAX) return false;
     uint64_t pos = hdr;
-    ZsLit lit{nullptr, regen, 0};
+    uint64_t lit_src_at = 0;                          // type 0: where the raw literals start in src
+    uint8_t lit_rle = 0;
     if (type == 0) {                                  // raw: used in place
         if (pos + regen > n) return false;
-        lit.p = p + pos;
+        lit_src_at = base + pos;
         pos += regen;
     } else if (type == 1) {                           // RLE
         if (pos + 1 > n) return false;
-        lit.rle = p[pos++];
+        lit_rle = (uint8_t)src.byte(base + pos++);
     } else {                                          // Huffman coded (2) / with the previous tree (3)
         if (pos + comp > n || regen > lit_cap) return false;
-        const uint8_t *q = p + pos;
-        uint64_t qn = comp;
+        uint64_t q = base + pos, qn = comp;
         if (type == 2) {
-            const uint64_t used = zs_read_huffman(w, q, qn);
+            const uint64_t used = zs_read_huffman(w, src, q, qn);
             if (!used) return false;
             q += used;
             qn -= used;
         } else if (!w.have_huf) {
             return false;
         }
-        if (streams == 1) {
-            if (!zs_huf_stream(w, q, qn, lit_buf, regen)) return false;
-        } else {
+        uint64_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
+        if (streams == 4) {
             if (qn < 6) return false;
-            const uint64_t s1 = (uint64_t)q[0] | ((uint64_t)q[1] << 8), s2 = (uint64_t)q[2] | ((uint64_t)q[3] << 8),
-                           s3 = (uint64_t)q[4] | ((uint64_t)q[5] << 8);
+            const uint64_t s1 = (uint64_t)src.byte(q) | ((uint64_t)src.byte(q + 1) << 8);
+            const uint64_t s2 = (uint64_t)src.byte(q + 2) | ((uint64_t)src.byte(q + 3) << 8);
+            const uint64_t s3 = (uint64_t)src.byte(q + 4) | ((uint64_t)src.byte(q + 5) << 8);
             if (6 + s1 + s2 + s3 > qn) return false;
-            const uint64_t s4 = qn - 6 - s1 - s2 - s3, each = ((uint64_t)regen + 3) / 4;
+            const uint64_t each = ((uint64_t)regen + 3) / 4;
             if (3 * each > regen) return false;
-            if (!zs_huf_stream(w, q + 6, s1, lit_buf, each) || !zs_huf_stream(w, q + 6 + s1, s2, lit_buf + each, each) ||
-                !zs_huf_stream(w, q + 6 + s1 + s2, s3, lit_buf + 2 * each, each) ||
-                !zs_huf_stream(w, q + 6 + s1 + s2 + s3, s4, lit_buf + 3 * each, regen - 3 * each))
-                return false;
+            at[0] = q + 6;
+            at[1] = at[0] + s1;
+            at[2] = at[1] + s2;
+            at[3] = at[2] + s3;
+            len[0] = s1;
+            len[1] = s2;
+            len[2] = s3;
+            len[3] = qn - 6 - s1 - s2 - s3;
+            count[0] = count[1] = count[2] = each;
+            count[3] = regen - 3 * each;
         }
-        lit.p = lit_buf;
+        if (!out.huf_streams(w, src, streams, at, len, count, lit_buf)) return false;
         pos += comp;
     }
     // sequences section
     if (pos >= n) return false;
-    uint32_t n_seq = p[pos++];
+    uint32_t n_seq = src.byte(base + pos++);
     if (n_seq >= 128) {
         if (n_seq < 255) {
             if (pos >= n) return false;
-            n_seq = ((n_seq - 128) << 8) + p[pos++];
+            n_seq = ((n_seq - 128) << 8) + src.byte(base + pos++);
         } else {
             if (pos + 2 > n) return false;
-            n_seq = (uint32_t)p[pos] + ((uint32_t)p[pos + 1] << 8) + 0x7F00u;
+            n_seq = src.byte(base + pos) + (src.byte(base + pos + 1) << 8) + 0x7F00u;
             pos += 2;
         }
     }
     uint64_t lit_at = 0;
     auto put_literals = [&](uint64_t cnt) -> bool {
-        if (cnt > lit.n - lit_at || op + cnt > cap || op + cnt - block_start > ZS_BLOCK_MAX) return false;
-        if (lit.p) for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit.p[lit_at + k];
-        else for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit.rle;
+        if (cnt > (uint64_t)regen - lit_at || out.op + cnt > cap || out.op + cnt - block_start > ZS_BLOCK_MAX) return false;
+        if (type == 0) out.lit_src(src, lit_src_at + lit_at, cnt);
+        else if (type == 1) out.lit_rle(lit_rle, cnt);
+        else out.lit_buf(lit_buf + lit_at, cnt);
         lit_at += cnt;
-        op += cnt;
         return true;
     };
     if (n_seq) {
         if (pos >= n) return false;
-        const uint32_t modes = p[pos++];
+        const uint32_t modes = src.byte(base + pos++);
         if (modes & 3u) return false;                 // reserved bits
-        if (!zs_seq_table(w, 0, modes >> 6, p, n, &pos) || !zs_seq_table(w, 1, (modes >> 4) & 3u, p, n, &pos) ||
-            !zs_seq_table(w, 2, (modes >> 2) & 3u, p, n, &pos))
+        if (!zs_seq_table(w, 0, modes >> 6, src, base, n, &pos) || !zs_seq_table(w, 1, (modes >> 4) & 3u, src, base, n, &pos) ||
+            !zs_seq_table(w, 2, (modes >> 2) & 3u, src, base, n, &pos))
             return false;
         if (pos >= n) return false;
-        ZsBack b;
-        if (!zs_back_init(b, p + pos, n - pos)) return false;
+        ZsBack<S> b;
+        if (!zs_back_init(b, &src, base + pos, n - pos)) return false;
         uint32_t sl = (uint32_t)zs_back(b, w.ll_log), so = (uint32_t)zs_back(b, w.of_log), sm = (uint32_t)zs_back(b, w.ml_log);
         if (b.off < 0) return false;
         for (uint32_t i = 0; i < n_seq; i++) {
@@ -459,23 +548,22 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *dst,
             uint32_t ml_base, ml_bits;
             if (mc < 32) { ml_base = mc + 3; ml_bits = 0; }
             else {
-                const uint8_t bits[21] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-                const uint32_t base[21] = {35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195,
-                                           16387, 32771, 65539};
                 if (mc > 52) return false;
-                ml_base = base[mc - 32];
-                ml_bits = bits[mc - 32];
+                const uint32_t j = mc - 32;           // 0..20
+                // extra bits 1,1,1,1,2,2,3,3,4,4,5,7,8,...,16; baselines 35,37,39,41,43,47,51,59,67,83,99,131,259,...
+                ml_bits = j < 4 ? 1u : (j < 10 ? (j >> 1) : (j == 10 ? 5u : j - 4u));
+                ml_base = j < 4 ? 35u + 2u * j : (j < 6 ? 43u + 4u * (j - 4) : (j < 8 ? 51u + 8u * (j - 6) : (j < 10 ? 67u + 16u * (j - 8)
+                        : (j == 10 ? 99u : (1u << (j - 4u)) + 3u))));
             }
             const uint64_t mlen = ml_base + zs_back(b, ml_bits);
             uint32_t ll_base, ll_bits;
             if (lc < 16) { ll_base = lc; ll_bits = 0; }
             else {
-                const uint8_t bits[20] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-                const uint32_t base[20] = {16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384,
-                                           32768, 65536};
                 if (lc > 35) return false;
-                ll_base = base[lc - 16];
-                ll_bits = bits[lc - 16];
+                const uint32_t j = lc - 16;           // 0..19
+                // extra bits 1,1,1,1,2,2,3,3,4,6,7,...,16; baselines 16,18,20,22,24,28,32,40,48,64,128,...,65536
+                ll_bits = j < 4 ? 1u : (j < 8 ? (j >> 1) : (j == 8 ? 4u : j - 3u));
+                ll_base = j < 4 ? 16u + 2u * j : (j < 6 ? 24u + 4u * (j - 4) : (j < 8 ? 32u + 8u * (j - 6) : (j == 8 ? 48u : 1u << (j - 3u))));
             }
             const uint64_t llen = ll_base + zs_back(b, ll_bits);
             if (i + 1 < n_seq) {                      // state updates: literal length, match length, offset
@@ -494,24 +582,22 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, const uint8_t *p, uint64_t n, uint8_t *dst,
                 uint32_t idx = (uint32_t)ov - 1 + (llen == 0 ? 1u : 0u);
                 if (idx == 0) offset = rep[0];
                 else {
-                    offset = idx < 3 ? rep[idx] : rep[0] - 1;
+                    offset = idx < 3 ? (idx == 1 ? rep[1] : rep[2]) : rep[0] - 1;
                     if (idx > 1) rep[2] = rep[1];
                     rep[1] = rep[0];
                     rep[0] = offset;
                 }
             }
             if (!put_literals(llen)) return false;
-            if (offset == 0 || offset > op - frame_start || op + mlen > cap || op + mlen - block_start > ZS_BLOCK_MAX) return false;
-            zs_copy(dst, op, offset, mlen);
-            op += mlen;
+            if (offset == 0 || offset > out.op - frame_start || out.op + mlen > cap || out.op + mlen - block_start > ZS_BLOCK_MAX)
+                return false;
+            out.match(offset, mlen);
         }
         if (b.off != 0) return false;                 // the stream is consumed exactly
     } else if (pos != n) {
         return false;
     }
-    if (!put_literals(lit.n - lit_at)) return false;  // the literals after the last sequence
-    *op_io = op;
-    return true;
+    return put_literals((uint64_t)regen - lit_at);    // the literals after the last sequence
 }
 
 struct ZsFrame {
@@ -521,17 +607,19 @@ struct ZsFrame {
     bool checksum;
 };
 
-KTA_ZSTD_HD bool zs_frame_header(const uint8_t *p, uint64_t n, ZsFrame *f)
+template <class S>
+KTA_ZSTD_HD bool zs_frame_header(S &src, uint64_t base, uint64_t n, ZsFrame *f)
 {
-    if (n < 6 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return false;
-    const uint32_t fhd = p[4], fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    if (n < 6 || src.byte(base) != 0x28 || src.byte(base + 1) != 0xB5 || src.byte(base + 2) != 0x2F || src.byte(base + 3) != 0xFD)
+        return false;
+    const uint32_t fhd = src.byte(base + 4), fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
     if (fhd & 0x08) return false;                     // reserved bit
     if (did) return false;                            // dictionaries are not supported
     uint64_t pos = 5;
     f->window = 0;
     if (!single) {
         if (pos >= n) return false;
-        const uint32_t wd = p[pos++], wlog = 10 + (wd >> 3);
+        const uint32_t wd = src.byte(base + pos++), wlog = 10 + (wd >> 3);
         if (wlog > 31) return false;
         f->window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
     }
@@ -540,7 +628,7 @@ KTA_ZSTD_HD bool zs_frame_header(const uint8_t *p, uint64_t n, ZsFrame *f)
     f->content = ~0ull;
     if (fcs_bytes) {
         uint64_t v = 0;
-        for (uint32_t i = 0; i < fcs_bytes; i++) v |= (uint64_t)p[pos + i] << (8 * i);
+        for (uint32_t i = 0; i < fcs_bytes; i++) v |= (uint64_t)src.byte(base + pos + i) << (8 * i);
         if (fcs_bytes == 2) v += 256;
         f->content = v;
         pos += fcs_bytes;
@@ -558,9 +646,10 @@ KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64
 {
     uint64_t pos = 0, total = 0, max_lit = 0;
     if (n == 0) return false;
+    ZsMem src{p};
     while (pos < n) {
         ZsFrame f;
-        if (!zs_frame_header(p + pos, n - pos, &f)) return false;
+        if (!zs_frame_header(src, pos, n - pos, &f)) return false;
         pos += f.header;
         const uint64_t block_max = f.window < ZS_BLOCK_MAX ? f.window : ZS_BLOCK_MAX;
         uint64_t frame_bound = 0;
@@ -578,7 +667,7 @@ KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64
                 if (pos + size > n) return false;
                 if (type == 2) {
                     uint32_t lt, regen, comp, streams;
-                    if (!zs_lit_header(p + pos, size, &lt, &regen, &comp, &streams)) return false;
+                    if (!zs_lit_header(src, pos, size, &lt, &regen, &comp, &streams)) return false;
                     if (lt >= 2 && regen > max_lit) max_lit = regen;
                     frame_bound += block_max ? block_max : ZS_BLOCK_MAX;
                 } else {
@@ -599,39 +688,37 @@ KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64
     return true;
 }
 
-// Inflates the frames of one batch payload into dst[0 .. cap).  `lit`: scratch of at least the size
-// zstd_scan reported.  Returns the bytes produced or -1.
-KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWork *w, uint8_t *lit,
-                                 uint64_t lit_cap)
+// Inflates the frames of one batch payload — the bytes [0, n) of src — through `out` (room for cap bytes).
+// `lit`: scratch of at least the size zstd_scan reported.  Returns the bytes produced or -1.
+template <class S, class O>
+KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, ZsWork *w, uint8_t *lit, uint64_t lit_cap)
 {
-    uint64_t pos = 0, op = 0;
+    uint64_t pos = 0;
     if (n == 0) return -1;
     while (pos < n) {
         ZsFrame f;
-        if (!zs_frame_header(src + pos, n - pos, &f)) return -1;
+        if (!zs_frame_header(src, pos, n - pos, &f)) return -1;
         pos += f.header;
-        const uint64_t frame_start = op;
+        const uint64_t frame_start = out.op;
         uint64_t rep[3] = {1, 4, 8};
         w->have_ll = w->have_of = w->have_ml = w->have_huf = 0;
         while (true) {
             if (pos + 3 > n) return -1;
-            const uint32_t h = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+            const uint32_t h = src.byte(pos) | (src.byte(pos + 1) << 8) | (src.byte(pos + 2) << 16);
             pos += 3;
             const uint32_t type = (h >> 1) & 3, size = h >> 3;
             if (type == 3 || size > ZS_BLOCK_MAX) return -1;
             if (type == 0) {
-                if (pos + size > n || op + size > cap) return -1;
-                for (uint32_t k = 0; k < size; k++) dst[op + k] = src[pos + k];
-                op += size;
+                if (pos + size > n || out.op + size > cap) return -1;
+                out.lit_src(src, pos, size);
                 pos += size;
             } else if (type == 1) {
-                if (pos + 1 > n || op + size > cap) return -1;
-                for (uint32_t k = 0; k < size; k++) dst[op + k] = src[pos];
-                op += size;
+                if (pos + 1 > n || out.op + size > cap) return -1;
+                out.lit_rle((uint8_t)src.byte(pos), size);
                 pos += 1;
             } else {
                 if (pos + size > n) return -1;
-                if (!zs_block(*w, src + pos, size, dst, &op, cap, frame_start, rep, lit, lit_cap)) return -1;
+                if (!zs_block(*w, src, pos, size, out, cap, frame_start, rep, lit, lit_cap)) return -1;
                 pos += size;
             }
             if (h & 1) break;
@@ -640,9 +727,18 @@ KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
             if (pos + 4 > n) return -1;
             pos += 4;
         }
-        if (f.content != ~0ull && op - frame_start != f.content) return -1;
+        if (f.content != ~0ull && out.op - frame_start != f.content) return -1;
     }
-    return (int64_t)op;
+    return (int64_t)out.op;
+}
+
+// ... from plain memory into plain memory (the host; one lane of the device's lane-per-batch kernel)
+KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWork *w, uint8_t *lit,
+                                 uint64_t lit_cap)
+{
+    ZsMem s{src};
+    ZsOutMem o{dst, 0};
+    return zstd_inflate_t(s, n, o, cap, w, lit, lit_cap);
 }
 
 }  // namespace kta
