@@ -623,6 +623,180 @@ __global__ __launch_bounds__(kGzipLanes) void kafka_zstd_inflate(uint8_t *buffer
     else descs[b].payload_end = d.payload_off + (uint64_t)got;       // the slice was sized by a bound
 }
 
+// ---- zstd inflate, wave-cooperative: one wave per batch ------------------------------------------------
+// csrc/kta_zstd.h run by a whole wave: every lane parses the frame / block / table descriptions and decodes
+// the sequences redundantly (uniform work: the compressed bytes come through an LDS window that all 64 lanes
+// refill together, the FSE / Huffman tables are in LDS), and the parts with width use it — literals and
+// matches move 64 bytes per step through an LDS mirror of the last 8 KiB of output (further back: the
+// written output, behind a fence), the four Huffman streams of a literals section run on four lanes.
+// The policy methods are force-inlined: a call would pass `this` through memory, and the LDS address
+// spaces of the window, the ring and the tables would be lost (flat accesses, private-memory traffic).
+constexpr uint32_t kZsWin = 2048, kZsRing = 8192;
+constexpr uint64_t kZsNoWindow = 1ull << 62;       // (x - kZsNoWindow is huge for every buffer offset x: "not in the window")
+
+struct ZsWaveSrc {                 // byte source: the batch payload behind an LDS window (absolute buffer offsets)
+    const uint8_t *buffer;
+    uint64_t src0, src_end;        // the payload is buffer[src0 .. src_end)
+    uint4 *win4;
+    uint64_t wabs;                 // absolute offset of the window's first byte (16-byte aligned); kZsNoWindow: empty
+    uint32_t lane;
+
+    __device__ __forceinline__ const uint8_t *memory() const { return buffer + src0; }
+    __device__ __forceinline__ void fetch(uint64_t abs, uint32_t need)   // make [abs, abs + need) readable through the window
+    {
+        __syncthreads();
+        const uint64_t lo = src0 & ~15ull;
+        uint64_t base = abs & ~15ull;
+        if (wabs != kZsNoWindow && abs < wabs) {       // reading backwards (bit streams): the window ends just above
+            const uint64_t end = (abs + need + 15) & ~15ull;
+            base = end >= kZsWin + lo ? end - kZsWin : lo;
+        }
+        wabs = base;
+        const uint64_t last = ((src_end + 15) & ~15ull) - 16;          // last readable block of the batch
+        const uint4 *blocks = reinterpret_cast<const uint4 *>(buffer);
+        static_assert(kZsWin == 2048, "two 16-byte blocks per lane");
+        const uint64_t a0 = wabs + lane * 16, a1 = a0 + 1024;
+        const uint4 v0 = blocks[(a0 < last ? a0 : last) >> 4], v1 = blocks[(a1 < last ? a1 : last) >> 4];   // in flight together
+        win4[lane] = v0;
+        win4[lane + 64] = v1;
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t byte(uint64_t at)          // `at` is the same in every lane
+    {
+        const uint64_t abs = src0 + at;
+        if (abs - wabs >= kZsWin) fetch(abs, 1);   // (unsigned: also abs < wabs and the empty window)
+        return reinterpret_cast<const uint8_t *>(win4)[abs - wabs];
+    }
+    // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; outside the slice: zeros
+    __device__ __forceinline__ uint64_t le64(uint64_t base, uint64_t n, int64_t first)
+    {
+        const int64_t lo = first < 0 ? 0 : first, hi = first + 8 < (int64_t)n ? first + 8 : (int64_t)n;
+        if (lo >= hi) return 0;
+        const uint64_t a0 = src0 + base + (uint64_t)lo, a1 = src0 + base + (uint64_t)hi - 1;
+        if (a0 - wabs >= kZsWin || a1 - wabs >= kZsWin) fetch(a0, (uint32_t)(hi - lo));
+        const uint8_t *w = reinterpret_cast<const uint8_t *>(win4) + (src0 + base - wabs);   // (may wrap: indexed with k below)
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int64_t k = first + i;
+            if (k >= lo && k < hi) c |= (uint64_t)w[k] << (8 * i);
+        }
+        return c;
+    }
+};
+
+struct ZsOutWave {                 // output sink: 64 bytes per step, the last kZsRing bytes mirrored in LDS
+    uint8_t *dst;
+    uint64_t op;
+    uint8_t *ring;
+    uint32_t lane;
+
+    __device__ __forceinline__ void put(uint64_t i, uint8_t v)
+    {
+        dst[op + i] = v;
+        ring[(op + i) & (kZsRing - 1)] = v;
+    }
+    template <class S>
+    __device__ __forceinline__ void lit_src(S &src, uint64_t at, uint64_t cnt)
+    {
+        const uint8_t *p = src.memory() + at;
+        for (uint64_t i0 = 0; i0 < cnt; i0 += 256) {                 // four loads in flight per lane
+            uint8_t v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t i = i0 + lane + 64 * k;
+                v[k] = i < cnt ? p[i] : (uint8_t)0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t i = i0 + lane + 64 * k;
+                if (i < cnt) put(i, v[k]);
+            }
+        }
+        op += cnt;
+    }
+    __device__ __forceinline__ void lit_buf(const uint8_t *lit, uint64_t cnt)   // written by lanes of this wave (huf_streams): past L1
+    {
+        for (uint64_t i0 = 0; i0 < cnt; i0 += 256) {
+            uint8_t v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t i = i0 + lane + 64 * k;
+                v[k] = i < cnt ? __hip_atomic_load(lit + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t i = i0 + lane + 64 * k;
+                if (i < cnt) put(i, v[k]);
+            }
+        }
+        op += cnt;
+    }
+    __device__ __forceinline__ void lit_rle(uint8_t v, uint64_t cnt)
+    {
+        for (uint64_t i = lane; i < cnt; i += 64) put(i, v);
+        op += cnt;
+    }
+    __device__ __forceinline__ void match(uint64_t dist, uint64_t len)
+    {
+        for (uint64_t i0 = 0; i0 < len; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            // dist >= 64: this step's sources were written before it; dist < 64: index modulo the period
+            const uint64_t s = dist >= 64 ? op - dist + i : op - dist + (i % dist);
+            uint8_t v = 0;
+            if (dist <= kZsRing) {
+                if (i < len) v = ring[s & (kZsRing - 1)];
+            } else {
+                __threadfence();
+                if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (i < len) put(i, v);
+        }
+        op += len;
+    }
+    // the Huffman streams of a literals section, one lane each, straight from memory (a lane on its own cannot
+    // use the wave's window); the decoded literals are read back by all lanes (lit_buf)
+    template <class S>
+    __device__ __forceinline__ bool huf_streams(const kta::ZsWork &w, S &src, uint32_t streams, const uint64_t at[4],
+                                                const uint64_t n[4], const uint64_t count[4], uint8_t *out)
+    {
+        const uint64_t my_at = lane == 0 ? at[0] : (lane == 1 ? at[1] : (lane == 2 ? at[2] : at[3]));
+        const uint64_t my_n = lane == 0 ? n[0] : (lane == 1 ? n[1] : (lane == 2 ? n[2] : n[3]));
+        const uint64_t my_count = lane == 0 ? count[0] : (lane == 1 ? count[1] : (lane == 2 ? count[2] : count[3]));
+        const uint64_t my_out = lane == 0 ? 0 : (lane == 1 ? count[0] : (lane == 2 ? count[0] + count[1] : count[0] + count[1] + count[2]));
+        bool ok = true;
+        if (lane < streams) {
+            kta::ZsMem m{src.memory()};
+            ok = kta::zs_huf_stream(w, m, my_at, my_n, out + my_out, my_count);
+        }
+        __threadfence();
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+    }
+};
+
+__global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    __shared__ kta::ZsWork s_w;
+    __shared__ uint4 s_win[kZsWin / 16];
+    __shared__ uint8_t s_ring[kZsRing];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    if (b >= n_batches) return;
+    const kta_kafka_batch_desc d = descs[b];
+    if (!(d.flags & KTA_KB_ZSTD) || d.status) return;
+    const uint64_t src0 = d.byte_off + KTA_KAFKA_BATCH_HEADER, n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER;
+    const uint64_t cap = d.payload_end - d.payload_off;
+    const uint64_t scratch = ((d.payload_end + 63) & ~63ull) + kZstdWorkBytes;   // the literals of a Huffman-coded section
+    const uint64_t lit_cap = d.scratch_end > scratch ? d.scratch_end - scratch : 0;
+    ZsWaveSrc src{buffer, src0, src0 + n, s_win, kZsNoWindow, lane};
+    ZsOutWave out{buffer + d.payload_off, 0, s_ring, lane};
+    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, &s_w, buffer + scratch, lit_cap);
+    if (lane == 0) {
+        if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
+        else descs[b].payload_end = d.payload_off + (uint64_t)got;   // the slice was sized by a bound
+    }
+}
+
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
 // Elements are inherently sequential, but each one moves up to 64 bytes: the wave parses the tag
 // uniformly (compressed stream staged in an LDS window, so a tag costs LDS latency, not an L2 round
@@ -1391,14 +1565,6 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
             lane_codecs |= KTA_KB_SNAPPY | KTA_KB_LZ4;
         }
         if (any_gzip && st->variant != 1) {   // Huffman decoding one lane per batch, then the copies one wave per batch
-            static const int lanes_env = getenv("KTA_GZIP_LANES") ? atoi(getenv("KTA_GZIP_LANES")) : 0;   // (measurement aid)
-            if (lanes_env == 8)
-                hipLaunchKernelGGL((kafka_gzip_tokenize<8>), dim3((uint32_t)((n_batches + 7) / 8)), dim3(8), 0, s, buf, st->d_descs, n_batches);
-            else if (lanes_env == 22)
-                hipLaunchKernelGGL((kafka_gzip_tokenize<22>), dim3((uint32_t)((n_batches + 21) / 22)), dim3(22), 0, s, buf, st->d_descs, n_batches);
-            else if (lanes_env == 32)
-                hipLaunchKernelGGL((kafka_gzip_tokenize<32>), dim3((uint32_t)((n_batches + 31) / 32)), dim3(32), 0, s, buf, st->d_descs, n_batches);
-            else
             hipLaunchKernelGGL((kafka_gzip_tokenize<kGzTokLanes>), dim3((uint32_t)((n_batches + kGzTokLanes - 1) / kGzTokLanes)),
                                dim3(kGzTokLanes), 0, s, buf, st->d_descs, n_batches);
             hipLaunchKernelGGL(kafka_gzip_apply, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs, n_batches);
@@ -1406,7 +1572,9 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
             hipLaunchKernelGGL((kafka_gzip_inflate<kGzipLanes>), dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)),
                                dim3(kGzipLanes), 0, s, buf, st->d_descs, n_batches);
         }
-        if (any_zstd)     // bit-serial entropy stages: one lane per batch as well
+        if (any_zstd && st->variant != 1)
+            hipLaunchKernelGGL(kafka_zstd_inflate_coop, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, st->d_descs, n_batches);
+        else if (any_zstd)
             hipLaunchKernelGGL(kafka_zstd_inflate, dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)), dim3(kGzipLanes), 0,
                                s, buf, st->d_descs, n_batches);
         if (lane_codecs)

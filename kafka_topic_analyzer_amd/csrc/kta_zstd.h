@@ -65,27 +65,35 @@ KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
 struct ZsMem {
     const uint8_t *p;
     KTA_ZSTD_HD uint32_t byte(uint64_t at) { return p[at]; }
+    // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; bytes outside the slice are zero
+    KTA_ZSTD_HD uint64_t le64(uint64_t base, uint64_t n, int64_t first)
+    {
+        uint64_t c = 0;
+        for (int i = 0; i < 8; i++) {
+            const int64_t k = first + i;
+            if (k >= 0 && (uint64_t)k < n) c |= (uint64_t)p[base + (uint64_t)k] << (8 * i);
+        }
+        return c;
+    }
     KTA_ZSTD_HD const uint8_t *memory() const { return p; }     // (a wave source hands out its global pointer here)
 };
 
 // ---- forward (LSB first) bit reader: FSE table descriptions --------------------------------------------
-template <class S>
 struct ZsFwd {
-    S *src;
-    uint64_t base, n;   // the bytes [base, base + n) of src
+    uint64_t base, n;   // the bytes [base, base + n) of the source
     uint64_t bit;       // next bit
     bool bad;
 };
 
 template <class S>
-KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd<S> &f, uint32_t nb)   // nb <= 16
+KTA_ZSTD_HD uint32_t zs_fwd(S &src, ZsFwd &f, uint32_t nb)   // nb <= 16
 {
     uint32_t v = 0;
     for (uint32_t got = 0; got < nb;) {
         const uint64_t byte = f.bit >> 3;
         if (byte >= f.n) { f.bad = true; return 0; }
         const uint32_t sh = (uint32_t)(f.bit & 7), take = (8 - sh) < (nb - got) ? (8 - sh) : (nb - got);
-        v |= ((f.src->byte(f.base + byte) >> sh) & ((1u << take) - 1u)) << got;
+        v |= ((src.byte(f.base + byte) >> sh) & ((1u << take) - 1u)) << got;
         got += take;
         f.bit += take;
     }
@@ -96,9 +104,7 @@ KTA_ZSTD_HD uint32_t zs_fwd(ZsFwd<S> &f, uint32_t nb)   // nb <= 16
 // A 64-bit container holds the stream bits [lo, lo + 64), lo a multiple of 8 (bytes before the stream's first
 // are zeros); it is reloaded, eight bytes at once, when a read leaves it — about once per sequence or per
 // eight Huffman symbols instead of once per field.
-template <class S>
 struct ZsBack {
-    S *src;
     uint64_t base, n;
     int64_t off;        // bits [0, off) are unread; may go negative (zeros)
     uint64_t cont;
@@ -107,12 +113,11 @@ struct ZsBack {
 };
 
 template <class S>
-KTA_ZSTD_HD bool zs_back_init(ZsBack<S> &b, S *src, uint64_t base, uint64_t n)
+KTA_ZSTD_HD bool zs_back_init(S &src, ZsBack &b, uint64_t base, uint64_t n)
 {
     if (n == 0) return false;
-    const uint32_t last = src->byte(base + n - 1);
+    const uint32_t last = src.byte(base + n - 1);
     if (last == 0) return false;
-    b.src = src;
     b.base = base;
     b.n = n;
     b.off = (int64_t)(8 * (n - 1)) + (int64_t)zs_highbit(last);
@@ -123,7 +128,7 @@ KTA_ZSTD_HD bool zs_back_init(ZsBack<S> &b, S *src, uint64_t base, uint64_t n)
 }
 
 template <class S>
-KTA_ZSTD_HD uint64_t zs_back(ZsBack<S> &b, uint32_t nb)   // nb <= 32
+KTA_ZSTD_HD uint64_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
 {
     b.off -= (int64_t)nb;
     if (nb == 0) return 0;
@@ -131,12 +136,7 @@ KTA_ZSTD_HD uint64_t zs_back(ZsBack<S> &b, uint32_t nb)   // nb <= 32
     if (!b.loaded || at < b.lo || at + (int64_t)nb > b.lo + 64) {
         // the container ends at the byte boundary at or above at + nb: reads go downwards from here
         const int64_t byte_hi = (at + (int64_t)nb + 7) >> 3, byte_lo = byte_hi - 8;
-        uint64_t c = 0;
-        for (int i = 0; i < 8; i++) {
-            const int64_t k = byte_lo + i;
-            if (k >= 0 && (uint64_t)k < b.n) c |= (uint64_t)b.src->byte(b.base + (uint64_t)k) << (8 * i);
-        }
-        b.cont = c;
+        b.cont = src.le64(b.base, b.n, byte_lo);
         b.lo = byte_lo * 8;
         b.loaded = true;
     }
@@ -146,15 +146,15 @@ KTA_ZSTD_HD uint64_t zs_back(ZsBack<S> &b, uint32_t nb)   // nb <= 32
 // ---- FSE ----------------------------------------------------------------------------------------------------
 // Reads a table description (normalized counts) into w.norm; returns the accuracy log, 0 on error.
 template <class S>
-KTA_ZSTD_HD uint32_t zs_read_norm(ZsFwd<S> &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
+KTA_ZSTD_HD uint32_t zs_read_norm(S &src, ZsFwd &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
 {
-    const uint32_t log = 5 + zs_fwd(f, 4);
+    const uint32_t log = 5 + zs_fwd(src, f, 4);
     if (f.bad || log > max_log) return 0;
     int32_t remaining = 1 << log;
     uint32_t s = 0;
     while (remaining > 0 && s <= max_sym) {
         const uint32_t bits = zs_highbit((uint32_t)remaining + 1) + 1;
-        uint32_t val = zs_fwd(f, bits);
+        uint32_t val = zs_fwd(src, f, bits);
         if (f.bad) return 0;
         const uint32_t lower = (1u << (bits - 1)) - 1u;
         const uint32_t threshold = (1u << bits) - 1u - ((uint32_t)remaining + 1u);
@@ -168,11 +168,11 @@ KTA_ZSTD_HD uint32_t zs_read_norm(ZsFwd<S> &f, ZsWork &w, uint32_t max_log, uint
         remaining -= proba < 0 ? 1 : proba;
         w.norm[s++] = (int16_t)proba;
         if (proba == 0) {                           // runs of zero probabilities: 2-bit repeat counts
-            uint32_t rep = zs_fwd(f, 2);
+            uint32_t rep = zs_fwd(src, f, 2);
             while (true) {
                 for (uint32_t i = 0; i < rep && s <= max_sym; i++) w.norm[s++] = 0;
                 if (rep != 3) break;
-                rep = zs_fwd(f, 2);
+                rep = zs_fwd(src, f, 2);
                 if (f.bad) return 0;
             }
         }
@@ -253,9 +253,9 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         return true;
     }
     if (mode == 2) {
-        ZsFwd<S> f{&src, base + *pos, n - *pos, 0, false};
+        ZsFwd f{base + *pos, n - *pos, 0, false};
         uint32_t n_sym = 0;
-        const uint32_t l = zs_read_norm(f, w, max_log, max_sym, &n_sym);
+        const uint32_t l = zs_read_norm(src, f, w, max_log, max_sym, &n_sym);
         if (!l) return false;
         *pos += f.bit >> 3;
         log = (uint8_t)l;
@@ -285,23 +285,23 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
     } else {                                          // FSE coded weights, two interleaved states
         used = 1 + hb;
         if (hb == 0 || used > n) return 0;
-        ZsFwd<S> f{&src, base + 1, hb, 0, false};
+        ZsFwd f{base + 1, hb, 0, false};
         uint32_t n_sym = 0;
-        const uint32_t log = zs_read_norm(f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
+        const uint32_t log = zs_read_norm(src, f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
         if (!log || !zs_build_fse(w, w.wfse, log, n_sym)) return 0;
         const uint64_t at = f.bit >> 3;
         if (at >= hb) return 0;
-        ZsBack<S> b;
-        if (!zs_back_init(b, &src, base + 1 + at, hb - at)) return 0;
-        uint32_t s1 = (uint32_t)zs_back(b, log), s2 = (uint32_t)zs_back(b, log);
+        ZsBack b;
+        if (!zs_back_init(src, b, base + 1 + at, hb - at)) return 0;
+        uint32_t s1 = (uint32_t)zs_back(src, b, log), s2 = (uint32_t)zs_back(src, b, log);
         if (b.off < 0) return 0;
         while (true) {
             if (n_w >= 254) return 0;
             w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF);
-            s1 = (w.wfse[s1] >> 16) + (uint32_t)zs_back(b, (w.wfse[s1] >> 8) & 0xFF);
+            s1 = (w.wfse[s1] >> 16) + (uint32_t)zs_back(src, b, (w.wfse[s1] >> 8) & 0xFF);
             if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF); break; }
             w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF);
-            s2 = (w.wfse[s2] >> 16) + (uint32_t)zs_back(b, (w.wfse[s2] >> 8) & 0xFF);
+            s2 = (w.wfse[s2] >> 16) + (uint32_t)zs_back(src, b, (w.wfse[s2] >> 8) & 0xFF);
             if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF); break; }
         }
     }
@@ -341,15 +341,15 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
 template <class S>
 KTA_ZSTD_HD bool zs_huf_stream(const ZsWork &w, S &src, uint64_t base, uint64_t n, uint8_t *out, uint64_t count)
 {
-    ZsBack<S> b;
-    if (!zs_back_init(b, &src, base, n)) return false;
+    ZsBack b;
+    if (!zs_back_init(src, b, base, n)) return false;
     const uint32_t log = w.huf_log, mask = (1u << log) - 1u;
-    uint32_t state = (uint32_t)zs_back(b, log);
+    uint32_t state = (uint32_t)zs_back(src, b, log);
     for (uint64_t i = 0; i < count; i++) {
         if (b.off <= -(int64_t)log) return false;    // more symbols wanted than the stream holds
         const uint32_t e = w.huf[state], nb = e >> 8;
         out[i] = (uint8_t)e;
-        state = ((state << nb) | (uint32_t)zs_back(b, nb)) & mask;
+        state = ((state << nb) | (uint32_t)zs_back(src, b, nb)) & mask;
     }
     return b.off == -(int64_t)log;                    // every bit consumed, none invented
 }
@@ -451,6 +451,27 @@ struct ZsOutMem {
     }
 };
 
+// The literals of a block being handed out to its sequences.
+struct ZsLits {
+    uint32_t type, regen;
+    uint64_t at;            // literals handed out so far
+    uint64_t src_at;        // raw: where they start in the source
+    uint8_t rle;
+    uint8_t *buf;           // Huffman coded: decoded here
+    uint64_t block_start, cap;
+};
+
+template <class S, class O>
+KTA_ZSTD_HD bool zs_put_literals(ZsLits &l, S &src, O &out, uint64_t cnt)
+{
+    if (cnt > (uint64_t)l.regen - l.at || out.op + cnt > l.cap || out.op + cnt - l.block_start > ZS_BLOCK_MAX) return false;
+    if (l.type == 0) out.lit_src(src, l.src_at + l.at, cnt);
+    else if (l.type == 1) out.lit_rle(l.rle, cnt);
+    else out.lit_buf(l.buf + l.at, cnt);
+    l.at += cnt;
+    return true;
+}
+
 // One compressed block: the bytes [base, base + n) of src, appended through `out`.  `cap`: room of the whole
 // output; `frame_start`: output position where the frame began (offsets may not reach before it).
 template <class S, class O>
@@ -518,15 +539,7 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
             pos += 2;
         }
     }
-    uint64_t lit_at = 0;
-    auto put_literals = [&](uint64_t cnt) -> bool {
-        if (cnt > (uint64_t)regen - lit_at || out.op + cnt > cap || out.op + cnt - block_start > ZS_BLOCK_MAX) return false;
-        if (type == 0) out.lit_src(src, lit_src_at + lit_at, cnt);
-        else if (type == 1) out.lit_rle(lit_rle, cnt);
-        else out.lit_buf(lit_buf + lit_at, cnt);
-        lit_at += cnt;
-        return true;
-    };
+    ZsLits lits{type, regen, 0, lit_src_at, lit_rle, lit_buf, block_start, cap};
     if (n_seq) {
         if (pos >= n) return false;
         const uint32_t modes = src.byte(base + pos++);
@@ -535,15 +548,15 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
             !zs_seq_table(w, 2, (modes >> 2) & 3u, src, base, n, &pos))
             return false;
         if (pos >= n) return false;
-        ZsBack<S> b;
-        if (!zs_back_init(b, &src, base + pos, n - pos)) return false;
-        uint32_t sl = (uint32_t)zs_back(b, w.ll_log), so = (uint32_t)zs_back(b, w.of_log), sm = (uint32_t)zs_back(b, w.ml_log);
+        ZsBack b;
+        if (!zs_back_init(src, b, base + pos, n - pos)) return false;
+        uint32_t sl = (uint32_t)zs_back(src, b, w.ll_log), so = (uint32_t)zs_back(src, b, w.of_log), sm = (uint32_t)zs_back(src, b, w.ml_log);
         if (b.off < 0) return false;
         for (uint32_t i = 0; i < n_seq; i++) {
             const uint32_t el = w.ll[sl], eo = w.of[so], em = w.ml[sm];
             const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
             if (oc > 31) return false;
-            const uint64_t ov = (1ull << oc) + zs_back(b, oc);
+            const uint64_t ov = (1ull << oc) + zs_back(src, b, oc);
             // match length: codes 0..31 are 3 + code; then baselines with 1,1,1,1,2,2,3,3,4,4,5,7,8,...,16 extra bits
             uint32_t ml_base, ml_bits;
             if (mc < 32) { ml_base = mc + 3; ml_bits = 0; }
@@ -555,7 +568,7 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
                 ml_base = j < 4 ? 35u + 2u * j : (j < 6 ? 43u + 4u * (j - 4) : (j < 8 ? 51u + 8u * (j - 6) : (j < 10 ? 67u + 16u * (j - 8)
                         : (j == 10 ? 99u : (1u << (j - 4u)) + 3u))));
             }
-            const uint64_t mlen = ml_base + zs_back(b, ml_bits);
+            const uint64_t mlen = ml_base + zs_back(src, b, ml_bits);
             uint32_t ll_base, ll_bits;
             if (lc < 16) { ll_base = lc; ll_bits = 0; }
             else {
@@ -565,11 +578,11 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
                 ll_bits = j < 4 ? 1u : (j < 8 ? (j >> 1) : (j == 8 ? 4u : j - 3u));
                 ll_base = j < 4 ? 16u + 2u * j : (j < 6 ? 24u + 4u * (j - 4) : (j < 8 ? 32u + 8u * (j - 6) : (j == 8 ? 48u : 1u << (j - 3u))));
             }
-            const uint64_t llen = ll_base + zs_back(b, ll_bits);
+            const uint64_t llen = ll_base + zs_back(src, b, ll_bits);
             if (i + 1 < n_seq) {                      // state updates: literal length, match length, offset
-                sl = (el >> 16) + (uint32_t)zs_back(b, (el >> 8) & 0xFF);
-                sm = (em >> 16) + (uint32_t)zs_back(b, (em >> 8) & 0xFF);
-                so = (eo >> 16) + (uint32_t)zs_back(b, (eo >> 8) & 0xFF);
+                sl = (el >> 16) + (uint32_t)zs_back(src, b, (el >> 8) & 0xFF);
+                sm = (em >> 16) + (uint32_t)zs_back(src, b, (em >> 8) & 0xFF);
+                so = (eo >> 16) + (uint32_t)zs_back(src, b, (eo >> 8) & 0xFF);
             }
             if (b.off < 0) return false;
             uint64_t offset;
@@ -588,7 +601,7 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
                     rep[0] = offset;
                 }
             }
-            if (!put_literals(llen)) return false;
+            if (!zs_put_literals(lits, src, out, llen)) return false;
             if (offset == 0 || offset > out.op - frame_start || out.op + mlen > cap || out.op + mlen - block_start > ZS_BLOCK_MAX)
                 return false;
             out.match(offset, mlen);
@@ -597,7 +610,7 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
     } else if (pos != n) {
         return false;
     }
-    return put_literals((uint64_t)regen - lit_at);    // the literals after the last sequence
+    return zs_put_literals(lits, src, out, (uint64_t)regen - lits.at);    // the literals after the last sequence
 }
 
 struct ZsFrame {
