@@ -83,20 +83,36 @@ struct ZsFwd {
     uint64_t base, n;   // the bytes [base, base + n) of the source
     uint64_t bit;       // next bit
     bool bad;
+    uint64_t cont;      // the stream bits [lo, lo + 64), lo a multiple of 8 (zeros past the end): one load per 6+ bytes
+    uint64_t lo;
+    bool loaded;
 };
+
+KTA_ZSTD_HD ZsFwd zs_fwd_init(uint64_t base, uint64_t n)
+{
+    ZsFwd f;
+    f.base = base;
+    f.n = n;
+    f.bit = 0;
+    f.bad = false;
+    f.cont = 0;
+    f.lo = 0;
+    f.loaded = false;
+    return f;
+}
 
 template <class S>
 KTA_ZSTD_HD uint32_t zs_fwd(S &src, ZsFwd &f, uint32_t nb)   // nb <= 16
 {
-    uint32_t v = 0;
-    for (uint32_t got = 0; got < nb;) {
-        const uint64_t byte = f.bit >> 3;
-        if (byte >= f.n) { f.bad = true; return 0; }
-        const uint32_t sh = (uint32_t)(f.bit & 7), take = (8 - sh) < (nb - got) ? (8 - sh) : (nb - got);
-        v |= ((src.byte(f.base + byte) >> sh) & ((1u << take) - 1u)) << got;
-        got += take;
-        f.bit += take;
+    if (nb == 0) return 0;
+    if (f.bit + nb > 8 * f.n) { f.bad = true; return 0; }
+    if (!f.loaded || f.bit < f.lo || f.bit + nb > f.lo + 64) {
+        f.lo = f.bit & ~7ull;
+        f.cont = src.le64(f.base, f.n, (int64_t)(f.lo >> 3));
+        f.loaded = true;
     }
+    const uint32_t v = (uint32_t)(f.cont >> (uint32_t)(f.bit - f.lo)) & ((1u << nb) - 1u);
+    f.bit += nb;
     return v;
 }
 
@@ -253,7 +269,7 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         return true;
     }
     if (mode == 2) {
-        ZsFwd f{base + *pos, n - *pos, 0, false};
+        ZsFwd f = zs_fwd_init(base + *pos, n - *pos);
         uint32_t n_sym = 0;
         const uint32_t l = zs_read_norm(src, f, w, max_log, max_sym, &n_sym);
         if (!l) return false;
@@ -285,7 +301,7 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
     } else {                                          // FSE coded weights, two interleaved states
         used = 1 + hb;
         if (hb == 0 || used > n) return 0;
-        ZsFwd f{base + 1, hb, 0, false};
+        ZsFwd f = zs_fwd_init(base + 1, hb);
         uint32_t n_sym = 0;
         const uint32_t log = zs_read_norm(src, f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
         if (!log || !zs_build_fse(w, w.wfse, log, n_sym)) return 0;
