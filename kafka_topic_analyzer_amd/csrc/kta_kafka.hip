@@ -489,49 +489,51 @@ __global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_ka
 struct LzWindow {
     uint4 *ring4;          // LDS, kLzRing bytes
     uint8_t *dst;          // the batch's slice (64-byte aligned)
-    uint64_t total;        // bytes of output
-    uint64_t c0;           // the chunk [c0, c0 + kLzChunk) is in the ring and not yet written back
+    uint32_t total;        // bytes of output (< 2 GiB)
+    uint32_t c0;           // the chunk [c0, c0 + kLzChunk) is in the ring and not yet written back
     uint32_t lane;
 
-    __device__ uint8_t *ring() const { return reinterpret_cast<uint8_t *>(ring4); }
-    __device__ void load(uint64_t at)           // chunk `at` (literals in place) -> ring
+    __device__ __forceinline__ uint8_t *ring() const { return reinterpret_cast<uint8_t *>(ring4); }
+    __device__ __forceinline__ void load(uint32_t at)           // chunk `at` (literals in place) -> ring
     {
+        static_assert(kLzChunk == 4096, "four 16-byte units per lane");
         c0 = at;
-        const uint64_t last = ((total + 15) & ~15ull) - 16;      // last 16-byte unit of the slice (total > 0)
-        uint4 v[kLzChunk / 1024];
-#pragma unroll
-        for (uint32_t k = 0; k < kLzChunk / 1024; k++) {
-            const uint64_t off = at + (uint64_t)(k * 64 + lane) * 16;
-            v[k] = *reinterpret_cast<const uint4 *>(dst + (off < last ? off : last));
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kLzChunk / 1024; k++)
-            ring4[((at + (uint64_t)(k * 64 + lane) * 16) & (kLzRing - 1)) >> 4] = v[k];
+        const uint32_t last = ((total + 15u) & ~15u) - 16u;      // last 16-byte unit of the slice (total > 0)
+        const uint32_t o0 = at + lane * 16u, o1 = o0 + 1024u, o2 = o0 + 2048u, o3 = o0 + 3072u;
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(dst + (o0 < last ? o0 : last));   // in flight together
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(dst + (o1 < last ? o1 : last));
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(dst + (o2 < last ? o2 : last));
+        const uint4 v3 = *reinterpret_cast<const uint4 *>(dst + (o3 < last ? o3 : last));
+        ring4[(o0 & (kLzRing - 1)) >> 4] = v0;
+        ring4[(o1 & (kLzRing - 1)) >> 4] = v1;
+        ring4[(o2 & (kLzRing - 1)) >> 4] = v2;
+        ring4[(o3 & (kLzRing - 1)) >> 4] = v3;
         __syncthreads();
     }
-    __device__ void advance()                   // write the chunk back, take the next one
+    __device__ __forceinline__ void advance()                   // write the chunk back, take the next one
     {
         __syncthreads();
 #pragma unroll
         for (uint32_t k = 0; k < kLzChunk / 1024; k++) {
-            const uint64_t off = c0 + (uint64_t)(k * 64 + lane) * 16;
+            const uint32_t off = c0 + (k * 64 + lane) * 16u;
             if (off < total) *reinterpret_cast<uint4 *>(dst + off) = ring4[(off & (kLzRing - 1)) >> 4];
         }
         if (c0 + kLzChunk < total) load(c0 + kLzChunk);
         else c0 += kLzChunk;
     }
     // out[op .. op + len) = out[op - dist ..), op inside or after the current chunk; dist <= op, op + len <= total
-    __device__ void match(uint64_t op, uint64_t dist, uint64_t len)
+    __device__ __forceinline__ void match(uint32_t op, uint32_t dist, uint32_t len)
     {
         while (len) {
             while (op >= c0 + kLzChunk) advance();
-            uint64_t n = c0 + kLzChunk - op;
+            uint32_t n = c0 + kLzChunk - op;
             n = n < len ? n : len;
-            if (n > 64 && dist >= 64 && op - dist + kLzRing >= c0 + kLzChunk) {
+            const bool in_ring = op - dist + kLzRing >= c0 + kLzChunk;   // the whole source is in the ring
+            if (n > 64 && dist >= 64 && in_ring) {
                 // up to four steps whose sources are all final already (the copy does not reach into itself
                 // within them): their reads go out together, one LDS round trip instead of four
-                uint32_t m = n < 256 ? (uint32_t)n : 256u;
-                m = dist < m ? (uint32_t)dist : m;
+                uint32_t m = n < 256 ? n : 256u;
+                m = dist < m ? dist : m;
                 uint8_t v[4];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
@@ -549,9 +551,9 @@ struct LzWindow {
             }
             n = n < 64 ? n : 64;
             // byte i of the step: source index repeats with period `dist` when the copy overlaps itself
-            const uint64_t s = op - dist + (dist >= 64 ? lane : lane % (uint32_t)dist);
+            const uint32_t s = op - dist + (dist >= 64 ? lane : lane % dist);
             uint8_t v = 0;
-            if (op - dist + kLzRing >= c0 + kLzChunk) {            // the whole step's source is in the ring
+            if (in_ring) {
                 if (lane < n) v = ring()[s & (kLzRing - 1)];
             } else {                                               // further back: written back already (kLzRing >= chunk + 64)
                 __threadfence();
@@ -562,7 +564,7 @@ struct LzWindow {
             len -= n;
         }
     }
-    __device__ void finish()                    // everything up to `total` written back
+    __device__ __forceinline__ void finish()                    // everything up to `total` written back
     {
         while (c0 < total) advance();
     }
@@ -576,13 +578,13 @@ __global__ __launch_bounds__(64) void kafka_gzip_apply(uint8_t *buffer, kta_kafk
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
     if (!(d.flags & KTA_KB_GZIP) || d.status || d.payload_end == d.payload_off) return;
-    const uint64_t total = d.payload_end - d.payload_off;
+    const uint32_t total = (uint32_t)(d.payload_end - d.payload_off);          // (the index caps a batch at 512 MiB)
     const uint32_t *tok = reinterpret_cast<const uint32_t *>(buffer + ((d.payload_end + 63) & ~63ull));
     const uint32_t n_tok = tok[0];
     if (n_tok == 0) return;                                    // literals only: stage 1 wrote everything
     LzWindow w{s_ring, buffer + d.payload_off, total, 0, lane};
     w.load(0);
-    uint64_t op = 0;
+    uint32_t op = 0;
     bool bad = false;
     for (uint32_t t0 = 0; t0 < n_tok && !bad; t0 += 64) {
         const uint32_t mine = t0 + lane < n_tok ? tok[2 + t0 + lane] : 0u;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(64) void kafka_gzip_apply(uint8_t *buffer, kta_kafk
             const uint32_t len = (tk >> 8) & 511u, dist = (tk >> 17) + 1u;
             op += tk & 255u;
             if (!len) continue;
-            if (dist > op || op + len > total) { bad = true; break; }   // (stage 1 accepted only tokens inside the output)
+            if (op > total || dist > op || len > total - op) { bad = true; break; }   // (stage 1 accepts only tokens inside the output)
             w.match(op, dist, len);
             op += len;
         }
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(kGzipLanes) void kafka_zstd_inflate(uint8_t *buffer
 // written output, behind a fence), the four Huffman streams of a literals section run on four lanes.
 // The policy methods are force-inlined: a call would pass `this` through memory, and the LDS address
 // spaces of the window, the ring and the tables would be lost (flat accesses, private-memory traffic).
-constexpr uint32_t kZsWin = 2048, kZsRing = 8192;
+constexpr uint32_t kZsWin = 2048;
 constexpr uint64_t kZsNoWindow = 1ull << 62;       // (x - kZsNoWindow is huge for every buffer offset x: "not in the window")
 
 struct ZsWaveSrc {                 // byte source: the batch payload behind an LDS window (absolute buffer offsets)
@@ -685,6 +687,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
     }
 };
 
+template <uint32_t kZsRing>
 struct ZsOutWave {                 // output sink: 64 bytes per step, the last kZsRing bytes mirrored in LDS
     uint8_t *dst;
     uint64_t op;
@@ -774,11 +777,10 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     }
 };
 
-__global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+template <uint32_t kZsRing>
+__device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches, kta::ZsWork *s_w,
+                                                  uint4 *s_win, uint8_t *s_ring)
 {
-    __shared__ kta::ZsWork s_w;
-    __shared__ uint4 s_win[kZsWin / 16];
-    __shared__ uint8_t s_ring[kZsRing];
     const uint32_t lane = threadIdx.x;
     const uint64_t b = blockIdx.x;
     if (b >= n_batches) return;
@@ -789,12 +791,20 @@ __global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, k
     const uint64_t scratch = ((d.payload_end + 63) & ~63ull) + kZstdWorkBytes;   // the literals of a Huffman-coded section
     const uint64_t lit_cap = d.scratch_end > scratch ? d.scratch_end - scratch : 0;
     ZsWaveSrc src{buffer, src0, src0 + n, s_win, kZsNoWindow, lane};
-    ZsOutWave out{buffer + d.payload_off, 0, s_ring, lane};
-    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, &s_w, buffer + scratch, lit_cap);
+    ZsOutWave<kZsRing> out{buffer + d.payload_off, 0, s_ring, lane};
+    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, s_w, buffer + scratch, lit_cap);
     if (lane == 0) {
         if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
         else descs[b].payload_end = d.payload_off + (uint64_t)got;   // the slice was sized by a bound
     }
+}
+
+__global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    __shared__ kta::ZsWork s_w;
+    __shared__ uint4 s_win[kZsWin / 16];
+    __shared__ uint8_t s_ring[8192];
+    zstd_inflate_wave<8192>(buffer, descs, n_batches, &s_w, s_win, s_ring);
 }
 
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
