@@ -176,7 +176,7 @@ uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 
 /* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and
  * their mean size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch
- * inflate), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
+ * inflate kernels of all four codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
  * 5 = 8 batches per wave (1 KiB windows). */
 int kta_kafka_set_variant(kta_ctx *ctx, int variant);
 

@@ -4,9 +4,15 @@
 //   host    kta_kafka_index_host      walks the 61-byte batch headers, sizes the inflate slices
 //   device  kafka_crc32c              optional CRC-32C check (librdkafka's check.crcs), one wave per batch
 //           kafka_snappy_inflate_coop / kafka_lz4_inflate_coop   wave-cooperative inflate (64 bytes per step)
-//           kafka_gzip_inflate / kafka_zstd_inflate              bit-serial entropy stages: one lane per batch
+//           kafka_gzip_tokenize<L> + kafka_gzip_apply            gzip in two stages: Huffman decoding one lane per
+//                                                                batch (literals in place, matches as tokens),
+//                                                                then the copies one wave per batch
+//           kafka_zstd_inflate_coop                              zstd one wave per batch (uniform parsing, LDS tables,
+//                                                                64-byte copy steps, Huffman streams on four lanes)
 //           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows
-//           kafka_decode / kafka_inflate_lane                    one-lane-per-batch forms kept for comparison
+//           kafka_decode / kafka_inflate_lane / kafka_gzip_inflate / kafka_zstd_inflate
+//                                                                one-lane-per-batch forms kept for comparison
+//                                                                (kta_kafka_set_variant 1)
 //   host    kta_kafka_blob_acquire / _submit / kta_kafka_consume   pinned staging ring -> PCIe -> the above ->
 //                                                                  kta_submit_device (both handlers)
 //

@@ -751,6 +751,60 @@ def test_device_gzip_and_zstd_copy_paths():
 
 
 @pytest.mark.gpu
+def test_device_inflate_verdicts_on_mutated_gzip_and_zstd_streams():
+    """The wave / lane executions of the gzip and zstd decoders against the host execution of the same text, on
+    damaged streams: a batch whose stream the host function refuses must come back flagged (all of its records
+    partition -1), undamaged batches must decode as before, and nothing may fault or hang — for both kernel
+    families (variant 0: two-stage gzip, wave zstd; variant 1: one lane per batch)."""
+    pytest.importorskip("pyarrow")
+    import ctypes as C2
+    lib = N.load()
+    rng = np.random.default_rng(314)
+    text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(2500))
+    noise = bytes(rng.integers(0, 256, size=6000, dtype=np.uint8))
+    recs = [(0, b"k0", text[:20000]), (1, b"k1", noise), (2, b"k2", text[20000:50000] + noise[:900]), (3, None, b"\0" * 9000)]
+    codecs = ["gzip", "zstd", "gzip-fixed", "zstd-19", "zstd-stream", "gzip"] * 6
+    batches = [K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c) for i, c in enumerate(codecs)]
+    blob = bytearray(b"".join(batches))
+    rc, descs, st = index_host(bytes(blob), 1)
+    assert rc == N.KTA_OK and st.n_batches == len(codecs)
+    damaged = set(range(0, len(codecs), 2)) | {1}
+    for b in sorted(damaged):                                   # one to three damaged bytes inside the compressed payload
+        lo, hi = descs[b].byte_off + 61 + 12, descs[b].byte_off + descs[b].batch_bytes - 8
+        for _ in range(int(rng.integers(1, 4))):
+            blob[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
+    blob = bytes(blob)
+    rc, descs, st = index_host(blob, 1)                          # (sizes come from headers / trailers the damage spared)
+    assert rc == N.KTA_OK and st.n_batches == len(codecs)
+    refused = []
+    for b in range(len(codecs)):
+        d = descs[b]
+        comp = blob[d.byte_off + 61:d.byte_off + d.batch_bytes]
+        cap = d.payload_end - d.payload_off
+        out = C2.create_string_buffer(cap + 1)
+        if codecs[b].startswith("gzip"):
+            refused.append(d.status != 0 or lib.kta_gzip_inflate_host(comp, len(comp), out, cap) != cap)
+        else:
+            refused.append(d.status != 0 or lib.kta_zstd_inflate_host(comp, len(comp), out, cap) < 0)
+    assert any(refused) and not all(refused[b] for b in damaged)          # both outcomes are in the sample
+    assert not any(refused[b] for b in range(len(codecs)) if b not in damaged)
+    want, _ = kafka_decode(b"".join(batches), 1)
+    for variant in (0, 1):
+        with kta.HipMetricHandler(2, now=NOW) as h:
+            h._check(lib.kta_kafka_set_variant(h._ctx, variant))
+            cols, st2, bad = _decode_on_device(h, blob, 1, False)
+            assert bad >= sum(refused)
+            for b in range(len(codecs)):
+                part = cols["partition"][b * len(recs):(b + 1) * len(recs)]
+                if refused[b]:
+                    assert (part == -1).all(), (variant, b, codecs[b])
+                elif b not in damaged:
+                    assert (part == 1).all(), (variant, b, codecs[b])
+                    for k in ("key_len", "val_len", "ts_ms"):
+                        assert np.array_equal(cols[k][b * len(recs):(b + 1) * len(recs)], want[k][b * len(recs):(b + 1) * len(recs)])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("inflate_limit", [0, 150_000])
 def test_consume_snappy_record_sets_end_to_end(inflate_limit):
     """All codecs through the staging pipeline; with a small inflate limit the batches of a blob are
