@@ -650,6 +650,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
     uint32_t lane;
 
     __device__ __forceinline__ const uint8_t *memory() const { return buffer + src0; }
+    __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
     __device__ __forceinline__ void fetch(uint64_t abs, uint32_t need)   // make [abs, abs + need) readable through the window
     {
         __syncthreads();
@@ -673,7 +674,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
     {
         const uint64_t abs = src0 + at;
         if (abs - wabs >= kZsWin) fetch(abs, 1);   // (unsigned: also abs < wabs and the empty window)
-        return reinterpret_cast<const uint8_t *>(win4)[abs - wabs];
+        return uni(reinterpret_cast<const uint8_t *>(win4)[abs - wabs]);
     }
     // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; outside the slice: zeros
     __device__ __forceinline__ uint64_t le64(uint64_t base, uint64_t n, int64_t first)
@@ -689,7 +690,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
             const int64_t k = first + i;
             if (k >= lo && k < hi) c |= (uint64_t)w[k] << (8 * i);
         }
-        return c;
+        return (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
     }
 };
 
@@ -750,8 +751,9 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     {
         for (uint64_t i0 = 0; i0 < len; i0 += 64) {
             const uint64_t i = i0 + lane;
-            // dist >= 64: this step's sources were written before it; dist < 64: index modulo the period
-            const uint64_t s = dist >= 64 ? op - dist + i : op - dist + (i % dist);
+            // dist >= 64: this step's sources were written before it; dist < 64: the period just before this step
+            // (not the one before the whole match: a match longer than the ring has overwritten that one)
+            const uint64_t s = dist >= 64 ? op - dist + i : op + i0 - dist + (lane % (uint32_t)dist);
             uint8_t v = 0;
             if (dist <= kZsRing) {
                 if (i < len) v = ring[s & (kZsRing - 1)];
@@ -997,8 +999,9 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
         for (uint64_t i0 = 0; i0 < len; i0 += 64) {
             const uint64_t i = i0 + lane;
             uint8_t v = 0;
-            // off >= 64: this step's sources were written before it; off < 64: index modulo the period
-            const uint64_t s = off >= 64 ? op - off + i : op - off + (i % off);
+            // off >= 64: this step's sources were written before it; off < 64: the period just before this step
+            // (not the one before the whole match: a match longer than the ring has overwritten that one)
+            const uint64_t s = off >= 64 ? op - off + i : op + i0 - off + (lane % (uint32_t)off);
             if (off <= kSnapRing) {
                 if (i < len) v = s_ring[s & (kSnapRing - 1)];
             } else {

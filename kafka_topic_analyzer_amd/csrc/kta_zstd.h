@@ -65,6 +65,9 @@ KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
 struct ZsMem {
     const uint8_t *p;
     KTA_ZSTD_HD uint32_t byte(uint64_t at) { return p[at]; }
+    // a value every lane of a wave source holds alike (read from an LDS table, say): a wave source moves it to the
+    // scalar unit, which keeps the uniform parsing out of the vector registers; nothing to do here
+    KTA_ZSTD_HD uint32_t uni(uint32_t x) { return x; }
     // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; bytes outside the slice are zero
     KTA_ZSTD_HD uint64_t le64(uint64_t base, uint64_t n, int64_t first)
     {
@@ -200,21 +203,23 @@ KTA_ZSTD_HD uint32_t zs_read_norm(S &src, ZsFwd &f, ZsWork &w, uint32_t max_log,
 }
 
 // Spreads w.norm[0 .. n_sym) into the decoding table `t` of 1 << log entries.
-KTA_ZSTD_HD bool zs_build_fse(ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
+template <class S>
+KTA_ZSTD_HD bool zs_build_fse(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
 {
     const uint32_t size = 1u << log, mask = size - 1u;
     uint32_t high = size;
     for (uint32_t s = 0; s < n_sym; s++)
-        if (w.norm[s] == -1) {
+        if ((int16_t)src.uni((uint16_t)w.norm[s]) == -1) {
             t[--high] = s;
             w.next[s] = 1;
         }
     const uint32_t step = (size >> 1) + (size >> 3) + 3u;
     uint32_t pos = 0;
     for (uint32_t s = 0; s < n_sym; s++) {
-        if (w.norm[s] <= 0) continue;
-        w.next[s] = (uint16_t)w.norm[s];
-        for (int32_t i = 0; i < w.norm[s]; i++) {
+        const int32_t cnt = (int16_t)src.uni((uint16_t)w.norm[s]);
+        if (cnt <= 0) continue;
+        w.next[s] = (uint16_t)cnt;
+        for (int32_t i = 0; i < cnt; i++) {
             t[pos] = s;
             do pos = (pos + step) & mask;
             while (pos >= high);
@@ -222,7 +227,8 @@ KTA_ZSTD_HD bool zs_build_fse(ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_s
     }
     if (pos != 0) return false;
     for (uint32_t i = 0; i < size; i++) {
-        const uint32_t s = t[i], x = w.next[s]++;
+        const uint32_t s = src.uni(t[i]), x = src.uni(w.next[s]);
+        w.next[s] = (uint16_t)(x + 1);
         const uint32_t nb = log - zs_highbit(x);
         t[i] = s | (nb << 8) | (((x << nb) - size) << 16);
     }
@@ -259,7 +265,7 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         zs_default_norm(w, which);
         log = which == 1 ? 5 : 6;
         have = 1;
-        return zs_build_fse(w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53));
+        return zs_build_fse(src, w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53));
     }
     if (mode == 1) {
         if (*pos >= n || src.byte(base + *pos) > max_sym) return false;
@@ -276,7 +282,7 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         *pos += f.bit >> 3;
         log = (uint8_t)l;
         have = 1;
-        return zs_build_fse(w, t, l, n_sym);
+        return zs_build_fse(src, w, t, l, n_sym);
     }
     return have != 0;   // repeat: the previous block's table
 }
@@ -304,7 +310,7 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
         ZsFwd f = zs_fwd_init(base + 1, hb);
         uint32_t n_sym = 0;
         const uint32_t log = zs_read_norm(src, f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
-        if (!log || !zs_build_fse(w, w.wfse, log, n_sym)) return 0;
+        if (!log || !zs_build_fse(src, w, w.wfse, log, n_sym)) return 0;
         const uint64_t at = f.bit >> 3;
         if (at >= hb) return 0;
         ZsBack b;
@@ -313,19 +319,22 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
         if (b.off < 0) return 0;
         while (true) {
             if (n_w >= 254) return 0;
-            w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF);
-            s1 = (w.wfse[s1] >> 16) + (uint32_t)zs_back(src, b, (w.wfse[s1] >> 8) & 0xFF);
-            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF); break; }
-            w.weights[n_w++] = (uint8_t)(w.wfse[s2] & 0xFF);
-            s2 = (w.wfse[s2] >> 16) + (uint32_t)zs_back(src, b, (w.wfse[s2] >> 8) & 0xFF);
-            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(w.wfse[s1] & 0xFF); break; }
+            const uint32_t e1 = src.uni(w.wfse[s1]);
+            w.weights[n_w++] = (uint8_t)(e1 & 0xFF);
+            s1 = (e1 >> 16) + (uint32_t)zs_back(src, b, (e1 >> 8) & 0xFF);
+            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(src.uni(w.wfse[s2]) & 0xFF); break; }
+            const uint32_t e2 = src.uni(w.wfse[s2]);
+            w.weights[n_w++] = (uint8_t)(e2 & 0xFF);
+            s2 = (e2 >> 16) + (uint32_t)zs_back(src, b, (e2 >> 8) & 0xFF);
+            if (b.off < 0) { w.weights[n_w++] = (uint8_t)(src.uni(w.wfse[s1]) & 0xFF); break; }
         }
     }
     // the last weight is implied: the code space must add up to a power of two
     uint32_t sum = 0;
     for (uint32_t i = 0; i < n_w; i++) {
-        if (w.weights[i] > 11) return 0;
-        sum += w.weights[i] ? 1u << (w.weights[i] - 1) : 0u;
+        const uint32_t wt = src.uni(w.weights[i]);
+        if (wt > 11) return 0;
+        sum += wt ? 1u << (wt - 1) : 0u;
     }
     if (sum == 0) return 0;
     const uint32_t log = zs_highbit(sum) + 1;
@@ -339,11 +348,11 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
     for (uint32_t wt = 1; wt <= log; wt++) {
         rank_start[wt] = at;
         for (uint32_t s = 0; s < n_w; s++)
-            if (w.weights[s] == wt) at += 1u << (wt - 1);
+            if (src.uni(w.weights[s]) == wt) at += 1u << (wt - 1);
     }
     if (at != (1u << log)) return 0;
     for (uint32_t s = 0; s < n_w; s++) {
-        const uint32_t wt = w.weights[s];
+        const uint32_t wt = src.uni(w.weights[s]);
         if (!wt) continue;
         const uint32_t len = 1u << (wt - 1), nb = log + 1 - wt;
         for (uint32_t i = 0; i < len; i++) w.huf[rank_start[wt] + i] = (uint16_t)(s | (nb << 8));
@@ -569,7 +578,7 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
         uint32_t sl = (uint32_t)zs_back(src, b, w.ll_log), so = (uint32_t)zs_back(src, b, w.of_log), sm = (uint32_t)zs_back(src, b, w.ml_log);
         if (b.off < 0) return false;
         for (uint32_t i = 0; i < n_seq; i++) {
-            const uint32_t el = w.ll[sl], eo = w.of[so], em = w.ml[sm];
+            const uint32_t el = src.uni(w.ll[sl]), eo = src.uni(w.of[so]), em = src.uni(w.ml[sm]);
             const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
             if (oc > 31) return false;
             const uint64_t ov = (1ull << oc) + zs_back(src, b, oc);

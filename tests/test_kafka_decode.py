@@ -729,16 +729,18 @@ def test_device_gzip_and_zstd_copy_paths():
     wide = bytes(rng.integers(0, 256, size=70000, dtype=np.uint8))
     farther = wide + bytes(rng.integers(0, 256, size=50000, dtype=np.uint8)) + wide    # zstd: offsets ~120 KB
     text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(9000))
-    recs = [(0, b"far", far), (1, b"rle", b"\x07" * 5000), (2, b"pat", b"abcdefg" * 900), (3, b"p70", chunk[:70] * 40),
+    # (a period that does not divide the LDS ring, repeated past the ring's length: one match longer than the ring)
+    recs = [(0, b"far", far), (1, b"rle", b"\x07" * 5000), (2, b"pat", b"abcdefg" * 9000), (3, b"p70", chunk[:70] * 40),
             (4, b"txt", text), (5, b"fth", farther), (6, b"zer", b"\0" * 300000), (7, None, text[:1000])]
-    codecs = ["gzip", "zstd", "gzip-fixed", "zstd-19", "gzip-stored", "zstd-stream", "gzip-named", None]
+    codecs = ["gzip", "zstd", "gzip-fixed", "zstd-19", "gzip-stored", "zstd-stream", "gzip-named", None, "lz4", "snappy",
+              "lz4-indep"]
     blob = b"".join(K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c) for i, c in enumerate(codecs))
     want, _ = kafka_decode(blob, 1)
     for variant in (0, 1):
         with kta.HipMetricHandler(2, now=NOW) as h:
             h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, bad = _decode_on_device(h, blob, 1, True)
-            assert bad == 0 and st.n_gzip == 4 and st.n_zstd == 3
+            assert bad == 0 and st.n_gzip == 4 and st.n_zstd == 3 and st.n_lz4 == 2 and st.n_snappy == 1
             for k in ("partition", "key_len", "val_len", "ts_ms"):
                 assert np.array_equal(cols[k], want[k]), k
             kb = cols["key_bytes"].tobytes()
