@@ -24,8 +24,11 @@ for line in open(path):
         rows[(m.group(1).strip(), m.group(2))] = (int(m.group(3)), float(m.group(4)), float(m.group(5)), float(m.group(6)))
 
 
-def find(sub, counter):
+def find(sub, counter, largest_grid=False):
     hits = [(k, v) for (k, c), v in rows.items() if c == counter and sub in k]
+    if largest_grid and len(hits) > 1:         # rows are per (kernel, grid size): the biggest launch
+        hits.sort(key=lambda kv: int(re.search(r"grid=(\d+)", kv[0]).group(1)))
+        hits = hits[-1:]
     assert len(hits) == 1, (sub, counter, [k for k, _ in hits])
     return hits[0][1]
 
@@ -69,14 +72,15 @@ out["kta_alive_apply"] = {"kernel": "kta_alive_apply<10,14>", "records_per_launc
                                   "block).  None of this is algorithmic input: the batch's algorithmic bytes are booked on "
                                   "kta_alive_partition"}
 
-f, w = find("kafka_decode_coop<4, 2048u, 32u>", "FETCH_SIZE"), find("kafka_decode_coop<4, 2048u, 32u>", "WRITE_SIZE")
+f, w = find("kafka_decode_coop<4, 2048u, 32u>", "FETCH_SIZE", True), find("kafka_decode_coop<4, 2048u, 32u>", "WRITE_SIZE", True)
 raw_log = 1075251127                          # bytes of the 4 M-record raw log bench.py's kafka_decode.roofline describes
 rd, wr = 2 * f[3] * KIB, w[3] * KIB
 out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<4, 2048u, 32u>", "records_per_launch": 4000000,
                             "algorithmic_bytes_per_launch": raw_log, "FETCH_SIZE_kib_max": f[3], "WRITE_SIZE_kib_max": w[3],
                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                             "ratio_to_algorithmic": (rd + wr) / raw_log,
-                            "note": "the PMC row of this kernel mixes %d launches of several sizes (4 M, 2 M and 1 M records); the MAX "
-                                    "of the row is the 4 M-record / 1.075 GB launch bench.py's kafka_decode.roofline describes" % f[0]}
+                            "note": "rows are per launch size where the summary carries grid sizes (the largest grid = the 4 M-record / "
+                                    "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them); the MAX of the row is "
+                                    "used, which also picks that launch out of a mixed row" % f[0]}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -16,8 +16,8 @@ def stats(db):
         print(f"{name[:110]:<110} {calls:>6} {total:>12.1f} {avg:>12.3f} {pct:>7.2f}")
     print("\n# per-dispatch geometry of the product kernels")
     for r in cur.execute("select name, count(*), min(duration), avg(duration), max(duration), grid_x, workgroup_x, "
-                         "lds_size, vgpr_count, sgpr_count from kernels where name like '%kta::%' "
-                         "group by name, grid_x, lds_size"):
+                         "lds_size, vgpr_count, sgpr_count from kernels where name like '%kta::%' or name like '%kafka_%' "
+                         "group by name, grid_x, lds_size"):     # one row per kernel AND launch size
         print("  %s\n     n=%d dur_ns min/avg/max=%d/%d/%d grid_x=%d wg_x=%d lds=%d vgpr=%d sgpr=%d" % r)
 
 
