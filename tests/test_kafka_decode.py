@@ -519,6 +519,14 @@ def test_gzip_inflate_host_against_zlib():
         with gzip.GzipFile(filename="some-name.bin", mode="wb", fileobj=f, mtime=12345) as g:
             g.write(d)
         check(f.getvalue(), d)
+    # many short matches and few literals: the worst case for the token area of the two-stage form (a token per
+    # match; the bound is out/3 + out/255 + 1) — three- and four-byte pieces of a small dictionary in random order
+    rng2 = np.random.default_rng(3)
+    pieces = [bytes(rng2.integers(0, 256, size=int(k), dtype=np.uint8)) for k in rng2.integers(3, 5, size=40)]
+    short = b"".join(pieces[int(i)] for i in rng2.integers(0, len(pieces), size=60000))
+    for level in (1, 6, 9):
+        co = zlib.compressobj(level, zlib.DEFLATED, 15 + 16)
+        check(co.compress(short) + co.flush(), short)
     pa = pytest.importorskip("pyarrow")
     for d in _library_cases():
         check(pa.compress(d, codec="gzip", asbytes=True), d)
