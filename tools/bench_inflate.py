@@ -26,7 +26,6 @@ ap.add_argument("--records", type=int, default=1_000_000)
 ap.add_argument("--rpb", type=int, default=60)
 ap.add_argument("--codecs", default="gzip,zstd")
 ap.add_argument("--variants", default="0,1")
-ap.add_argument("--text", action="store_true", help="text-like values (many short matches) instead of the c4 preset's")
 args = ap.parse_args()
 lib = N.load()
 spec, _ = kta.synth_preset("c4")
@@ -68,7 +67,7 @@ for name in args.codecs.split(","):
         h._check(lib.kta_kafka_decode_device(h._ctx, blob.partition, ln.value, descs, st.n_batches, nc, C.byref(out), None, C.byref(bad)))
         cols = h.download_batch(out, len(ref["partition"]))
         ok = bad.value == 0 and all(np.array_equal(cols[k], ref[k]) for k in ("key_len", "val_len", "ts_ms"))
-        print(json.dumps({"codec": name, "variant": variant, "lanes_env": os.environ.get("KTA_GZIP_LANES", ""), "batches": int(st.n_batches),
+        print(json.dumps({"codec": name, "variant": variant, "batches": int(st.n_batches),
                           "compressed_bytes": int(ln.value), "inflate_area": int(st.inflate_bytes), "ms": round(best * 1e3, 3),
                           "compressed_GBps": round(ln.value / best / 1e9, 2), "ok": bool(ok), "bad_batches": int(bad.value)}), flush=True)
     h._check(lib.kta_kafka_set_variant(h._ctx, 0))
