@@ -157,6 +157,7 @@ struct ShardedJob {
     uint64_t batch = 1ull << 20;
     uint32_t P = 0;
     kta_synth_spec spec{};
+    bool oversubscribe = false;                        // kta.oversubscribe=1: several ranks may share a device (test doubles of RCCL)
     uint64_t n_records = 0;
     std::vector<std::vector<uint8_t>> segment_bytes;   // segment:// : file k is partition k
     std::vector<uint64_t> base_seq;                    //   global sequence number of each partition's first record
@@ -246,6 +247,12 @@ int run_sharded(ShardedJob &job, const std::chrono::steady_clock::time_point sta
         fprintf(stderr, "kta_create failed: no HIP device visible (libkta_hip has no CPU fallback)\n");
         return 2;
     }
+    // one rank per device: two ranks on one GPU would each take a 32 GiB table under -c, and real RCCL refuses
+    // the second one ("duplicate GPU") while the first is still blocked in its init
+    if (job.nranks > ndev && !job.oversubscribe) {
+        fprintf(stderr, "kta.gpus=%d: only %d HIP device(s) visible\n", job.nranks, ndev);
+        return 2;
+    }
     uint8_t uid[KTA_COMM_ID_BYTES];
     if (kta_comm_unique_id(uid) != KTA_OK) {
         fprintf(stderr, "kta.gpus=%d: RCCL is not loadable (KTA_RCCL_LIBRARY)\n", job.nranks);
@@ -292,7 +299,18 @@ int main(int argc, char **argv)
     std::map<std::string, std::string> cfg = parse_librdkafka(args);                // main.rs:84-92
     const int device = cfg.count("kta.device") ? atoi(cfg["kta.device"].c_str()) : 0;
     const uint64_t batch = cfg.count("kta.batch") ? strtoull(cfg["kta.batch"].c_str(), nullptr, 10) : (1ull << 20);
-    const int gpus = cfg.count("kta.gpus") ? atoi(cfg["kta.gpus"].c_str()) : 1;
+    int gpus = 1;
+    if (cfg.count("kta.gpus")) {   // strictly a positive decimal number
+        const std::string &g = cfg["kta.gpus"];
+        char *end = nullptr;
+        const long v = strtol(g.c_str(), &end, 10);
+        if (g.empty() || *end || v < 1 || v > 1024) {
+            fprintf(stderr, "kta.gpus=%s: expected a number of GPUs >= 1\n", g.c_str());
+            return 2;
+        }
+        gpus = (int)v;
+    }
+    const bool oversubscribe = cfg.count("kta.oversubscribe") && cfg["kta.oversubscribe"] == "1";
 
     // ---- the record source (stands in for TopicAnalyzer, src/kafka.rs) ------------------------------
     const std::string &b = args.bootstrap;
@@ -417,6 +435,7 @@ int main(int argc, char **argv)
         job.check_crcs = check_crcs;
         job.device = device;
         job.nranks = gpus;
+        job.oversubscribe = oversubscribe;
         job.batch = batch;
         job.P = P;
         job.spec = spec;

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -63,25 +65,31 @@ struct Rccl {
     std::string error;
 };
 
-Rccl *rccl()
+// Bound once per process (std::call_once): contexts live on their own threads and may reach their first
+// kta_comm_create together.  The handle is published only after every symbol is bound.
+static void rccl_load(Rccl &r)
 {
-    static Rccl r;
-    if (r.lib || !r.error.empty()) return &r;
     const char *env = getenv("KTA_RCCL_LIBRARY");
-    const char *names[] = {env, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    const bool only_env = getenv("KTA_RCCL_ONLY_ENV") != nullptr;  // tests: no default search paths
+    const char *names[] = {env, only_env ? nullptr : "/opt/rocm/lib/librccl.so.1", only_env ? nullptr : "librccl.so.1",
+                           only_env ? nullptr : "librccl.so"};
+    void *lib = nullptr;
+    std::string why;
     for (const char *n : names) {
         if (!n || !*n) continue;
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+        const char *e = dlerror();  // one call: dlerror() clears the message it returns
+        if (why.empty() && e) why = e;
     }
-    if (!r.lib) {
-        r.error = std::string("RCCL not found (set KTA_RCCL_LIBRARY): ") + (dlerror() ? dlerror() : "");
-        return &r;
+    if (!lib) {
+        r.error = std::string("RCCL not found (set KTA_RCCL_LIBRARY): ") + why;
+        return;
     }
     bool ok = true;
     auto sym = [&](const char *name) {
-        void *p = dlsym(r.lib, name);
-        if (!p) {
+        void *p = dlsym(lib, name);
+        if (!p && ok) {
             ok = false;
             r.error = std::string("RCCL symbol missing: ") + name;
         }
@@ -90,6 +98,7 @@ Rccl *rccl()
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(lib, "ncclCommAbort"));  // optional
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
@@ -98,9 +107,17 @@ Rccl *rccl()
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) {
-        dlclose(r.lib);
-        r.lib = nullptr;
+        dlclose(lib);
+        return;
     }
+    r.lib = lib;
+}
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
     return &r;
 }
 
@@ -113,6 +130,7 @@ struct CommState {
     uint64_t *d_send_vals = nullptr, *d_recv_vals = nullptr;
     uint64_t send_cap = 0, recv_cap = 0;
     uint64_t last_sent = 0, last_received = 0;
+    bool aborted = false;
 };
 
 void free_comm(void *p)
@@ -292,17 +310,24 @@ int kta_comm_destroy(kta_ctx *ctx)
     return KTA_OK;
 }
 
-int kta_exchange(kta_ctx *ctx)
+// A rank that fails locally (a kernel launch, an allocation) before or between the collectives would leave
+// its peers blocked inside theirs for ever: abort the communicator, which makes the peers' pending and
+// later collectives fail with an error (ncclCommAbort; a library without it keeps the communicator).
+static int exchange_failed(CommState *st, int rc)
 {
-    if (!ctx) return KTA_ERR_INVALID;
-    void **slot = kta_internal_comm_slot(ctx, free_comm);
-    CommState *st = static_cast<CommState *>(*slot);
-    if (!st) return fail(ctx, KTA_ERR_INVALID, "kta_exchange without kta_comm_create");
-    int rc = kta_finish_device(ctx);           // flush + snapshot (+ this rank's alive count)
-    if (rc != KTA_OK || !st->comm) return rc;  // one rank without a communicator: the snapshot is the job's result
+    if (st->comm && rccl()->CommAbort) {
+        (void)rccl()->CommAbort(st->comm);
+        st->comm = nullptr;
+        st->aborted = true;
+    }
+    return rc;
+}
+
+static int exchange_collectives(kta_ctx *ctx, CommState *st)
+{
     CH(ctx, hipSetDevice(kta_internal_device(ctx)));
     if (kta_internal_count_alive(ctx)) {
-        rc = exchange_alive(ctx, st);
+        int rc = exchange_alive(ctx, st);
         if (rc != KTA_OK) return rc;
     }
     Rccl *R = rccl();
@@ -314,6 +339,20 @@ int kta_exchange(kta_ctx *ctx)
     CN(ctx, R->AllReduce(vec + sum_words, vec + sum_words, KTA_NGLOBALS - KTA_NSUM_GLOBALS, ncclInt64, ncclMax, st->comm, s));
     CN(ctx, R->GroupEnd());
     return KTA_OK;
+}
+
+int kta_exchange(kta_ctx *ctx)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    void **slot = kta_internal_comm_slot(ctx, free_comm);
+    CommState *st = static_cast<CommState *>(*slot);
+    if (!st) return fail(ctx, KTA_ERR_INVALID, "kta_exchange without kta_comm_create");
+    if (st->aborted) return fail(ctx, KTA_ERR_COMM, "kta_exchange: the communicator was aborted by an earlier failure");
+    int rc = kta_finish_device(ctx);           // flush + snapshot (+ this rank's alive count)
+    if (rc != KTA_OK) return exchange_failed(st, rc);
+    if (!st->comm) return rc;                  // one rank without a communicator: the snapshot is the job's result
+    rc = exchange_collectives(ctx, st);
+    return rc == KTA_OK ? rc : exchange_failed(st, rc);
 }
 
 int kta_comm_allreduce_i64(kta_ctx *ctx, int64_t *host_values, size_t n, int op_max)

@@ -270,8 +270,11 @@ HEADER = ["P", "< OS", "> OS", "Total", "Alive", "Tmb", "DR", "K Null", "K !Null
 
 def report(topic: str, duration_secs: int, mm: MessageMetrics,
            lc: Optional[LogCompactionInMemoryMetrics], partitions: List[int],
-           start_offsets: Dict[int, int], end_offsets: Dict[int, int]) -> str:
-    """main.rs:123-179 (stdout only)."""
+           start_offsets: Dict[int, int], end_offsets: Dict[int, int],
+           os_names: Tuple[str, str] = ("< OS", "> OS")) -> str:
+    """main.rs:123-179 (stdout only).  `os_names`: the two offset column names — v0.5.0 prints
+    "< OS" / "> OS" (main.rs:150,175); the build behind /root/reference/demo_output.png printed
+    "|< OS" / ">| OS" (tests/test_reference_demo.py compares against that screenshot)."""
     o = "\n"
     o += "=" * 120 + "\n"
     o += "Calculating statistics...\n"
@@ -290,7 +293,7 @@ def report(topic: str, duration_secs: int, mm: MessageMetrics,
         o += "Alive keys: %d\n" % lc.sum_all_alive()
         o += "-" * 120 + "\n"
     o += "=" * 120 + "\n"
-    rows = [HEADER]
+    rows = [[HEADER[0], os_names[0], os_names[1]] + HEADER[3:]]
     for p in sorted(partitions):
         key_size_avg = mm.key_size_avg(p)  # may raise DivideByZeroPanic (main.rs:154)
         rows.append([
@@ -302,7 +305,7 @@ def report(topic: str, duration_secs: int, mm: MessageMetrics,
             str(mm.message_size_avg(p)),
         ])
     o += "| K = Key, V = Value, P = Partition, Tmb = Tombstone(s), Sz = Size\n"
-    o += "| DR = Dirty Ratio, A = Average, Lst = last, < OS = start offset, > OS = end offset\n"
+    o += "| DR = Dirty Ratio, A = Average, Lst = last, %s = start offset, %s = end offset\n" % os_names
     o += prettytable(rows)
     o += "\n"
     o += "=" * 120 + "\n"

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -193,3 +194,19 @@ def test_synth_sharding_partitions_are_disjoint_and_cover():
         assert not (parts & seen)
         seen |= parts
     assert seen == set(range(256))
+
+
+def test_missing_rccl_is_an_error_not_a_crash(tmp_path):
+    """kta_comm_unique_id with no loadable RCCL: KTA_ERR_COMM (the loader once built its message from two
+    dlerror() calls, the second of which returns NULL).  Own process: the binding is made once per process."""
+    code = ("import os, ctypes as C\n"
+            "from kafka_topic_analyzer_amd import _native as N\n"
+            "lib = N.load()\n"
+            "buf = C.create_string_buffer(128)\n"
+            "rc = lib.kta_comm_unique_id(buf)\n"
+            "print('rc', rc, N.KTA_ERR_COMM)\n"
+            "assert rc == N.KTA_ERR_COMM\n")
+    env = dict(os.environ, KTA_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"), KTA_RCCL_ONLY_ENV="1",
+               PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -107,6 +107,12 @@ def test_cli_required_arguments():
     assert r.returncode == 1 and "wasn't expected" in r.stderr
 
 
+def test_cli_kta_gpus_is_parsed_strictly():
+    for bad in ("two", "-1", "0", "2x", ""):
+        r = run_cli("-t", "x", "-b", "synthetic://c1", "--librdkafka", "kta.gpus=" + bad)
+        assert r.returncode == 2 and "kta.gpus=" in r.stderr and "expected a number" in r.stderr, (bad, r.stderr)
+
+
 def test_cli_librdkafka_pair_without_equals_panics():
     r = run_cli("-t", "x", "-b", "synthetic://c1", "--librdkafka", "a=b,broken")
     assert r.returncode == 101 and "panicked" in r.stderr and "src/main.rs:89" in r.stderr
@@ -272,7 +278,7 @@ def test_cli_sharded_over_several_ranks_prints_the_single_gpu_report(tmp_path, m
     env = dict(os.environ, KTA_RCCL_LIBRARY=mock_rccl)
     one = run_cli("-t", "c2", "-b", "synthetic://c2?records=250000", "-c")
     many = subprocess.run([CLI, "-t", "c2", "-b", "synthetic://c2?records=250000", "-c", "--librdkafka",
-                           "kta.gpus=%d,kta.batch=32768" % gpus], capture_output=True, text=True, timeout=300, env=env)
+                           "kta.gpus=%d,kta.batch=32768,kta.oversubscribe=1" % gpus], capture_output=True, text=True, timeout=300, env=env)
     assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
     assert "Alive keys: " in one.stdout and _normalise(many.stdout) == _normalise(one.stdout)
     from kafka_cases import random_record_set
@@ -285,10 +291,14 @@ def test_cli_sharded_over_several_ranks_prints_the_single_gpu_report(tmp_path, m
         files.append(str(path))
     src = "segment://" + ",".join(files)
     one = run_cli("-t", "seg", "-b", src, "-c")
-    many = subprocess.run([CLI, "-t", "seg", "-b", src, "-c", "--librdkafka", "kta.gpus=%d" % gpus], capture_output=True,
-                          text=True, timeout=300, env=env)
+    many = subprocess.run([CLI, "-t", "seg", "-b", src, "-c", "--librdkafka", "kta.gpus=%d,kta.oversubscribe=1" % gpus],
+                          capture_output=True, text=True, timeout=300, env=env)
     assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
     assert _normalise(many.stdout) == _normalise(one.stdout) and "Alive keys: " in many.stdout
     r = subprocess.run([CLI, "-t", "x", "-b", "dump:///nonexistent", "--librdkafka", "kta.gpus=2"], capture_output=True, text=True,
                        timeout=60, env=env)
     assert r.returncode != 0
+    # more ranks than devices is refused before any thread starts (one rank per GPU) ...
+    r = subprocess.run([CLI, "-t", "c2", "-b", "synthetic://c2?records=1000", "--librdkafka", "kta.gpus=999"],
+                       capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 2 and "HIP device(s) visible" in r.stderr
