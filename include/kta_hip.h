@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 3   /* 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
+#define KTA_ABI_VERSION 4   /* 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
 
 /* status codes */
 #define KTA_OK 0
@@ -104,6 +104,16 @@ typedef struct kta_config {
  * every record's GLOBAL consumption index, kta_batch_submit's base_seq is ignored.  For a rank of a
  * partition-sharded run, whose records are not consecutive in the topic's consumption order. */
 #define KTA_FLAG_SEQ_COLUMN 2u
+/* How a -c context keeps the alive set (the reference: one BitSet, metric.rs:262-264):
+ *   default               the reference's own bit set, 2^32 bits = 512 MiB.  Batches are applied IN SUBMISSION
+ *                         ORDER (what the reference does with the messages it polls); base_seq is not looked at.
+ *   KTA_FLAG_ALIVE_TABLE  a last-writer table u64[2^32] = 32 GiB of ((seq + 1) << 1 | alive): batches, shards and
+ *                         ranks may arrive in any order, the largest GLOBAL sequence number of a slot wins.  What a
+ *                         rank of a sharded run needs (kta_comm_create with nranks > 1, kta_alive_table,
+ *                         kta_alive_export_entries / import_entries / count_range).  Implied by KTA_FLAG_SEQ_COLUMN.
+ *                         A seq column has to ascend inside each batch to take the fast path (checked on the device;
+ *                         other batches are still exact, through the single-kernel update). */
+#define KTA_FLAG_ALIVE_TABLE 4u
 #define KTA_HIST_BUCKETS 34 /* [0] None, [1] length 0, [2+k] 2^k <= length < 2^(k+1), k = 0..31 */
 
 typedef struct kta_analytics {

@@ -56,13 +56,18 @@ class HipMetricHandler:
 
     def __init__(self, n_partitions: int, count_alive_keys: bool = False, device: int = 0,
                  batch_capacity: int = 0, key_bytes_capacity: int = 0, n_staging: int = 0,
-                 now: Optional[Tuple[int, int]] = None, analytics: bool = False):
+                 now: Optional[Tuple[int, int]] = None, analytics: bool = False, alive_table: bool = False,
+                 seq_column: bool = False):
+        """alive_table: keep the alive set as the sequence-numbered table (KTA_FLAG_ALIVE_TABLE: batches / shards in
+        any order, needed by a rank of a sharded run) instead of the reference's bit set (submission order);
+        seq_column: the staging batches carry every record's global sequence number (KTA_FLAG_SEQ_COLUMN)."""
         self._lib = N.load()
         self._ctx = C.c_void_p()
         self.n_partitions = int(n_partitions)
         self.count_alive_keys = bool(count_alive_keys)
         cfg = KtaConfig(device, n_partitions, 1 if count_alive_keys else 0, n_staging, batch_capacity,
-                        key_bytes_capacity, N.KTA_FLAG_ANALYTICS if analytics else 0, 0)
+                        key_bytes_capacity, (N.KTA_FLAG_ANALYTICS if analytics else 0) |
+                        (N.KTA_FLAG_ALIVE_TABLE if alive_table else 0) | (N.KTA_FLAG_SEQ_COLUMN if seq_column else 0), 0)
         rc = self._lib.kta_create(C.byref(cfg), C.byref(self._ctx))
         if rc != N.KTA_OK:
             raise KtaError(rc, self._lib.kta_last_error(None).decode())

@@ -43,6 +43,8 @@ class KtaConfig(C.Structure):
 
 
 KTA_FLAG_ANALYTICS = 1
+KTA_FLAG_SEQ_COLUMN = 2
+KTA_FLAG_ALIVE_TABLE = 4
 KTA_HIST_BUCKETS = 34
 
 
@@ -174,7 +176,7 @@ SIGNATURES = {
 _lib = None
 
 
-KTA_ABI_VERSION = 3  # include/kta_hip.h
+KTA_ABI_VERSION = 4  # include/kta_hip.h
 
 
 def load() -> C.CDLL:

@@ -169,7 +169,8 @@ struct ShardedJob {
 void run_rank(const ShardedJob &job, int rank, const uint8_t *uid, int ndev, kta::HipMetricHandler **out)
 {
     try {
-        const uint32_t flags = job.synthetic && job.count_alive ? KTA_FLAG_SEQ_COLUMN : 0u;
+        // a rank's records are not consecutive in consumption order: global sequence numbers, table state
+        const uint32_t flags = job.count_alive ? (job.synthetic ? KTA_FLAG_SEQ_COLUMN : KTA_FLAG_ALIVE_TABLE) : 0u;
         kta::HipMetricHandler *h = new kta::HipMetricHandler((int32_t)job.P, job.count_alive, (job.device + rank) % ndev,
                                                              job.batch, 0, flags);
         kta_ctx *ctx = h->ctx();

@@ -1,27 +1,35 @@
-// kta_alive.hip — the partitioned alive-key pass (gfx950): LogCompactionInMemoryMetrics::handle_message
-// (/root/reference/src/metric.rs:288-305) over one batch, as two kernels that keep the random accesses
-// on chip.
+// kta_alive.hip — the alive-key pass (gfx950): LogCompactionInMemoryMetrics::handle_message
+// (/root/reference/src/metric.rs:288-305) over one batch, as two kernels that keep the random accesses on chip.
 //
-// The table semantics are those of kta_kernels.hip: table[h] = max(table[h], ((seq+1) << 1) | alive), the
-// largest sequence number per 32-bit hash slot being the last writer in consumption order, which is what
-// sequential BitSet::insert / remove leave behind (metric.rs:273-280).  What changes is how a batch gets
-// there.  One memory-side atomic (or even one L2-missing read) per record caps the pass at 20-50 G
-// records/s whatever the kernel does, so:
+// What the reference leaves behind is a bit per 32-bit hash slot: the alive flag of the LAST record that hashed
+// there, in consumption order (BitSet::insert / remove, metric.rs:273-280).  One memory-side atomic (or even
+// one L2-missing read) per record caps a direct implementation at 20-50 G records/s, so:
 //
-//   pass 1  kta_alive_partition   streams the batch once (coalesced), hashes every key (fnv32.rs:92-101)
-//           and appends the pair (h, local sequence, alive) to the segment [bucket][workgroup], bucket =
-//           the hash's top bits.  Segments are private to a workgroup: no global atomics.  Pairs do not go
-//           to memory one by one — a partial 64-byte write costs a memory-side read-modify-write, 28 G/s
-//           whatever its size (tools/ubench_scatter.hip) — but through a ring of 16 pairs per bucket in
-//           LDS that is flushed in aligned 64-byte blocks (software write combining).
-//   pass 2  kta_alive_apply       one workgroup owns one bucket, i.e. one contiguous region of the table.
-//           It merges the bucket's pairs in an LDS hash table (last writer per slot: 64-bit LDS max on
-//           (h, seq)), so that records superseded inside the batch die in LDS, and then applies the
-//           survivors to its region with a plain read / compare / write — it is the region's only writer.
+//   pass 1  kta_alive_partition   streams the batch once (16-byte loads, a lane owns four consecutive
+//           records), hashes every key (fnv32.rs:92-101) and appends the pair (hash, batch-local index,
+//           alive) to the segment [bucket = top hash bits][workgroup].  Workgroups take contiguous ranges
+//           of the batch, so segment w of a bucket holds an older range than segment w + 1.  Pairs reach
+//           memory through a ring of 16 pairs per bucket in LDS and leave it in whole aligned 64-byte
+//           blocks (a partial block write costs a memory-side read-modify-write, 28 G/s whatever its size:
+//           tools/ubench_scatter.hip).  No workgroup barrier in the loop: a writer reserves a position with
+//           an LDS atomic, writes its pair, and counts the block's arrivals; whoever completes a block queues
+//           it and the wave writes its queued blocks out together.
+//   pass 2  kta_alive_apply       one workgroup owns one bucket, i.e. one contiguous region of the slot
+//           space.  It merges the bucket's pairs in an LDS table (8-way sets of 16-bit tags chosen by the
+//           slot's ADDRESS, one 16-byte read per lookup; the largest index per slot survives), then applies
+//           the survivors:
+//             bitmap state (in-order batches, the single-GPU default): the region of the reference's own
+//               512 MiB bit set is streamed through LDS in 32 KiB slices — survivors set / clear their bit
+//               with LDS atomics, the slice goes back in whole lines.  No partial writes, no 32 GiB table.
+//             table state (global sequence numbers: sharded runs): table[slot] = max(table[slot],
+//               ((seq + 1) << 1) | alive) by the region's only writer, as in round 2.
 //
-// Exactness never depends on sizes or on luck: a record that finds no room in its ring, its segment or
-// the LDS table takes the direct path (pre-read + atomicMax, as kta_alive_update_filtered), and max is
-// commutative.  The running alive count telescopes exactly as in kta_alive_update_counting.
+// Exactness never depends on sizes or luck.  A pair that finds no room in its segment goes to a pool; a
+// record that finds its set full goes to a small LDS list that is resolved at the end of the merge.  In table
+// state both end in the direct path (pre-read + atomicMax, commutative).  In bitmap state a bucket that cannot
+// be finished on chip (pool pairs, list overflow) is left untouched and reported to kta_alive_fallback, which
+// resolves it exactly in direct-indexed passes over the bucket's pairs.  A bucket with more distinct slots
+// than the LDS table takes is applied in instalments, in segment order (older ranges first).
 #include "kta_kernels.h"
 
 // Phase timers for tools/ubench_alive.hip (which includes this file with KTA_ALIVE_PHASES defined): thread 0
@@ -105,44 +113,32 @@ __device__ __forceinline__ uint32_t fnv32_more(uint32_t h, const uint8_t *k, uin
     return h;
 }
 
-// The direct path: what kta_alive_update_filtered does for one record.
+// FNV of a key whose first 16 bytes are in registers
+__device__ __forceinline__ uint32_t fnv32_prefetched(const uint4 &k16, const uint8_t *key, uint32_t len)
+{
+    if (len == 16u) return fnv_16(kFnvInit, k16);
+    if (len > 16u) return fnv32_more(fnv_16(kFnvInit, k16), key + 16, len - 16u);
+    const uint32_t w[4] = {k16.x, k16.y, k16.z, k16.w};
+    uint32_t h = kFnvInit;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++)
+        if (len >= 4u * (d + 1u)) h = fnv_word(h, w[d]);
+    const uint32_t q = len >> 2;
+    uint32_t tw = q == 0u ? w[0] : (q == 1u ? w[1] : (q == 2u ? w[2] : w[3]));
+    for (uint32_t t = len & 3u; t > 0u; t--) {
+        h = fnv_byte(h, tw & 0xFFu);
+        tw >>= 8;
+    }
+    return h;
+}
+
+// The direct path of the table state: what kta_alive_update_filtered does for one record.
 __device__ __forceinline__ long long direct_update(unsigned long long *table, uint32_t h, unsigned long long v)
 {
     const unsigned long long seen = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen >= v) return 0;
     const unsigned long long old = atomicMax(&table[h], v);
     return v > old ? (long long)(v & 1ull) - (long long)(old & 1ull) : 0;
-}
-
-// Records that found no room on chip (ring, segment, LDS set) are not sent down the direct path where
-// they stand — a wave would wait microseconds for two dependent memory round trips while its workgroup
-// waits for it at the next barrier — but parked in a small LDS list that the whole workgroup drains, one
-// entry per thread, when it fills up and at the end.
-constexpr uint32_t kSpill = 512;
-
-struct SpillList {
-    uint32_t n;
-    uint32_t h[kSpill];
-    unsigned long long v[kSpill];
-};
-
-// false: the list is full, the caller runs the direct path itself
-__device__ __forceinline__ bool spill_push(SpillList &sp, uint32_t h, unsigned long long v)
-{
-    const uint32_t k = atomicAdd(&sp.n, 1u);
-    if (k >= kSpill) return false;
-    sp.h[k] = h;
-    sp.v[k] = v;
-    return true;
-}
-
-// all threads of the workgroup, between two barriers of the caller's
-__device__ __forceinline__ long long spill_drain(SpillList &sp, unsigned long long *table)
-{
-    const uint32_t n = sp.n < kSpill ? sp.n : kSpill;
-    long long delta = 0;
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) delta += direct_update(table, sp.h[k], sp.v[k]);
-    return delta;
 }
 
 __device__ __forceinline__ void add_running(long long delta, long long *running, long long *s_w)
@@ -159,431 +155,535 @@ __device__ __forceinline__ void add_running(long long delta, long long *running,
     }
 }
 
+// LDS operations of one wave are performed in program order; what has to be prevented is the COMPILER moving
+// an LDS access across the atomic that publishes (or acquires) it.  A release / acquire atomic would do that
+// too, but it also waits for the wave's outstanding global loads (vmcnt(0)) — the prefetches.
+#define KTA_LDS_ORDER() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ uint32_t lds_add(uint32_t *p, uint32_t v)
+{
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ------------------------------------------------------------------------------------------------------
-// pass 1: hash + partition with software write combining
+// pass 1: hash + partition with software write combining, no workgroup barrier in the loop
 // ------------------------------------------------------------------------------------------------------
 constexpr int kPartThreads = 1024;                 // one workgroup per CU: the rings take most of the LDS
-#ifndef KTA_PART_RECS
-#define KTA_PART_RECS 4
-#endif
-constexpr int kPartRecs = KTA_PART_RECS;           // records per thread per round
-constexpr uint32_t kPartRound = kPartThreads * kPartRecs;
+constexpr int kPartWaves = kPartThreads / 64;
+constexpr uint32_t kTile = 256;                    // records of one wave step: four consecutive records per lane
 constexpr uint32_t kRing = 16;                     // pairs per bucket ring: two 64-byte blocks
+constexpr uint32_t kQueue = 128;                   // completed blocks a wave queues between two flushes
 
-struct PartCols {
-    int32_t kl[kPartRecs], vl[kPartRecs];
-    uint32_t ko[kPartRecs];
+struct TileCols {
+    int4 kl, vl;
+    uint4 ko;
 };
-struct PartKeys {
-    uint4 k16[kPartRecs];                          // the 16 bytes at the key's offset
+struct TileKeys {
+    uint4 k[4];                                    // the 16 bytes at each key's offset
 };
 
-__device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uint64_t base, PartCols &r)
+// Unconditional loads (the index is clamped into the batch, the result masked): a load under a lane predicate
+// becomes a branch, and the compiler then waits with vmcnt(0) wherever the value is used — which would also
+// wait for every prefetch issued in between.  The columns are 16-byte aligned and tiles start at multiples
+// of four records, so the last, partial group of four is read inside its own aligned 16 bytes.
+// The first `skip` (0..3) positions lie before the batch: the three columns were aligned down by that many records.
+__device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uint32_t skip, uint64_t tile, bool tile_ok, TileCols &r)
 {
-#pragma unroll
-    // Unconditional loads (the index is clamped, the result masked): a load under a lane predicate becomes
-    // a branch, and the compiler then waits with vmcnt(0) wherever the value is used — which would also wait
-    // for every prefetch issued in between.
-    for (int j = 0; j < kPartRecs; j++) {
-        const uint64_t i = base + (uint64_t)j * kPartThreads + threadIdx.x;
-        const bool in = i < n;
-        const uint64_t ic = in ? i : n - 1;
-        const int32_t kl = c.key_len[ic], vl = c.val_len[ic];
-        const uint32_t ko = c.key_off[ic];
-        r.kl[j] = in ? kl : -1;
-        r.vl[j] = in ? vl : -1;
-        r.ko[j] = in ? ko : 0u;
-    }
+    const uint64_t base = tile * kTile + (uint64_t)(threadIdx.x & 63u) * 4u;
+    const uint64_t last = (n - 1) & ~3ull;
+    const uint64_t bc = tile_ok && base < last ? base : last;
+    r.kl = *reinterpret_cast<const int4 *>(c.key_len + bc);
+    r.vl = *reinterpret_cast<const int4 *>(c.val_len + bc);
+    r.ko = *reinterpret_cast<const uint4 *>(c.key_off + bc);
+    const bool in0 = tile_ok && base < n && base >= skip, in1 = tile_ok && base + 1 < n && base + 1 >= skip,
+               in2 = tile_ok && base + 2 < n && base + 2 >= skip, in3 = tile_ok && base + 3 < n;
+    r.kl.x = in0 ? r.kl.x : -1;                    // key None: ignored (metric.rs:302)
+    r.kl.y = in1 ? r.kl.y : -1;
+    r.kl.z = in2 ? r.kl.z : -1;
+    r.kl.w = in3 ? r.kl.w : -1;
 }
 
 // The first 16 bytes at every key's offset, whatever the key's length: the bytes past a shorter key are
 // loaded and ignored (key_bytes is readable for 16 bytes past its last key: kta_hip.h).
-__device__ __forceinline__ void load_keys(const AliveColumns &c, const PartCols &r, PartKeys &k)
+__device__ __forceinline__ void load_keys(const AliveColumns &c, const TileCols &r, TileKeys &k)
 {
-#pragma unroll
-    for (int j = 0; j < kPartRecs; j++)      // unconditional as well: a keyless record loads the blob's first 16 bytes
-        __builtin_memcpy(&k.k16[j], c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u), 16);
+    // unconditional as well: a keyless record loads the blob's first 16 bytes
+    __builtin_memcpy(&k.k[0], c.key_bytes + (r.kl.x > 0 ? r.ko.x : 0u), 16);
+    __builtin_memcpy(&k.k[1], c.key_bytes + (r.kl.y > 0 ? r.ko.y : 0u), 16);
+    __builtin_memcpy(&k.k[2], c.key_bytes + (r.kl.z > 0 ? r.ko.z : 0u), 16);
+    __builtin_memcpy(&k.k[3], c.key_bytes + (r.kl.w > 0 ? r.ko.w : 0u), 16);
 }
 
-#ifdef KTA_HASH_NOINLINE   /* experiment of tools/ubench_alive.hip: the general-length path out of line (code size) */
-__device__ __attribute__((noinline)) uint32_t fnv32_more_ool(uint32_t h, const uint8_t *k, uint32_t len) { return fnv32_more(h, k, len); }
-#else
-__device__ __forceinline__ uint32_t fnv32_more_ool(uint32_t h, const uint8_t *k, uint32_t len) { return fnv32_more(h, k, len); }
-#endif
+// pool control words (device memory, zeroed before every launch pair)
+enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_WORDS = 2 };
 
-// FNV of a key whose first 16 bytes are in registers
-__device__ __forceinline__ uint32_t fnv32_prefetched(const uint4 &k16, const uint8_t *key, uint32_t len)
-{
-    if (len == 16u) return fnv_16(kFnvInit, k16);
-    if (len > 16u) return fnv32_more_ool(fnv_16(kFnvInit, k16), key + 16, len - 16u);
-    const uint32_t w[4] = {k16.x, k16.y, k16.z, k16.w};
-    uint32_t h = kFnvInit;
-#pragma unroll
-    for (uint32_t d = 0; d < 3; d++)
-        if (len >= 4u * (d + 1u)) h = fnv_word(h, w[d]);
-    const uint32_t q = len >> 2;
-    uint32_t tw = q == 0u ? w[0] : (q == 1u ? w[1] : (q == 2u ? w[2] : w[3]));
-    for (uint32_t t = len & 3u; t > 0u; t--) {
-        h = fnv_byte(h, tw & 0xFFu);
-        tw >>= 8;
-    }
-    return h;
-}
-
-// LDS address (in pairs) of position p of bucket b's ring.  A ring is one 128-byte row, so without a twist
-// every bucket's entry k would sit in the same two banks; rows are rotated by 2 * (b & 7) entries (an even
-// rotation keeps the 16-byte pieces of a block aligned).
-__device__ __forceinline__ uint32_t ring_at(uint32_t b, uint32_t p)
-{
-    return b * kRing + ((p + 2u * (b & 7u)) & (kRing - 1));
-}
-
-// Write the completed 64-byte blocks [from, to & ~7) of up to kPartRecs segments from their rings (aligned:
-// cap is a multiple of 8), and forget them.
+// pair = h << 32 | (batch-local index + 1) << 1 | alive       (index < 2^31 - 1: a pair is never zero)
+//
+// Per bucket in LDS: a ring of 16 pairs (two blocks of 8 = 64 bytes), a position counter, and one word per
+// ring half = (times this half was written out) << 4 | (pairs of the current block that have arrived).
+// Position p of a bucket belongs to block p >> 3, which uses half (p >> 3) & 1 once that half has been
+// written out (p >> 4) times.
 template <int BLOG2>
-__device__ __forceinline__ void flush_blocks(const unsigned long long *s_ring, unsigned long long *__restrict__ pairs,
-                                             uint32_t W, uint32_t w, uint32_t cap, uint32_t (&pb)[kPartRecs],
-                                             uint32_t (&from)[kPartRecs], uint32_t (&to)[kPartRecs])
-{
-#pragma unroll
-    for (int j = 0; j < kPartRecs; j++) {
-        unsigned long long *seg = pairs + ((uint64_t)pb[j] * W + w) * cap;
-        for (uint32_t blk = from[j]; blk + 8 <= to[j]; blk += 8) {
-            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(seg + blk);
-            const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(pb[j], blk));
-            const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(pb[j], blk + 2));
-            const ulonglong2 a2 = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(pb[j], blk + 4));
-            const ulonglong2 a3 = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(pb[j], blk + 6));
-#ifdef KTA_DBG_NOFLUSH  /* ablation build of tools/ubench_alive.hip only */
-            if (a0.x == 0x1234ull) dst[0] = a1;
-#else
-            dst[0] = a0;
-            dst[1] = a1;
-            dst[2] = a2;
-            dst[3] = a3;
-#endif
-        }
-        from[j] = to[j] = 0u;
-    }
-}
-
-// pair = h << 32 | (local index + 1) << 1 | alive       (local index < 2^31 - 1: a pair is never zero)
-template <int BLOG2>
-__global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint64_t base_seq,
+__global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint32_t skip, uint32_t tiles_per_wg,
                                                                     unsigned long long *__restrict__ pairs,
                                                                     uint32_t *__restrict__ counts, uint32_t cap,
-                                                                    unsigned long long *__restrict__ table,
-                                                                    long long *__restrict__ running)
+                                                                    unsigned long long *__restrict__ pool,
+                                                                    unsigned long long *__restrict__ pool_ctl,
+                                                                    uint32_t *__restrict__ pool_hist)
 {
     constexpr uint32_t B = 1u << BLOG2;
     KTA_PHASE_BEGIN;
-    // 128-byte aligned whatever the static LDS before it adds up to: a ring is one 128-byte row, read back in
-    // 16-byte pieces
     extern __shared__ __attribute__((aligned(128))) unsigned long long s_ring[];   // B x kRing pairs
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);   // arrivals of this round
-    uint32_t *s_fill = s_cnt + B;                                        // pairs accepted into the segment so far
-    __shared__ long long s_w[kPartThreads / 64];
-    __shared__ SpillList s_spill;
+    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);   // B positions handed out
+    uint32_t *s_half = s_pos + B;                                                 // 2B half words
+    uint32_t *s_queue = s_half + 2 * B;                                           // kPartWaves x kQueue
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        s_cnt[b] = 0;
-        s_fill[b] = 0;
+        s_pos[b] = 0;
+        s_half[2 * b] = 0;
+        s_half[2 * b + 1] = 0;
     }
-    if (threadIdx.x == 0) s_spill.n = 0;
     __syncthreads();
     const uint32_t W = gridDim.x, w = blockIdx.x;
-    const uint64_t nrounds = (n + kPartRound - 1) / kPartRound;
-    long long delta = 0;
-    // Rounds are dealt round-robin and walked from the END of the batch: what overflows into the direct
-    // path (a hot key fills its ring at once) then meets the newest records first, and the pre-read of
-    // the direct path filters the older ones.
-    if (nrounds > w) {
-        int64_t rd = (int64_t)(w + ((nrounds - 1 - w) / W) * W);
-        // Two-stage prefetch: the columns run two rounds ahead of the hash, the key bytes (whose addresses
-        // come from the columns) one round ahead — no load waits for another inside a round.  Two register
-        // sets alternate (the loop is unrolled by two): copying "next" into "current" at the end of a round
-        // would make the wave wait for the prefetch at the very place it was issued.
-        PartCols cols_a, cols_b;
-        PartKeys keys_a, keys_b;
-        load_cols(c, n, (uint64_t)rd * kPartRound, cols_a);
-        load_cols(c, n, rd >= (int64_t)W ? (uint64_t)(rd - W) * kPartRound : n, cols_b);
-        load_keys(c, cols_a, keys_a);
-        // blocks completed in the previous round, written at the START of the next one (after its hash): the
-        // stores then have a whole round to be acknowledged before this wave next waits on its memory counter
-        uint32_t pend_b[kPartRecs], pend_from[kPartRecs], pend_to[kPartRecs];
-#pragma unroll
-        for (int j = 0; j < kPartRecs; j++) pend_b[j] = pend_from[j] = pend_to[j] = 0u;
-        // one round: hash (r, keys), request the other set's keys and this set's columns of two rounds on
-        auto round = [&](PartCols &r, PartKeys &keys, PartCols &r_next, PartKeys &keys_next, int64_t rd) {
-            const uint64_t base = (uint64_t)rd * kPartRound;
-            uint32_t h[kPartRecs], alive[kPartRecs];
-            bool keyed[kPartRecs];
-#pragma unroll
-            for (int j = 0; j < kPartRecs; j++) {
-                keyed[j] = r.kl[j] >= 0;         // key None: ignored (metric.rs:302)
-                alive[j] = r.vl[j] >= 0 ? 1u : 0u;
-#ifdef KTA_DBG_NOHASH   /* ablation build of tools/ubench_alive.hip only */
-                h[j] = (keys.k16[j].x ^ keys.k16[j].y ^ keys.k16[j].z ^ keys.k16[j].w) * 0x9E3779B1u;
-#else
-                h[j] = r.kl[j] > 0 ? fnv32_prefetched(keys.k16[j], c.key_bytes + r.ko[j], (uint32_t)r.kl[j]) : kFnvInit;
-#endif
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t ntiles = (n + kTile - 1) / kTile;
+    const uint64_t first = (uint64_t)w * tiles_per_wg;
+    const uint64_t end = first + tiles_per_wg < ntiles ? first + tiles_per_wg : ntiles;
+    uint32_t *queue = s_queue + wave * kQueue;
+    uint32_t qn = 0;                                                              // wave-uniform
+
+    // write the wave's queued blocks out: four lanes per block, 16 bytes each, whole aligned 64-byte blocks
+    auto flush_queue = [&]() __attribute__((always_inline)) {
+        for (uint32_t q0 = 0; q0 < qn; q0 += 16) {
+            const uint32_t e = q0 + (lane >> 2), piece = lane & 3u;
+            const bool on = e < qn;
+            const uint32_t ent = queue[on ? e : 0u];
+            const uint32_t b = ent & (B - 1), k = ent >> BLOG2;                   // bucket, block number
+            const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(s_ring + b * kRing + (k & 1u) * 8u + piece * 2u);
+            unsigned long long *dst;
+            if ((k + 1u) * 8u <= cap) {
+                dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 8u;
+            } else {                                                              // the segment is full: to the pool
+                unsigned long long at = 0;
+                if (on && piece == 0u) {
+                    at = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
+                    atomicAdd(&pool_hist[b], 8u);
+                }
+                at = __shfl(at, (int)(lane & ~3u));
+                dst = pool + at;
             }
-            KTA_PHASE(0, 0);   // waiting for the round's loads + hashing
-            load_keys(c, r_next, keys_next);                      // their columns were requested a round ago
-            load_cols(c, n, rd >= 2 * (int64_t)W ? (uint64_t)(rd - 2 * W) * kPartRound : n, r);   // r is spent: hashed
-#ifdef KTA_DBG_NOLDS   /* ablation build of tools/ubench_alive.hip only: stream + hash, nothing else */
-            delta += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + alive[0];
-#ifdef KTA_DBG_BARRIERS
-            __syncthreads();
-            __syncthreads();
+            if (on) *reinterpret_cast<ulonglong2 *>(dst + piece * 2u) = d;
+            KTA_LDS_ORDER();
+            if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);    // the half is free again
+        }
+        qn = 0;
+    };
+
+#ifdef KTA_DBG_NOLDS
+    long long dummy = 0;
 #endif
+    if (first + wave < end) {
+        // Two-stage prefetch: the columns run two steps ahead of the hash, the key bytes (whose addresses come
+        // from the columns) one step ahead — no load waits for another inside a step.  Two register sets
+        // alternate (the loop is unrolled by two): copying "next" into "current" at the end of a step would
+        // make the wave wait for the prefetch at the very place it was issued.
+        TileCols cols_a, cols_b;
+        TileKeys keys_a, keys_b;
+        uint64_t tile = first + wave;
+        load_cols(c, n, skip, tile, true, cols_a);
+        load_cols(c, n, skip, tile + kPartWaves, tile + kPartWaves < end, cols_b);
+        load_keys(c, cols_a, keys_a);
+        auto step = [&](TileCols &r, TileKeys &keys, TileCols &r_next, TileKeys &keys_next, uint64_t t) __attribute__((always_inline)) {
+            const int32_t kl[4] = {r.kl.x, r.kl.y, r.kl.z, r.kl.w}, vl[4] = {r.vl.x, r.vl.y, r.vl.z, r.vl.w};
+            const uint32_t ko[4] = {r.ko.x, r.ko.y, r.ko.z, r.ko.w};
+            uint32_t h[4];
+            unsigned long long pr[4];
+            bool keyed[4];
+            const uint64_t i0 = t * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                keyed[j] = kl[j] >= 0;
+                h[j] = kl[j] > 0 ? fnv32_prefetched(keys.k[j], c.key_bytes + ko[j], (uint32_t)kl[j]) : kFnvInit;
+                pr[j] = ((unsigned long long)h[j] << 32) | ((unsigned long long)(i0 + j + 1) << 1) | (vl[j] >= 0 ? 1ull : 0ull);
+            }
+            KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
+            load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
+            load_cols(c, n, skip, t + 2 * kPartWaves, t + 2 * kPartWaves < end, r);   // r is spent: hashed
+#ifdef KTA_DBG_NOLDS   /* ablation build of tools/ubench_alive.hip only: stream + hash, nothing else */
+            dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
             return;
 #endif
-            flush_blocks<BLOG2>(s_ring, pairs, W, w, cap, pend_b, pend_from, pend_to);
-            __syncthreads();   // the ring entries of the flushed blocks are free again
-            // Arrivals.  Straight-line, so that the four LDS atomics (and then the four reads) of a thread
-            // are in flight together.  rank = arrival order in the bucket's round; the ring holds the
-            // positions [fill & ~7, (fill & ~7) + 16) of the segment, the segment holds cap pairs.
-            uint32_t bk[kPartRecs], rank[kPartRecs], fill[kPartRecs], room[kPartRecs];
+            // Straight-line, so that a lane's four LDS atomics (and then its four reads) are in flight together.
+            uint32_t bk[4], p[4], hw[4];
 #pragma unroll
-            for (int j = 0; j < kPartRecs; j++) bk[j] = h[j] >> (32 - BLOG2);
+            for (int j = 0; j < 4; j++) bk[j] = h[j] >> (32 - BLOG2);
 #pragma unroll
-            for (int j = 0; j < kPartRecs; j++) rank[j] = keyed[j] ? atomicAdd(&s_cnt[bk[j]], 1u) : ~0u;
+            for (int j = 0; j < 4; j++) p[j] = keyed[j] ? lds_add(&s_pos[bk[j]], 1u) : 0u;
+            KTA_LDS_ORDER();
 #pragma unroll
-            for (int j = 0; j < kPartRecs; j++) fill[j] = s_fill[bk[j]];
-            bool any_direct = false;
+            for (int j = 0; j < 4; j++) hw[j] = s_half[2 * bk[j] + ((p[j] >> 3) & 1u)];   // plain reads: four in flight
+            KTA_LDS_ORDER();
+            uint32_t pending = 0;
+            bool done[4];
+            // insert record j at its position once its ring half is free; true when that completed the block
+            auto insert = [&](int j) __attribute__((always_inline)) -> bool {
+                s_ring[bk[j] * kRing + (p[j] & (kRing - 1))] = pr[j];
+                KTA_LDS_ORDER();
+                return (lds_add(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)], 1u) & 15u) == 7u;
+            };
 #pragma unroll
-            for (int j = 0; j < kPartRecs; j++) {
-                room[j] = (fill[j] & ~7u) + kRing - fill[j];
-                if (cap - fill[j] < room[j]) room[j] = cap - fill[j];
-                if (rank[j] < room[j]) {
-                    const uint64_t i = base + (uint64_t)j * kPartThreads + threadIdx.x;
-                    s_ring[ring_at(bk[j], fill[j] + rank[j])] =
-                        ((unsigned long long)h[j] << 32) | ((unsigned long long)(i + 1) << 1) | alive[j];
-                } else if (keyed[j]) {
-                    any_direct = true;
+            for (int j = 0; j < 4; j++) {
+                const bool free_now = (hw[j] >> 4) == (p[j] >> 4);
+                done[j] = false;
+                if (keyed[j]) {
+                    if (free_now) done[j] = insert(j);
+                    else pending |= 1u << j;
                 }
             }
-            if (any_direct) {   // no room in the ring or the segment (rare): parked for the direct path
+            auto enqueue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < kPartRecs; j++) {
-                    if (!keyed[j] || rank[j] < room[j]) continue;
-                    const uint64_t i = base + (uint64_t)j * kPartThreads + threadIdx.x;
-                    const unsigned long long v = ((unsigned long long)(base_seq + i + 1) << 1) | alive[j];
-                    if (!spill_push(s_spill, h[j], v)) delta += direct_update(table, h[j], v);
+                for (int j = 0; j < 4; j++) {
+                    if (qn > kQueue - 64u) flush_queue();           // room for 64 more (wave-uniform)
+                    const unsigned long long m = __ballot(done[j]);
+                    if (done[j]) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        bk[j] | ((p[j] >> 3) << BLOG2);
+                    qn += (uint32_t)__popcll(m);
+                    done[j] = false;
                 }
-            }
-            KTA_PHASE(0, 4);   // arrivals: LDS atomics, ring writes, parking
-            __syncthreads();
-            // The first arrival of every bucket closes the bucket's round: accept what fitted, write the
-            // completed 64-byte blocks to the segment (aligned: cap is a multiple of 8).
-            uint32_t arrivals[kPartRecs];
+                KTA_LDS_ORDER();
+            };
+            enqueue();
+            flush_queue();   // every step: a completed block frees its ring half only when it is written out
+            // Rare: a position whose ring half still holds the block before last (sixteen arrivals of one
+            // bucket in flight).  Whoever holds a position in an older block never waits for a younger one, so
+            // the oldest unwritten block always completes; its writers may sit in this very wave, which is why
+            // the loop body carries the whole protocol (insert, queue, write out).
+            while (__any(pending != 0u)) {
 #pragma unroll
-            for (int j = 0; j < kPartRecs; j++) arrivals[j] = rank[j] == 0u ? s_cnt[bk[j]] : 0u;
-#pragma unroll
-            for (int j = 0; j < kPartRecs; j++) {
-                if (rank[j] != 0u) continue;
-                const uint32_t newf = fill[j] + (arrivals[j] < room[j] ? arrivals[j] : room[j]);
-                s_fill[bk[j]] = newf;
-                s_cnt[bk[j]] = 0;
-                pend_b[j] = bk[j];
-                pend_from[j] = fill[j] & ~7u;
-                pend_to[j] = newf;
+                for (int j = 0; j < 4; j++) {
+                    if (!((pending >> j) & 1u)) continue;
+                    const uint32_t word = lds_load(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)]);
+                    if ((word >> 4) != (p[j] >> 4)) continue;
+                    done[j] = insert(j);
+                    pending &= ~(1u << j);
+                }
+                enqueue();
+                flush_queue();
+                __builtin_amdgcn_s_sleep(1);
             }
-            const bool drain = s_spill.n >= kSpill / 2;     // uniform: nobody pushes between two arrival phases
-            if (drain) {
-                __syncthreads();
-                delta += spill_drain(s_spill, table);
-                __syncthreads();
-                if (threadIdx.x == 0) s_spill.n = 0;
-                __syncthreads();
-            }
-            KTA_PHASE(0, 6);   // closing the buckets
+            KTA_PHASE(0, 4);   // arrivals: LDS atomics, ring writes, queueing
         };
-        for (; rd >= 0; rd -= 2 * (int64_t)W) {
-            round(cols_a, keys_a, cols_b, keys_b, rd);
-            if (rd < (int64_t)W) break;
-            round(cols_b, keys_b, cols_a, keys_a, rd - W);
+        for (;; tile += 2 * kPartWaves) {
+            step(cols_a, keys_a, cols_b, keys_b, tile);
+            if (tile + kPartWaves >= end) break;
+            step(cols_b, keys_b, cols_a, keys_a, tile + kPartWaves);
+            if (tile + 2 * kPartWaves >= end) break;
         }
-        __syncthreads();
-        flush_blocks<BLOG2>(s_ring, pairs, W, w, cap, pend_b, pend_from, pend_to);
+        flush_queue();
     }
+#ifdef KTA_DBG_NOLDS
+    if (dummy == 0x1234567) counts[0] = 1;
+#endif
     __syncthreads();
-    delta += spill_drain(s_spill, table);
     // the last, partial block of every segment, and the segment fills for pass 2
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        const uint32_t f = s_fill[b];
-        unsigned long long *seg = pairs + ((uint64_t)b * W + w) * cap;
-        for (uint32_t p = f & ~7u; p < f; p++) seg[p] = s_ring[ring_at(b, p)];
-        counts[(uint64_t)b * W + w] = f;
+        const uint32_t f = s_pos[b], k = f >> 3, rem = f & 7u;
+        if (rem) {
+            unsigned long long *dst;
+            if ((k + 1u) * 8u <= cap) {
+                dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 8u;
+            } else {
+                dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)rem);
+                atomicAdd(&pool_hist[b], rem);
+            }
+            for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring[b * kRing + (k & 1u) * 8u + q];
+        }
+        counts[(uint64_t)b * W + w] = f < cap ? f : cap;
     }
-    add_running(delta, running, s_w);
     KTA_PHASE(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// pass 2: per-bucket merge in LDS, then the owner's read / compare / write on its table region
+// pass 2: per-bucket merge in LDS, then the survivors go to the bucket's region
 // ------------------------------------------------------------------------------------------------------
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
-constexpr int kApplyUnroll = 4;                    // 16-byte loads a lane has in flight
+constexpr int kApplyUnroll = 4;                    // 16-byte loads a lane has in flight = 8 pairs per lane and unit
 constexpr uint32_t kMaxSegWGs = 1024;              // partition workgroups (segments per bucket) at most
+constexpr uint32_t kSetLog2 = 11;                  // 2048 sets of 8 entries = 16384 entries
+constexpr uint32_t kSets = 1u << kSetLog2;
+constexpr uint32_t kEntries = kSets * 8u;
+constexpr uint32_t kOvf = 1024;                    // records that found their set full
+constexpr uint32_t kSliceSets = 128;               // sets of one bitmap slice
+constexpr uint32_t kNoFail = 0xFFFFFFFFu;
 
-// The LDS table of a workgroup: T entries in 8-way sets, as two parallel u32 arrays — tag[e] = (h << PBITS) | 1
-// (the hash without the PBITS top bits all of the workgroup's pairs share; never zero, zero = free) and val[e] = the largest
-// (local sequence + 1) << 1 | alive seen for that slot.  The set is chosen from the slot's table LINE
-// (h >> 3: the 8 slots of one 64-byte line of the table).  A merge reads the set's 8 tags (32 bytes),
-// claims a free entry with a 32-bit CAS when the slot is new, and does one 32-bit max on the value.  No
-// probing beyond the set: a wave costs what its unluckiest lane costs, so every lane does the same thing.
-// Returns 1 merged into an existing entry, 2 claimed a new one, 0 the set is full (the caller parks the
-// record for the direct path).
-// The pairs of one unit (N per lane) are merged in four phases — all set reads, then all decisions, all
-// claims, all value updates — so that a lane's N LDS round trips overlap instead of queueing up behind
-// each other.  ok[i]: 1 merged into an existing entry, 2 claimed a new one, 0 not merged (the set is full,
-// or a record of another slot took the chosen entry in the same instant: the caller parks the record for the
-// direct path).  Pairs with valid[i] false are skipped.
-template <int PBITS, int TLOG2, int N>
-__device__ __forceinline__ void set_merge_unit(uint32_t *s_tag, uint32_t *s_val, const uint32_t (&h)[N],
-                                               const uint32_t (&lo)[N], const bool (&valid)[N], int (&ok)[N])
+typedef unsigned short __attribute__((ext_vector_type(2))) ushort2v;
+
+// One lookup: which of the set's eight 16-bit tags equals `tag` (8 = none).  t = the set's 16 bytes.  The
+// entries are numbered as the halves lie in memory: entry 2 d + s is half s of dword d.
+__device__ __forceinline__ uint32_t find_tag(const uint4 &t, uint32_t tag)
 {
-    constexpr uint32_t kSetBits = TLOG2 - 3;
-    uint32_t sbase[N], tagv[N];
-    uint4 t0[N], t1[N];
+    const uint32_t rep = tag * 0x10001u;
+    const ushort2v one = {1, 1};
+    const uint32_t x[4] = {t.x ^ rep, t.y ^ rep, t.z ^ rep, t.w ^ rep};
+    uint32_t acc = 0;                              // bit d of each half: that half of dword d does NOT match
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        tagv[i] = (h[i] << PBITS) | 1u;
-        sbase[i] = (((h[i] >> 3) ^ (h[i] >> (3 + kSetBits))) & ((1u << kSetBits) - 1u)) << 3;
-        t0[i] = *reinterpret_cast<const uint4 *>(s_tag + sbase[i]);
-        t1[i] = *reinterpret_cast<const uint4 *>(s_tag + sbase[i] + 4);
+    for (int d = 0; d < 4; d++) {
+        ushort2v v;
+        __builtin_memcpy(&v, &x[d], 4);
+        v = __builtin_elementwise_min(v, one);
+        uint32_t z;
+        __builtin_memcpy(&z, &v, 4);
+        acc |= z << d;
     }
-    uint32_t idx[N];
-    bool claim[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const uint32_t t[8] = {t0[i].x, t0[i].y, t0[i].z, t0[i].w, t1[i].x, t1[i].y, t1[i].z, t1[i].w};
-        uint32_t m = 8u, e = 8u;       // the entry holding this slot, else the first free entry, else none (8)
-#pragma unroll
-        for (int j = 7; j >= 0; j--) {
-            e = t[j] == 0u ? (uint32_t)j : e;
-            m = t[j] == tagv[i] ? (uint32_t)j : m;
-        }
-        claim[i] = valid[i] && m == 8u && e < 8u;
-        ok[i] = valid[i] && m < 8u ? 1 : 0;
-        idx[i] = m < 8u ? m : e;
-    }
-    uint32_t old[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) old[i] = claim[i] ? atomicCAS(&s_tag[sbase[i] + idx[i]], 0u, tagv[i]) : 1u;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        // the entry is this slot's if the CAS took it or another record of the same slot just did
-        if (claim[i]) ok[i] = old[i] == 0u ? 2 : (old[i] == tagv[i] ? 1 : 0);
-        if (ok[i]) atomicMax(&s_val[sbase[i] + idx[i]], lo[i]);
-    }
+    const uint32_t m = ~acc & 0x000F000Fu;
+    const uint32_t lo = m & 0xFu, hi = m >> 16;    // dwords whose low / high half match
+    if ((lo | hi) == 0u) return 8u;
+    return lo ? 2u * (uint32_t)__builtin_ctz(lo) : 2u * (uint32_t)__builtin_ctz(hi) + 1u;
 }
 
-// The survivors of the LDS table, one per slot, go to the table region this workgroup owns: it is the
-// region's only writer during this kernel (its own direct-path atomics are complete: barrier), so read /
-// compare / write needs no RMW atomic.  Loads and stores are agent-scope so that they see, and are seen
-// by, the atomics of the direct path and of other kernels.  Leaves the LDS table empty.
-// One 8-byte update of a 64-byte block is a memory-side read-modify-write at 28 G/s whichever instruction
-// asks for it (tools/ubench_scatter.hip), and that rate is what this sweep runs at (8.8 k updates per bucket
-// in 87 us).  Two ways around it were built, measured on the config-3 shape and dropped: (1) appending the
-// survivors to a list that a third kernel applies with atomicMax on a second stream, under the next batch's
-// partition kernel — the concurrent atomics slowed that kernel by more than they saved (1.61 vs 1.43 ms per
-// batch); (2) whole-line updates — the sets are chosen by table line, so the first survivor of a line in
-// its set can read the 64-byte line, apply the line's survivors and write it back whole (no partial
-// write) — 140 us per bucket instead of 87: random 64-byte read + write pairs through L2 cost more than the
-// partial writes they replace.
-template <int PBITS, int TLOG2>
-__device__ __forceinline__ long long sweep_table(uint32_t *s_tag, uint32_t *s_val, uint32_t prefix,
-                                                 unsigned long long *__restrict__ table, uint64_t seq2)
-{
-    constexpr uint32_t T = 1u << TLOG2;
-    constexpr int kSweep = T / kApplyThreads;
-    static_assert(kSweep % 4 == 0, "sweep unroll");
-    long long delta = 0;
-    for (int e0 = 0; e0 < kSweep; e0 += 4) {
-        uint32_t tg[4], lo[4], slot[4];
-        unsigned long long old[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t e = (uint32_t)(e0 + u) * kApplyThreads + threadIdx.x;
-            tg[u] = s_tag[e];
-            lo[u] = s_val[e];
-            s_tag[e] = 0u;
-            s_val[e] = 0u;
-            slot[u] = (prefix << (32 - PBITS)) | (tg[u] >> PBITS);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            old[u] = tg[u] ? __hip_atomic_load(&table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned long long v = seq2 + lo[u];
-            if (tg[u] && v > old[u]) {
-                __hip_atomic_store(&table[slot[u]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                delta += (long long)(v & 1ull) - (long long)(old[u] & 1ull);
-            }
-        }
-    }
-    return delta;
-}
+struct ApplyShared {
+    uint32_t occ, pairs, claims, ovf_n, fail, decision, slice_mask, growth;
+    long long w[kApplyWaves];
+};
 
-template <int BLOG2, int TLOG2>
+// BITMAP: the persistent state is the reference's bit set (u32 words, bit h & 31 of word h >> 5); else the
+// u64 last-writer table.
+template <int BLOG2, bool BITMAP>
 __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned long long *__restrict__ pairs,
                                                                  const uint32_t *__restrict__ counts, uint32_t cap,
                                                                  uint32_t W, uint64_t base_seq,
+                                                                 const uint64_t *__restrict__ seq_col,
                                                                  unsigned long long *__restrict__ table,
+                                                                 uint32_t *__restrict__ bitmap,
                                                                  long long *__restrict__ running,
-                                                                 unsigned long long *__restrict__ stats)
+                                                                 unsigned long long *__restrict__ stats,
+                                                                 const uint32_t *__restrict__ pool_hist,
+                                                                 uint32_t *__restrict__ fail_from,
+                                                                 unsigned long long *__restrict__ pool_ctl,
+                                                                 const uint32_t *__restrict__ skip_flag)
 {
-    constexpr uint32_t T = 1u << TLOG2;
+    constexpr uint32_t RBITS = 32 - BLOG2;             // hash bits below the bucket
+    constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
+    static_assert(TAGBITS <= 15, "tags are 16 bit");
+    constexpr uint32_t kSlices = kSets / kSliceSets;
+    constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
+    static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
+    // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
+    // records that found their set full stay short up to about 0.75 load
+    constexpr uint32_t kFlushAt = kEntries / 2 + kEntries / 4;
     KTA_PHASE_BEGIN;
-    // A bucket with more distinct slots than the table takes (a batch of mostly unique keys) is applied in
-    // instalments: once this many entries are claimed the survivors so far are swept out and the table
-    // starts empty again — exact, because the region's entries carry their sequence numbers.
-    constexpr uint32_t kFlushAt = T / 2 + T / 16 + T / 32;
-    // aligned: a set's 8 tags are read as two 16-byte pieces, and the dynamic LDS starts wherever the static
-    // LDS of the kernel ends — a misaligned ds_read_b128 is split by the hardware
-    extern __shared__ __attribute__((aligned(128))) uint32_t s_tag[];   // T tags, T values, then the segment fills
-    uint32_t *s_val = s_tag + T;
-    uint32_t *s_cnt = s_val + T;
-    __shared__ uint32_t s_occ, s_pairs, s_claims;
-    __shared__ long long s_w[kApplyWaves];
-    __shared__ SpillList s_spill;
-    constexpr int PBITS = BLOG2;       // the hash bits all pairs of the bucket share
-    const uint32_t b = blockIdx.x, prefix = b;
-    for (uint32_t e = threadIdx.x; e < 2 * T; e += kApplyThreads) s_tag[e] = 0u;
+    extern __shared__ __attribute__((aligned(128))) uint32_t s_val[];        // kEntries values
+    unsigned short *s_tag = reinterpret_cast<unsigned short *>(s_val + kEntries);   // kEntries tags
+    uint32_t *s_setcnt = reinterpret_cast<uint32_t *>(s_tag + kEntries);     // entries handed out per set
+    unsigned long long *s_ovf = reinterpret_cast<unsigned long long *>(s_setcnt + kSets);   // kOvf pairs
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ovf + kOvf);            // W segment fills
+    uint32_t *s_slice = s_cnt + ((W + 31u) & ~31u);                          // BITMAP: one slice of the region
+    __shared__ ApplyShared sh;
+    const uint32_t b = blockIdx.x;
+    if (skip_flag && *skip_flag) return;               // the batch was handed to another path (unordered seq column)
+    if (BITMAP) {
+        // a bucket with pool pairs is not attempted: its pairs are not all in its segments
+        if (pool_hist[b] != 0u) {
+            if (threadIdx.x == 0) {
+                fail_from[b] = 0u;
+                atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
+            }
+            return;
+        }
+        if (threadIdx.x == 0) fail_from[b] = kNoFail;
+    }
+    for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + kSets; e += kApplyThreads) s_val[e] = 0u;   // values, tags, set counts
     if (threadIdx.x == 0) {
-        s_occ = 0;
-        s_pairs = 0;
-        s_claims = 0;
-        s_spill.n = 0;
+        sh.occ = 0;
+        sh.pairs = 0;
+        sh.claims = 0;
+        sh.ovf_n = 0;
+        sh.fail = 0;
+        sh.decision = 0;
+        sh.slice_mask = 0;
+        sh.growth = 0;
     }
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
         const uint32_t cw = counts[(uint64_t)b * W + w];
         s_cnt[w] = cw;
-        atomicAdd(&s_pairs, cw);
+        if (cw) atomicAdd(&sh.pairs, cw);
     }
     __syncthreads();
+    if (sh.pairs == 0u) return;                        // nothing hashed into this bucket: the region is not touched
     KTA_PHASE(1, 0);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     long long delta = 0;
-    const uint64_t seq2 = base_seq << 1;
-    // A wave reads its segments (every kApplyWaves-th of the bucket) in units of up to kApplyUnroll 16-byte
-    // loads per lane = 512 pairs, masked by the segment's fill (cap is a multiple of 128).  The loads of
-    // unit u + 1 are issued before unit u is merged, so a wave always has a unit in flight.
-    const unsigned long long *region = pairs + (uint64_t)b * W * cap;
+
+    // global value of a survivor (table state): ((sequence + 1) << 1) | alive
+    auto global_val = [&](uint32_t lo) -> unsigned long long {
+        const uint64_t idx = (uint64_t)(lo >> 1) - 1u;
+        const uint64_t s = seq_col ? seq_col[idx] : base_seq + idx;
+        return ((unsigned long long)(s + 1) << 1) | (lo & 1u);
+    };
+
+    // ---- end of an instalment: resolve duplicates and the full-set list, apply, leave the table empty ----
+    // (every lambda of this kernel is forced inline: out of line, its captures live in scratch memory and the LDS
+    // pointers among them lose their address space — flat instead of ds instructions)
+    auto end_instalment = [&]() __attribute__((always_inline)) {
+        // (1) duplicates.  Lookups run ahead of claims (four pairs of a lane are looked up together, waves
+        // race), so one slot can hold two entries of its set: keep the larger value in the first.
+        for (uint32_t s = threadIdx.x; s < kSets; s += kApplyThreads) {
+            const uint4 t4 = *reinterpret_cast<const uint4 *>(s_tag + s * 8u);
+            if ((t4.x | t4.y | t4.z | t4.w) == 0u) continue;
+            if (BITMAP) atomicOr(&sh.slice_mask, 1u << (s / kSliceSets));
+            const uint32_t t[8] = {t4.x & 0xFFFFu, t4.x >> 16, t4.y & 0xFFFFu, t4.y >> 16,
+                                   t4.z & 0xFFFFu, t4.z >> 16, t4.w & 0xFFFFu, t4.w >> 16};
+            bool dup = false;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) dup |= t[i] != 0u && t[i] == t[j];
+            if (!dup) continue;
+            for (int i = 0; i < 8; i++)
+                for (int j = i + 1; j < 8; j++) {
+                    if (s_tag[s * 8u + i] == 0 || s_tag[s * 8u + i] != s_tag[s * 8u + j]) continue;
+                    const uint32_t vi = s_val[s * 8u + i], vj = s_val[s * 8u + j];
+                    s_val[s * 8u + i] = vi > vj ? vi : vj;
+                    s_tag[s * 8u + j] = 0;
+                    s_val[s * 8u + j] = 0u;
+                }
+        }
+        __syncthreads();
+        // (2) the records that found their set full: the slot may have entered the set meanwhile (-> max into
+        // its entry); otherwise the record with the largest value per slot of the list survives on its own.
+        const uint32_t novf = sh.ovf_n < kOvf ? sh.ovf_n : kOvf;
+        for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
+            const unsigned long long pr = s_ovf[k];
+            const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u), lo = (uint32_t)pr;
+            const uint32_t set = h >> TAGBITS, tag = (h & ((1u << TAGBITS) - 1u)) + 1u;
+            const uint32_t e = find_tag(*reinterpret_cast<const uint4 *>(s_tag + set * 8u), tag);
+            bool keep = e == 8u;
+            if (!keep) atomicMax(&s_val[set * 8u + e], lo);
+            for (uint32_t q = 0; keep && q < novf; q++) {
+                const unsigned long long o = s_ovf[q];
+                // the same slot with a larger value (or the same pair at a lower position) wins
+                if ((uint32_t)(o >> 32) == (uint32_t)(pr >> 32) && ((uint32_t)o > lo || ((uint32_t)o == lo && q < k))) keep = false;
+            }
+            if (!keep) s_ovf[k] = 0ull;                 // (a pair is never zero)
+        }
+        __syncthreads();
+        if (BITMAP) {
+            // (3) the region of the bit set, slice by slice through LDS: a slice = the slots of 128 consecutive sets
+            uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
+            const uint32_t mask = sh.slice_mask | (novf ? (1u << kSlices) - 1u : 0u);
+            uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+            uint32_t s = mask ? (uint32_t)__builtin_ctz(mask) : kSlices;
+            if (s < kSlices) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(region + (size_t)s * kSliceWords);
+                pre0 = src[threadIdx.x];
+                pre1 = src[threadIdx.x + kApplyThreads];
+            }
+            while (s < kSlices) {
+                uint4 *sl = reinterpret_cast<uint4 *>(s_slice);
+                sl[threadIdx.x] = pre0;
+                sl[threadIdx.x + kApplyThreads] = pre1;
+                const uint32_t rest = mask & ~((2u << s) - 1u);
+                const uint32_t nxt = rest ? (uint32_t)__builtin_ctz(rest) : kSlices;
+                if (nxt < kSlices) {                     // the next slice is requested while this one is worked on
+                    const uint4 *src = reinterpret_cast<const uint4 *>(region + (size_t)nxt * kSliceWords);
+                    pre0 = src[threadIdx.x];
+                    pre1 = src[threadIdx.x + kApplyThreads];
+                }
+                __syncthreads();
+                {   // one entry per thread: the slice's 128 sets x 8 entries
+                    const uint32_t e = s * (kSliceSets * 8u) + threadIdx.x;
+                    const uint32_t tag = s_tag[e], lo = s_val[e];
+                    if (tag) {
+                        const uint32_t bit = ((threadIdx.x >> 3) << TAGBITS) | (tag - 1u);
+                        const uint32_t m = 1u << (bit & 31u);
+                        const uint32_t old = lo & 1u ? atomicOr(&s_slice[bit >> 5], m) : atomicAnd(&s_slice[bit >> 5], ~m);
+                        delta += (long long)(lo & 1u) - (long long)((old & m) != 0u);
+                        s_tag[e] = 0;
+                        s_val[e] = 0u;
+                    }
+                }
+                for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
+                    const unsigned long long pr = s_ovf[k];
+                    if (pr == 0ull) continue;
+                    const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u), lo = (uint32_t)pr;
+                    if ((h >> TAGBITS) / kSliceSets != s) continue;
+                    const uint32_t bit = h & ((kSliceSets << TAGBITS) - 1u);
+                    const uint32_t m = 1u << (bit & 31u);
+                    const uint32_t old = lo & 1u ? atomicOr(&s_slice[bit >> 5], m) : atomicAnd(&s_slice[bit >> 5], ~m);
+                    delta += (long long)(lo & 1u) - (long long)((old & m) != 0u);
+                }
+                __syncthreads();
+                uint4 *dst = reinterpret_cast<uint4 *>(region + (size_t)s * kSliceWords);
+                dst[threadIdx.x] = sl[threadIdx.x];
+                dst[threadIdx.x + kApplyThreads] = sl[threadIdx.x + kApplyThreads];
+                __syncthreads();                        // the slice is read out before the next one lands in it
+                s = nxt;
+            }
+        } else {
+            // (3) the workgroup is its region's only writer during this kernel (its own direct-path atomics
+            // are complete: barrier), so read / compare / write needs no RMW atomic.  Loads and stores are
+            // agent-scope so that they see, and are seen by, the atomics of the direct path and other kernels.
+            for (uint32_t e0 = 0; e0 < kEntries; e0 += 4 * kApplyThreads) {
+                uint32_t tg[4], lo[4], slot[4];
+                unsigned long long v[4], old[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t e = e0 + (uint32_t)u * kApplyThreads + threadIdx.x;
+                    tg[u] = s_tag[e];
+                    lo[u] = s_val[e];
+                    s_tag[e] = 0;
+                    s_val[e] = 0u;
+                    slot[u] = (b << RBITS) | ((e >> 3) << TAGBITS) | (tg[u] - 1u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = tg[u] ? global_val(lo[u]) : 0ull;
+                    old[u] = tg[u] ? __hip_atomic_load(&table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (tg[u] && v[u] > old[u]) {
+                        __hip_atomic_store(&table[slot[u]], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        delta += (long long)(v[u] & 1ull) - (long long)(old[u] & 1ull);
+                    }
+            }
+            __syncthreads();                            // the plain writes are out before the list's atomics
+            for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
+                const unsigned long long pr = s_ovf[k];
+                if (pr) delta += direct_update(table, (b << RBITS) | ((uint32_t)(pr >> 32) & ((1u << RBITS) - 1u)), global_val((uint32_t)pr));
+            }
+        }
+        for (uint32_t s = threadIdx.x; s < kSets; s += kApplyThreads) s_setcnt[s] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            sh.claims += sh.occ;
+            sh.occ = 0;
+            sh.ovf_n = 0;
+            sh.slice_mask = 0;
+            sh.growth = 0;
+        }
+        __syncthreads();
+    };
+
+    // A wave reads its segments (every kApplyWaves-th of the bucket, in ascending order) in units of up to
+    // kApplyUnroll 16-byte loads per lane = 512 pairs, masked by the segment's fill (cap is a multiple of 128).
+    // The loads of unit u + 1 are issued before unit u is merged, so a wave always has a unit in flight.
+    const unsigned long long *region_pairs = pairs + (uint64_t)b * W * cap;
     const uint32_t loads = cap >> 7;
     const uint32_t chunks = (loads + kApplyUnroll - 1) / kApplyUnroll;
-    const uint32_t units = ((W + kApplyWaves - 1) / kApplyWaves) * chunks;      // the same for every wave
+    const uint32_t groups = (W + kApplyWaves - 1) / kApplyWaves;
+    const uint32_t units = groups * chunks;                                     // the same for every wave
     ulonglong2 p[kApplyUnroll], pn[kApplyUnroll];
     uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2
     auto issue = [&](uint32_t u, ulonglong2 (&q)[kApplyUnroll], uint32_t (&qv)[kApplyUnroll]) {
         const uint32_t w = (u / chunks) * kApplyWaves + wave, r0 = (u % chunks) * kApplyUnroll;
         const uint32_t cnt = u < units && w < W ? s_cnt[w] : 0u;
-        const unsigned long long *seg = region + (uint64_t)(u < units && w < W ? w : 0u) * cap;
+        const unsigned long long *seg = region_pairs + (uint64_t)(u < units && w < W ? w : 0u) * cap;
 #pragma unroll
         for (int x = 0; x < kApplyUnroll; x++) {
             const uint32_t k = ((r0 + (uint32_t)x) << 7) + 2u * lane;
@@ -595,135 +695,330 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     };
     issue(0, p, nv);
     uint32_t claimed = 0;
-    // merge the unit held in (q, qv)
+    // merge the unit held in (q, qv): two groups of four pairs, each group's four lookups in flight together
     auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll]) {
-        uint32_t failed = 0;                                  // bit i: pair i of the unit was not merged
 #pragma unroll
-        for (int x = 0; x < 2 * kApplyUnroll; x++) {          // one pair after the other (batching them costs registers, gains nothing)
-            const uint32_t hh[1] = {(uint32_t)((x & 1 ? q[x >> 1].y : q[x >> 1].x) >> 32)};
-            const uint32_t ll[1] = {(uint32_t)(x & 1 ? q[x >> 1].y : q[x >> 1].x)};
-            const bool vv[1] = {qv[x >> 1] > (uint32_t)(x & 1)};
-            int ok[1];
-            set_merge_unit<PBITS, TLOG2, 1>(s_tag, s_val, hh, ll, vv, ok);
-            claimed += ok[0] == 2 ? 1u : 0u;
-            failed |= (vv[0] && ok[0] == 0 ? 1u : 0u) << x;
-        }
-        if (failed) {   // once per unit: a set was full, or lost a claim to another slot's record — park for the direct path
+        for (int g = 0; g < 2; g++) {
+            uint32_t set[4], tag[4], lo[4];
+            uint4 t[4];
+            bool valid[4];
 #pragma unroll
-            for (int x = 0; x < kApplyUnroll; x++) {
-                const uint32_t h0 = (uint32_t)(q[x].x >> 32), l0 = (uint32_t)q[x].x;
-                const uint32_t h1 = (uint32_t)(q[x].y >> 32), l1 = (uint32_t)q[x].y;
-                if ((failed >> (2 * x)) & 1u)
-                    if (!spill_push(s_spill, h0, seq2 + l0)) delta += direct_update(table, h0, seq2 + l0);
-                if ((failed >> (2 * x)) & 2u)
-                    if (!spill_push(s_spill, h1, seq2 + l1)) delta += direct_update(table, h1, seq2 + l1);
+            for (int i = 0; i < 4; i++) {
+                const int x = g * 4 + i;
+                const unsigned long long pr = x & 1 ? q[x >> 1].y : q[x >> 1].x;
+                const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u);
+                valid[i] = qv[x >> 1] > (uint32_t)(x & 1);
+                lo[i] = (uint32_t)pr;
+                set[i] = h >> TAGBITS;
+                tag[i] = (h & ((1u << TAGBITS) - 1u)) + 1u;
+                t[i] = *reinterpret_cast<const uint4 *>(s_tag + set[i] * 8u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (!valid[i]) continue;
+                uint32_t e = find_tag(t[i], tag[i]);
+                if (e == 8u) {                            // a new slot: the set hands out its next entry
+                    e = lds_add(&s_setcnt[set[i]], 1u);
+                    if (e < 8u) {
+                        s_tag[set[i] * 8u + e] = (unsigned short)tag[i];
+                        claimed++;
+                    } else {                              // the set is full: to the list (or, the list full too, give up here)
+                        const uint32_t k = lds_add(&sh.ovf_n, 1u);
+                        const unsigned long long pr = ((unsigned long long)((set[i] << TAGBITS) | (tag[i] - 1u)) << 32) | lo[i];
+                        if (k < kOvf) s_ovf[k] = pr;
+                        else if (BITMAP) sh.fail = 1u;
+                        else delta += direct_update(table, (b << RBITS) | (uint32_t)(pr >> 32), global_val(lo[i]));
+                        continue;
+                    }
+                }
+                atomicMax(&s_val[set[i] * 8u + e], lo[i]);
             }
         }
     };
-    // every fourth unit: does the table need sweeping out, or the parked records draining?
-    auto checkpoint = [&](uint32_t u) {
+    // After a group of segments (every wave has finished one segment): has the table to be emptied?  In bitmap
+    // state only here, between two groups: everything merged so far is older than everything that follows.
+    uint32_t inst_start = 0;                            // first segment of the current instalment
+    auto checkpoint = [&](uint32_t u) __attribute__((always_inline)) -> bool {         // false: the bucket is given up (bitmap state)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
-        if (lane == 0 && claimed) atomicAdd(&s_occ, claimed);
+        if (lane == 0 && claimed) atomicAdd(&sh.occ, claimed);
         claimed = 0;
         __syncthreads();
-        const bool flush = s_occ >= kFlushAt && u + 1 < units;      // uniform: read between two barriers
-        const bool drain = s_spill.n >= kSpill / 2 || flush;        // (the direct path must not run beside a sweep)
-        if (drain) {
-            delta += spill_drain(s_spill, table);
-            __syncthreads();
-            if (threadIdx.x == 0) s_spill.n = 0;
-            if (flush) {
-                delta += sweep_table<PBITS, TLOG2>(s_tag, s_val, prefix, table, seq2);
-                if (threadIdx.x == 0) {
-                    s_claims += s_occ;
-                    s_occ = 0;
-                }
-            }
-            __syncthreads();
+        if (threadIdx.x == 0) {
+            // flush when the next group, growing like the last one, would take the table past kFlushAt
+            const uint32_t grew = sh.occ - sh.growth;
+            sh.growth = sh.occ;
+            const bool more = u + 1 < units;
+            const bool full = sh.occ + grew + grew / 4 > kFlushAt || sh.ovf_n > kOvf / 2;
+            sh.decision = (sh.fail ? 2u : 0u) | (more && full ? 1u : 0u);
         }
+        __syncthreads();
+        const uint32_t d = sh.decision;
+        if (d & 2u) return false;
+        if (d & 1u) {
+            end_instalment();
+            inst_start = ((u + 1) / chunks) * kApplyWaves;
+        }
+        return true;
     };
     // Two units per trip, the buffers alternating: copying the prefetched registers into the current ones at the
     // end of an iteration would make the compiler wait for the prefetch right where it was issued.
     // The prefetch is issued unconditionally (a unit past the end loads a clamped address and merges nothing):
     // under a branch the compiler could not count it and would wait with vmcnt(0).
-    for (uint32_t u = 0; u < units; u += 2) {
+    bool ok = true;
+    for (uint32_t u = 0; u < units && ok; u += 2) {
         issue(u + 1, pn, nvn);
         merge(p, nv);
-        if ((u & 3u) == 3u || u + 1 >= units) checkpoint(u);
+        if ((u + 1) % chunks == 0u) ok = checkpoint(u);
+        if (!ok) break;
         issue(u + 2, p, nv);
         merge(pn, nvn);
-        if (((u + 1) & 3u) == 3u || u + 2 == units) checkpoint(u + 1);
+        if (u + 1 < units && (u + 2) % chunks == 0u) ok = checkpoint(u + 1);
     }
-    delta += spill_drain(s_spill, table);
-    __syncthreads();
+    if (BITMAP && !ok) {                                // handed to kta_alive_fallback from this instalment on
+        if (threadIdx.x == 0) {
+            fail_from[b] = inst_start;
+            atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
+        }
+        return;
+    }
     KTA_PHASE(1, 1);
-    delta += sweep_table<PBITS, TLOG2>(s_tag, s_val, prefix, table, seq2);
-    add_running(delta, running, s_w);
+    end_instalment();
+    add_running(delta, running, sh.w);
     // what the host's choice of kernel for the NEXT batch feeds on: pairs read, entries claimed (one per
     // distinct slot and instalment) — their ratio says how much of the batch died in LDS
     if (stats && threadIdx.x == 0) {
-        atomicAdd(&stats[0], (unsigned long long)s_pairs);
-        atomicAdd(&stats[1], (unsigned long long)(s_claims + s_occ));
+        atomicAdd(&stats[0], (unsigned long long)sh.pairs);
+        atomicAdd(&stats[1], (unsigned long long)sh.claims);
     }
     KTA_PHASE(1, 2);
 }
 
-template <int BLOG2, int TLOG2>
-hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table, int64_t *running,
-                       const AlivePartitionPlan &pl, uint64_t *pairs, uint32_t *counts, uint64_t *stats, hipStream_t s)
+// Table state: the pool pairs (segments that were full) take the direct path.
+__global__ __launch_bounds__(kWG) void kta_alive_pool_direct(const unsigned long long *__restrict__ pool,
+                                                             const unsigned long long *__restrict__ pool_ctl,
+                                                             uint64_t base_seq, const uint64_t *__restrict__ seq_col,
+                                                             unsigned long long *__restrict__ table,
+                                                             long long *__restrict__ running,
+                                                             const uint32_t *__restrict__ skip_flag)
 {
-    unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
-    unsigned long long *pp = reinterpret_cast<unsigned long long *>(pairs);
-    long long *run = reinterpret_cast<long long *>(running);
-    const size_t lds1 = ((size_t)8 * kRing + 8) << BLOG2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    __shared__ long long s_w[kWG / 64];
+    const unsigned long long n = pool_ctl[POOL_CURSOR];
+    if (n == 0ull || (skip_flag && *skip_flag)) return;
+    long long delta = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kWG + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * kWG) {
+        const unsigned long long pr = pool[k];
+        const uint64_t idx = (uint64_t)((uint32_t)pr >> 1) - 1u;
+        const uint64_t s = seq_col ? seq_col[idx] : base_seq + idx;
+        delta += direct_update(table, (uint32_t)(pr >> 32), ((unsigned long long)(s + 1) << 1) | (pr & 1ull));
+    }
+    add_running(delta, running, s_w);
+}
+
+// Bitmap state: the buckets pass 2 gave up (fail_from[b] != kNoFail), exactly, whatever they hold: the
+// bucket's region in sub-ranges of 2^15 slots, each resolved in a direct-indexed LDS array (largest index per
+// slot) over ALL pairs of the bucket from segment fail_from[b] on plus the bucket's pool pairs.  Slow (every
+// pass re-reads the bucket's pairs) and only ever needed by batches that defeat the sizes of pass 1 / 2.
+template <int BLOG2>
+__global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const unsigned long long *__restrict__ pairs,
+                                                                    const uint32_t *__restrict__ counts, uint32_t cap,
+                                                                    uint32_t W, const unsigned long long *__restrict__ pool,
+                                                                    const unsigned long long *__restrict__ pool_ctl,
+                                                                    const uint32_t *__restrict__ fail_from,
+                                                                    uint32_t *__restrict__ bitmap,
+                                                                    long long *__restrict__ running)
+{
+    constexpr uint32_t RBITS = 32 - BLOG2;
+    constexpr uint32_t kSub = 1u << 15;                  // slots per pass
+    extern __shared__ __attribute__((aligned(128))) uint32_t s_max[];   // kSub values
+    __shared__ long long s_w[kApplyWaves];
+    if (pool_ctl[POOL_FAILED] == 0ull) return;
+    const uint32_t b = blockIdx.x, from = fail_from[b];
+    if (from == kNoFail) return;
+    const unsigned long long npool = pool_ctl[POOL_CURSOR];
+    uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
+    long long delta = 0;
+    for (uint32_t r = 0; r < (1u << RBITS) / kSub; r++) {
+        for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0u;
+        __syncthreads();
+        for (uint32_t w = from; w < W; w++) {
+            const uint32_t cnt = counts[(uint64_t)b * W + w];
+            const unsigned long long *seg = pairs + ((uint64_t)b * W + w) * cap;
+            for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) {
+                const unsigned long long pr = seg[k];
+                const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u);
+                if (h / kSub == r) atomicMax(&s_max[h % kSub], (uint32_t)pr);
+            }
+        }
+        for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
+            const unsigned long long pr = pool[k];
+            const uint32_t hh = (uint32_t)(pr >> 32);
+            if ((hh >> RBITS) != b) continue;
+            const uint32_t h = hh & ((1u << RBITS) - 1u);
+            if (h / kSub == r) atomicMax(&s_max[h % kSub], (uint32_t)pr);
+        }
+        __syncthreads();
+        for (uint32_t wd = threadIdx.x; wd < kSub / 32; wd += kApplyThreads) {
+            uint32_t set_m = 0, clr_m = 0;
+            for (uint32_t bit = 0; bit < 32; bit++) {
+                const uint32_t v = s_max[wd * 32 + bit];
+                if (v) (v & 1u ? set_m : clr_m) |= 1u << bit;
+            }
+            if (set_m | clr_m) {
+                uint32_t *word = region + (size_t)r * (kSub / 32) + wd;
+                const uint32_t old = *word, neu = (old | set_m) & ~clr_m;
+                *word = neu;
+                delta += (long long)__popc(neu) - (long long)__popc(old);
+            }
+        }
+        __syncthreads();
+    }
+    add_running(delta, running, s_w);
+}
+
+// seq column of a batch: strictly ascending?  (the merge of pass 2 orders a batch's records by their index)
+__global__ __launch_bounds__(kWG) void kta_seq_ascending(const uint64_t *__restrict__ seq, uint64_t n, uint32_t *flag)
+{
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i + 1 < n; i += (uint64_t)gridDim.x * kWG) bad |= seq[i] >= seq[i + 1];
+    if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
+}
+
+// bit set state: table of bits -> count (sum_all_alive, metric.rs:282-284)
+__global__ __launch_bounds__(kWG) void kta_bitmap_count(const uint4 *__restrict__ words, uint64_t n16, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    unsigned long long cnt = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * kWG) {
+        const uint4 v = words[i];
+        cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+template <int BLOG2>
+hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
+                       const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
+{
+    constexpr uint32_t B = 1u << BLOG2;
+    unsigned long long *pp = reinterpret_cast<unsigned long long *>(ws.pairs);
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(ws.pool);
+    unsigned long long *ctl = reinterpret_cast<unsigned long long *>(ws.pool_ctl);
+    long long *run = reinterpret_cast<long long *>(st.running);
+    // pool control words, pool histogram and (seq column) the order flag: [ctl 2 x u64][hist B x u32][flag u32]
+    hipError_t e = hipMemsetAsync(ws.pool_ctl, 0, POOL_WORDS * 8 + (size_t)B * 4 + 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kta_alive_partition<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, base_seq, pp,
-                       counts, pl.cap, t, run);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(ctl + POOL_WORDS);
+    uint32_t *flag = hist + B;
+    const bool bitmap = st.bitmap != nullptr;
+    const uint32_t *skip = nullptr;
+    if (c.seq && !bitmap) {
+        hipLaunchKernelGGL(kta_seq_ascending, dim3(1024), dim3(kWG), 0, s, c.seq, n, flag);
+        skip = flag;
+    }
+    // the kernel reads the three i32 columns 16 bytes at a time: align them down together
+    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(c.key_len) & 15u) / 4u);
+    if ((reinterpret_cast<uintptr_t>(c.val_len) & 15u) / 4u != head || (reinterpret_cast<uintptr_t>(c.key_off) & 15u) / 4u != head ||
+        (reinterpret_cast<uintptr_t>(c.key_len) & 3u))
+        return hipErrorInvalidValue;
+    AliveColumns ca = c;
+    ca.key_len -= head;
+    ca.val_len -= head;
+    ca.key_off -= head;
+    const size_t lds1 = (size_t)B * kRing * 8 + (size_t)B * 12 + (size_t)kPartWaves * kQueue * 4;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((kta_alive_partition<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head, pl.tiles_per_wg, pp,
+                       ws.counts, pl.cap, pool, ctl, hist);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds2 = ((size_t)8 << TLOG2) + (size_t)pl.segment_wgs * 4;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, TLOG2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kta_alive_apply<BLOG2, TLOG2>), dim3(1u << BLOG2), dim3(kApplyThreads), lds2, s, pp, counts, pl.cap,
-                       pl.segment_wgs, base_seq, t, run, reinterpret_cast<unsigned long long *>(stats));
+    const size_t lds2 = (size_t)kEntries * 6 + (size_t)kSets * 4 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
+                        (bitmap ? (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8 : 0);
+    if (bitmap) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+                           pl.segment_wgs, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
+                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, skip);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const size_t lds3 = (size_t)4 << 15;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_fallback<BLOG2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, pp, ws.counts, pl.cap,
+                           pl.segment_wgs, pool, ctl, ws.fail_from, st.bitmap, run);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
+        hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+                           pl.segment_wgs, base_seq, c.seq, t, (uint32_t *)nullptr, run,
+                           reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip);
+    }
     return hipGetLastError();
 }
 
 } // namespace
 
-AlivePartitionPlan plan_alive_partition(uint64_t n, int bucket_log2, int req_wgs, int cu_count)
+const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2)
+{
+    return reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned long long *>(ws.pool_ctl) + POOL_WORDS) +
+           (1u << bucket_log2);
+}
+
+AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count)
 {
     AlivePartitionPlan pl;
-    pl.bucket_log2 = bucket_log2 == 9 ? 9u : 10u;
+    pl.bucket_log2 = 10u;
     pl.max_records = kAlivePartitionMax;
     if (n > pl.max_records) n = pl.max_records;
-    // one partition workgroup per CU (its rings take most of a CU's LDS); every workgroup sees n / W records
+    if (n == 0) n = 1;
+    // one partition workgroup per CU (its rings take most of a CU's LDS); workgroup w takes the tiles
+    // [w * tiles_per_wg, (w + 1) * tiles_per_wg): a contiguous, older-to-newer range of the batch
     uint64_t wgs = req_wgs > 0 ? (uint64_t)req_wgs : (uint64_t)(cu_count > 0 ? cu_count : 256);
     if (wgs > kMaxSegWGs) wgs = kMaxSegWGs;
-    const uint64_t rounds = (n + kPartRound - 1) / kPartRound;
-    if (wgs > rounds) wgs = rounds ? rounds : 1;
-    pl.segment_wgs = (uint32_t)wgs;
+    const uint64_t ntiles = (n + 3 + kTile - 1) / kTile;              // + 3: columns aligned down by up to three records
+    const uint64_t want = (ntiles + kPartWaves - 1) / kPartWaves;     // at least one tile per wave
+    if (wgs > want) wgs = want;
+    pl.tiles_per_wg = (uint32_t)((ntiles + wgs - 1) / wgs);
+    pl.segment_wgs = (uint32_t)((ntiles + pl.tiles_per_wg - 1) / pl.tiles_per_wg);
     // a segment receives n / (W * B) pairs on average; 1/8 + 48 of slack (8 sigma at 2^26 records) before it
-    // overflows into the direct path, rounded up to what a wave reads with one load instruction (128 pairs)
-    const uint64_t mean = n / (wgs << pl.bucket_log2) + 1;
+    // overflows into the pool, rounded up to what a wave reads with one load instruction (128 pairs)
+    const uint64_t mean = n / ((uint64_t)pl.segment_wgs << pl.bucket_log2) + 1;
     pl.cap = (uint32_t)((mean + mean / 8 + 48 + 127) & ~127ull);
     pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap;
     pl.count_words = (uint64_t)pl.segment_wgs << pl.bucket_log2;
+    pl.pool_words = n;
+    pl.ctl_bytes = POOL_WORDS * 8 + ((size_t)4 << pl.bucket_log2) + 4;
     return pl;
 }
 
-hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                                    int64_t *running, const AlivePartitionPlan &pl, uint64_t *pairs, uint32_t *counts,
-                                    uint64_t *stats, hipStream_t s)
+hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
+                                    const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
 {
-    switch (pl.bucket_log2) {
-    case 9: return launch_pair<9, 14>(c, n, base_seq, table, running, pl, pairs, counts, stats, s);
-    default: return launch_pair<10, 14>(c, n, base_seq, table, running, pl, pairs, counts, stats, s);
-    }
+    return launch_pair<10>(c, n, base_seq, st, pl, ws, stats, s);
+}
+
+hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(kta_bitmap_count, dim3(2048), dim3(kWG), 0, s, reinterpret_cast<const uint4 *>(bitmap),
+                       (uint64_t)(kAliveSlots / 128), reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
 }
 
 } // namespace kta

@@ -51,8 +51,13 @@ struct kta_ctx {
                                     // exchange reduces in place — the accumulator itself is never reduced
     uint64_t *d_partials = nullptr; // scan workspace: max_rows x row_len
     uint32_t max_rows = 0;
-    uint64_t *d_table = nullptr;    // u64[2^32] last-writer table (-c)
-    int64_t *d_alive_running = nullptr; // running alive count (alive_variant 1)
+    // -c: the persistent state is ONE of
+    //   d_bitmap  the reference's bit set, u32[2^27] (default: batches are applied in submission order), or
+    //   d_table   u64[2^32] last-writer table (KTA_FLAG_ALIVE_TABLE / KTA_FLAG_SEQ_COLUMN: global sequence numbers)
+    bool alive_table = false;
+    uint32_t *d_bitmap = nullptr;
+    uint64_t *d_table = nullptr;
+    int64_t *d_alive_running = nullptr; // running alive count
     bool running_valid = true;          // false once an update ran without counting
     uint32_t *d_exp_slots = nullptr;    // kta_alive_export_entries buffers
     uint64_t *d_exp_vals = nullptr, *d_exp_count = nullptr;
@@ -61,7 +66,10 @@ struct kta_ctx {
     uint64_t hash_scratch_cap = 0;
     uint64_t *d_pairs = nullptr;        // partitioned alive pass: (hash, local seq, alive) pairs by [workgroup][bucket]
     uint32_t *d_pair_counts = nullptr;  //   and the fill of every segment, [bucket][workgroup]
-    uint64_t pairs_cap = 0, pair_counts_cap = 0;
+    uint64_t *d_pool = nullptr;         //   pairs whose segment was full
+    void *d_pool_ctl = nullptr;         //   pool cursor, histogram, order flag
+    uint32_t *d_fail_from = nullptr;    //   buckets handed to the fallback kernel (bit set state)
+    uint64_t pairs_cap = 0, pair_counts_cap = 0, pool_cap = 0;
     // Feedback for the automatic choice (alive_variant 3 / 4): the partitioned pass pays when records die in
     // LDS (a compacted topic repeats its keys inside a batch); a batch of mostly unique keys is cheaper in
     // the single-kernel update.  Every partitioned batch reports [pairs, entries claimed]; a batch that
@@ -225,23 +233,27 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             if (rc != KTA_OK) return rc;
             KTA_HIP(ctx, hipEventRecord(a, ctx->s_compute));
         }
-        if ((ctx->alive_variant == 8 || ctx->alive_variant == 9) && ctx->hash_scratch_cap < n) {
+        if (ctx->alive_table && (ctx->alive_variant == 8 || ctx->alive_variant == 9) && ctx->hash_scratch_cap < n) {
             KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
             if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
             ctx->d_hash_scratch = nullptr;
             KTA_HIP(ctx, hipMalloc((void **)&ctx->d_hash_scratch, n * sizeof(uint32_t)));
             ctx->hash_scratch_cap = n;
         }
-        // 3 / 4: the partitioned pass with 2^10 / 2^9 buckets (13 / 14: the same for batches of any size —
-        // tests).  It needs the batch-local index as the sequence number (no explicit seq column) and enough
-        // records to fill its segments; anything else runs the single-kernel filtered update, which is
-        // exact on the same table.
-        const int pv = ctx->alive_variant >= 13 && ctx->alive_variant <= 14 ? ctx->alive_variant - 10 : ctx->alive_variant;
-        const bool part_kind = pv >= 3 && pv <= 4;
-        const bool partitioned = part_kind && !c->seq && (n >= kta::kAlivePartitionMin || pv != ctx->alive_variant);
-        if (ctx->alive_variant != 1 && ctx->alive_variant != 2 && !part_kind) ctx->running_valid = false;   // non-counting kernels
+        // Bit set state: every batch takes the partitioned pass (hash + partition, per-bucket merge in LDS, the
+        // bucket's bitmap region streamed through LDS); batches are applied in submission order, base_seq and a
+        // seq column are not looked at.
+        // Table state: 3 = the partitioned pass for batches of >= 2^21 records (13: for batches of any size —
+        // tests), with the automatic fall-back to the single-kernel filtered update (2) for batches of mostly
+        // unique keys; 1 / 2 / 8 / 9 = the single-kernel variants.  A seq column has to ascend inside a batch
+        // for the partitioned pass (the merge orders a batch's records by their index): checked on the device,
+        // and a batch that fails the check runs the filtered update instead, conditionally, without a host
+        // round trip.
+        const bool part_kind = ctx->alive_variant == 3 || ctx->alive_variant == 13 || ctx->alive_variant == 4 || ctx->alive_variant == 14;
+        const bool partitioned = !ctx->alive_table || (part_kind && (n >= kta::kAlivePartitionMin || ctx->alive_variant >= 13));
+        if (ctx->alive_table && ctx->alive_variant != 1 && ctx->alive_variant != 2 && !part_kind) ctx->running_valid = false;   // non-counting kernels
         bool use_partitioned = partitioned;
-        if (partitioned && ctx->alive_variant == pv) {          // automatic choice only (13 / 14 force it)
+        if (partitioned && ctx->alive_table && ctx->alive_variant < 13) {          // automatic choice only (13 forces it)
             if (ctx->alive_stats_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
                 ctx->alive_stats_pending = false;
                 const uint64_t pairs = ctx->h_alive_stats[0], claims = ctx->h_alive_stats[1];
@@ -253,33 +265,50 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             }
         }
         if (use_partitioned) {
-            const int blog2 = pv == 4 ? 9 : 10;
+            if ((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->val_len)) & 15u ||
+                (reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->key_off)) & 15u)
+                return fail(ctx, KTA_ERR_INVALID, "key_len, val_len and key_off must share their alignment modulo 16 bytes");
             if (!ctx->d_alive_stats) {
                 KTA_HIP(ctx, hipMalloc((void **)&ctx->d_alive_stats, 2 * sizeof(uint64_t)));
                 KTA_HIP(ctx, hipHostMalloc((void **)&ctx->h_alive_stats, 2 * sizeof(uint64_t), hipHostMallocDefault));
                 KTA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_alive_stats, hipEventDisableTiming));
             }
-            const bool report = !ctx->alive_stats_pending;       // one report in flight at a time
+            const bool report = ctx->alive_table && !ctx->alive_stats_pending;       // one report in flight at a time
             if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 2 * sizeof(uint64_t), ctx->s_compute));
             for (uint64_t at = 0; at < n;) {
-                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, blog2, ctx->alive_wgs, ctx->cu_count);
+                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, ctx->alive_wgs, ctx->cu_count);
                 const uint64_t take = n - at < pl.max_records ? n - at : pl.max_records;
-                if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words) {
+                if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words || ctx->pool_cap < pl.pool_words) {
                     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
                     if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
                     if (ctx->d_pair_counts) (void)hipFree(ctx->d_pair_counts);
+                    if (ctx->d_pool) (void)hipFree(ctx->d_pool);
                     ctx->d_pairs = nullptr;
                     ctx->d_pair_counts = nullptr;
-                    ctx->pairs_cap = ctx->pair_counts_cap = 0;
+                    ctx->d_pool = nullptr;
+                    ctx->pairs_cap = ctx->pair_counts_cap = ctx->pool_cap = 0;
                     KTA_HIP(ctx, hipMalloc((void **)&ctx->d_pairs, pl.pair_words * sizeof(uint64_t)));
                     KTA_HIP(ctx, hipMalloc((void **)&ctx->d_pair_counts, pl.count_words * sizeof(uint32_t)));
+                    KTA_HIP(ctx, hipMalloc((void **)&ctx->d_pool, (pl.pool_words + 8) * sizeof(uint64_t)));
                     ctx->pairs_cap = pl.pair_words;
                     ctx->pair_counts_cap = pl.count_words;
+                    ctx->pool_cap = pl.pool_words;
                 }
-                kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes, nullptr};
-                KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, ctx->d_table, ctx->d_alive_running, pl,
-                                                           ctx->d_pairs, ctx->d_pair_counts,
+                if (!ctx->d_pool_ctl) {
+                    KTA_HIP(ctx, hipMalloc(&ctx->d_pool_ctl, pl.ctl_bytes));
+                    KTA_HIP(ctx, hipMalloc((void **)&ctx->d_fail_from, sizeof(uint32_t) << pl.bucket_log2));
+                }
+                kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes,
+                                     ctx->alive_table && c->seq ? c->seq + at : nullptr};
+                kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,
+                                   ctx->d_alive_running};
+                kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from};
+                KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws,
                                                            report ? ctx->d_alive_stats : nullptr, ctx->s_compute));
+                if (sl.seq)   // the batch's seq column did not ascend: the pair did nothing, this runs instead
+                    KTA_HIP(ctx, kta::launch_alive_update(sl, take, base_seq + at, ctx->d_table, 0, 2, nullptr,
+                                                          ctx->d_alive_running, ctx->s_compute,
+                                                          kta::alive_order_flag(ws, (int)pl.bucket_log2)));
                 at += take;
             }
             if (report) {
@@ -291,7 +320,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         } else {
             const int v = part_kind ? 2 : ctx->alive_variant;
             KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs > 2048 ? 0 : ctx->alive_wgs,
-                                                  v, ctx->d_hash_scratch, ctx->d_alive_running, ctx->s_compute));
+                                                  v, ctx->d_hash_scratch, ctx->d_alive_running, ctx->s_compute, nullptr));
         }
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
@@ -302,7 +331,8 @@ int reset_state(kta_ctx *ctx)
 {
     KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->d_avec, ctx->s_compute));
     if (ctx->alive) {
-        KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
+        if (ctx->alive_table) KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
+        else KTA_HIP(ctx, hipMemsetAsync(ctx->d_bitmap, 0, (size_t)(kta::kAliveSlots / 8), ctx->s_compute));
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
         ctx->running_valid = true;
     }
@@ -356,6 +386,7 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     ctx->alive = cfg->count_alive_keys != 0;
     ctx->analytics = (cfg->flags & KTA_FLAG_ANALYTICS) != 0;
     ctx->stage_seq = (cfg->flags & KTA_FLAG_SEQ_COLUMN) != 0;
+    ctx->alive_table = ctx->alive && (cfg->flags & (KTA_FLAG_SEQ_COLUMN | KTA_FLAG_ALIVE_TABLE)) != 0;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->batch_capacity = cfg->batch_capacity ? cfg->batch_capacity : (1ull << 22);
     ctx->key_bytes_capacity = cfg->key_bytes_capacity ? cfg->key_bytes_capacity : 64ull * ctx->batch_capacity;
@@ -387,7 +418,8 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     if (ctx->analytics)
         KTA_TRY(hipMalloc((void **)&ctx->d_avec, (size_t)kta::analytics_len(ctx->P) * sizeof(uint64_t)));
     if (ctx->alive) {
-        KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+        if (ctx->alive_table) KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+        else KTA_TRY(hipMalloc((void **)&ctx->d_bitmap, (size_t)(kta::kAliveSlots / 8)));
         KTA_TRY(hipMalloc((void **)&ctx->d_alive_running, sizeof(int64_t)));
     }
 #undef KTA_TRY
@@ -417,6 +449,10 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_avec) (void)hipFree(ctx->d_avec);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->d_bitmap) (void)hipFree(ctx->d_bitmap);
+    if (ctx->d_pool) (void)hipFree(ctx->d_pool);
+    if (ctx->d_pool_ctl) (void)hipFree(ctx->d_pool_ctl);
+    if (ctx->d_fail_from) (void)hipFree(ctx->d_fail_from);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->d_alive_stats) (void)hipFree(ctx->d_alive_stats);
     if (ctx->h_alive_stats) (void)hipHostFree(ctx->h_alive_stats);
@@ -678,8 +714,12 @@ int kta_finish_device(kta_ctx *ctx)
         if (ctx->running_valid)  // exact running count (every update so far ran a counting kernel): no table scan
             KTA_HIP(ctx, hipMemcpyAsync(dst, ctx->d_alive_running, sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                         ctx->s_compute));
-        else
+        else if (ctx->alive_table)
             KTA_HIP(ctx, kta::launch_alive_count(ctx->d_table, kta::kAliveSlots, dst, ctx->s_compute));
+        else {
+            KTA_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(uint64_t), ctx->s_compute));
+            KTA_HIP(ctx, kta::launch_bitmap_count(ctx->d_bitmap, dst, ctx->s_compute));
+        }
     }
     return KTA_OK;
 }
@@ -797,6 +837,9 @@ int kta_get_analytics(kta_ctx *ctx, kta_analytics *out, int64_t *part_min_ts_sec
     return KTA_OK;
 }
 
+static const char *const kNeedsTable =
+    "the context keeps the alive set as a bit set: create it with KTA_FLAG_ALIVE_TABLE for sequence-numbered entries";
+
 int kta_export_alive_bitmap(kta_ctx *ctx, void *dst)
 {
     if (!ctx || !dst) return KTA_ERR_INVALID;
@@ -806,6 +849,11 @@ int kta_export_alive_bitmap(kta_ctx *ctx, void *dst)
     if (rc != KTA_OK) return rc;
     uint32_t *d_bm = nullptr;
     const size_t bytes = (size_t)(kta::kAliveSlots / 8);
+    if (!ctx->alive_table) {       // the state IS the reference's bit set
+        KTA_HIP(ctx, hipMemcpyAsync(dst, ctx->d_bitmap, bytes, hipMemcpyDeviceToHost, ctx->s_compute));
+        KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+        return KTA_OK;
+    }
     KTA_HIP(ctx, hipMalloc((void **)&d_bm, bytes));
     hipError_t e = kta::launch_alive_bitmap(ctx->d_table, kta::kAliveSlots, d_bm, ctx->s_compute);
     if (e == hipSuccess) e = hipMemcpyAsync(dst, d_bm, bytes, hipMemcpyDeviceToHost, ctx->s_compute);
@@ -819,6 +867,7 @@ int kta_alive_table(kta_ctx *ctx, void **device_ptr, size_t *n_u64)
 {
     if (!ctx || !device_ptr || !n_u64) return KTA_ERR_INVALID;
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    if (!ctx->alive_table) return fail(ctx, KTA_ERR_INVALID, kNeedsTable);
     *device_ptr = ctx->d_table;
     *n_u64 = (size_t)kta::kAliveSlots;
     return KTA_OK;
@@ -828,6 +877,7 @@ int kta_alive_export_entries(kta_ctx *ctx, void **d_slots, void **d_vals, uint64
 {
     if (!ctx || !d_slots || !d_vals || !n) return KTA_ERR_INVALID;
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    if (!ctx->alive_table) return fail(ctx, KTA_ERR_INVALID, kNeedsTable);
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
@@ -860,6 +910,7 @@ int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_va
 {
     if (!ctx || (n && (!d_slots || !d_vals))) return KTA_ERR_INVALID;
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    if (!ctx->alive_table) return fail(ctx, KTA_ERR_INVALID, kNeedsTable);
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
@@ -872,6 +923,7 @@ int kta_alive_count_range(kta_ctx *ctx, uint64_t slot_lo, uint64_t slot_hi, uint
 {
     if (!ctx || !count || slot_lo > slot_hi || slot_hi > kta::kAliveSlots) return KTA_ERR_INVALID;
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
+    if (!ctx->alive_table) return fail(ctx, KTA_ERR_INVALID, kNeedsTable);
     KTA_HIP(ctx, hipSetDevice(ctx->device));
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
@@ -968,6 +1020,7 @@ void **kta_internal_comm_slot(kta_ctx *ctx, void (*free_fn)(void *))
 uint64_t *kta_internal_vec_out(kta_ctx *ctx) { return ctx->d_vec_out; }
 uint32_t kta_internal_partitions(kta_ctx *ctx) { return ctx->P; }
 uint64_t *kta_internal_table(kta_ctx *ctx) { return ctx->d_table; }
+bool kta_internal_alive_table(kta_ctx *ctx) { return ctx->alive_table; }
 int64_t *kta_internal_running(kta_ctx *ctx) { return ctx->d_alive_running; }
 uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n)
 {

@@ -35,6 +35,7 @@ int kta_internal_device(kta_ctx *ctx);
 void kta_internal_set_error(kta_ctx *ctx, const char *msg);
 void **kta_internal_comm_slot(kta_ctx *ctx, void (*free_fn)(void *));
 bool kta_internal_count_alive(kta_ctx *ctx);
+bool kta_internal_alive_table(kta_ctx *ctx);
 uint64_t *kta_internal_vec_out(kta_ctx *ctx);
 uint32_t kta_internal_partitions(kta_ctx *ctx);
 uint64_t *kta_internal_table(kta_ctx *ctx);
@@ -268,6 +269,8 @@ int kta_comm_create(kta_ctx *ctx, int nranks, int rank, const uint8_t id[KTA_COM
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return KTA_ERR_INVALID;
     void **slot = kta_internal_comm_slot(ctx, free_comm);
     if (*slot) return fail(ctx, KTA_ERR_INVALID, "kta_comm_create: the context already has a communicator");
+    if (nranks > 1 && kta_internal_count_alive(ctx) && !kta_internal_alive_table(ctx))
+        return fail(ctx, KTA_ERR_INVALID, "kta_comm_create: a -c rank of a sharded run needs KTA_FLAG_ALIVE_TABLE (global sequence numbers)");
     CH(ctx, hipSetDevice(kta_internal_device(ctx)));
     CommState *st = new CommState();
     st->nranks = nranks;
@@ -326,7 +329,7 @@ static int exchange_failed(CommState *st, int rc)
 static int exchange_collectives(kta_ctx *ctx, CommState *st)
 {
     CH(ctx, hipSetDevice(kta_internal_device(ctx)));
-    if (kta_internal_count_alive(ctx)) {
+    if (kta_internal_count_alive(ctx) && kta_internal_alive_table(ctx)) {
         int rc = exchange_alive(ctx, st);
         if (rc != KTA_OK) return rc;
     }

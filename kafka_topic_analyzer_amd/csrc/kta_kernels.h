@@ -67,26 +67,46 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *analytics_vec
 // variant 0 = fused; 1 = fused + running alive count (returning atomics, default); 8 / 9 = ablation halves
 // (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s);
-// K2'+K3' (kta_alive.hip): the same update as two kernels — hash + partition the batch's (hash, sequence, alive)
+                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s,
+                               const uint32_t *only_if /* variant 2: device word, run only when non-zero; may be null */);
+// K2'+K3' (kta_alive.hip): the same update as two kernels — hash + partition the batch's (hash, index, alive)
 // pairs by the hash's top bits into workgroup-private segments, then one workgroup per bucket merges its
-// pairs in LDS and applies the survivors to the table region it alone writes.  Batches without an explicit
-// seq column only (the pair carries the batch-local index).
-constexpr uint64_t kAlivePartitionMin = 1ull << 21;   // below this the segments stay nearly empty
-constexpr uint64_t kAlivePartitionMax = 1ull << 26;   // records per launch pair: larger batches are sliced
+// pairs in LDS and applies the survivors to the region of the persistent state it alone writes.  The state is
+// either the reference's bit set (batches applied in submission order) or the u64 last-writer table (global
+// sequence numbers).  A seq column must ascend inside a batch (checked on the device: alive_order_flag).
+constexpr uint64_t kAlivePartitionMin = 1ull << 21;   // table state: below this the single-kernel update is used
+constexpr uint64_t kAlivePartitionMax = 1ull << 28;   // records per launch pair: larger batches are sliced
 struct AlivePartitionPlan {
-    uint32_t bucket_log2;   // buckets = table regions = apply workgroups
+    uint32_t bucket_log2;   // buckets = state regions = apply workgroups
     uint32_t segment_wgs;   // partition workgroups = segments per bucket
+    uint32_t tiles_per_wg;  // 256-record tiles each partition workgroup takes (a contiguous range)
     uint32_t cap;           // pairs per segment
     uint64_t max_records;   // records one launch pair takes (larger batches are sliced)
     uint64_t pair_words;    // u64 words of the pair workspace
     uint64_t count_words;   // u32 words of the segment-count workspace
+    uint64_t pool_words;    // u64 words of the pool (pairs whose segment was full)
+    uint64_t ctl_bytes;     // pool control words + pool histogram + order flag
 };
-AlivePartitionPlan plan_alive_partition(uint64_t n, int bucket_log2, int req_wgs, int cu_count);
-hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                                    int64_t *running, const AlivePartitionPlan &plan, uint64_t *pairs,
-                                    uint32_t *counts, uint64_t *stats /* [pairs, claims] += ; may be null */,
-                                    hipStream_t s);
+struct AliveState {
+    uint64_t *table;        // u64[2^32], or null
+    uint32_t *bitmap;       // u32[2^27] = 2^32 bits, or null (exactly one of the two)
+    int64_t *running;       // running alive count
+};
+struct AliveWorkspace {
+    uint64_t *pairs;
+    uint32_t *counts;
+    uint64_t *pool;
+    void *pool_ctl;         // ctl_bytes
+    uint32_t *fail_from;    // u32[buckets] (bit set state)
+};
+AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count);
+hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
+                                    const AlivePartitionPlan &plan, const AliveWorkspace &ws,
+                                    uint64_t *stats /* [pairs, claims] += ; may be null */, hipStream_t s);
+// device word that the launch pair sets when the batch's seq column does not ascend (the pair then did nothing)
+const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2);
+// popcount of the bit set -> *out += (u64)
+hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
 hipError_t launch_alive_count(const uint64_t *table, uint64_t n_slots, uint64_t *out, hipStream_t s);
 // compact (slot, value) export / import of the entries ever written: what sharded GPUs exchange

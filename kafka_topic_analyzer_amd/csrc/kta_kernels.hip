@@ -604,9 +604,11 @@ __global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c,
 // proves that a later record has already been applied, and a stale smaller value merely costs the atomic.
 __global__ __launch_bounds__(kWG) void kta_alive_update_filtered(AliveColumns c, uint64_t n, uint64_t base_seq,
                                                                  unsigned long long *__restrict__ table,
-                                                                 long long *__restrict__ running)
+                                                                 long long *__restrict__ running,
+                                                                 const uint32_t *__restrict__ only_if)
 {
     __shared__ long long s_w[kWG / 64];
+    if (only_if && *only_if == 0u) return;   // stands in for the partitioned pass only when that gave the batch up
     const uint64_t stride = (uint64_t)gridDim.x * kWG;
     long long delta = 0;
     for (uint64_t j = (uint64_t)blockIdx.x * kWG + threadIdx.x; j < n; j += stride) {
@@ -914,7 +916,8 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *avec, hipStre
 }
 
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
-                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s)
+                               int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s,
+                               const uint32_t *only_if)
 {
     uint64_t wgs = (n + kWG - 1) / kWG;
     const uint64_t cap = workgroups > 0 ? (uint64_t)workgroups : 256ull * 8ull;
@@ -927,7 +930,7 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
         hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t);
     } else if (variant == 2 && running) {
         hipLaunchKernelGGL(kta_alive_update_filtered, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
-                           reinterpret_cast<long long *>(running));
+                           reinterpret_cast<long long *>(running), only_if);
     } else if (variant == 1 && running) {
         hipLaunchKernelGGL(kta_alive_update_counting, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
                            reinterpret_cast<long long *>(running));

@@ -43,7 +43,7 @@ class V:
 rng = np.random.default_rng(9)
 cols = random_cols(rng, 100000, 8, key_space=2000, tomb=0.4)
 o = Oracle(NOW, True); o.run_soa(cols)
-h = kta.HipMetricHandler(8, count_alive_keys=True, now=NOW)
+h = kta.HipMetricHandler(8, count_alive_keys=True, now=NOW, alive_table=True)
 h.submit_columns(**cols); h.finish_device(); h.sync()
 p, n = h.result_vector()
 vec = torch.as_tensor(V(p, n), device="cuda:0")
@@ -100,7 +100,7 @@ pos = np.repeat(src, kl) + (np.arange(int(kl.sum())) - np.repeat(off, kl))
 kb[:int(kl.sum())] = cols["key_bytes"][pos]
 shard = {"partition": cols["partition"][idx], "key_len": cols["key_len"][idx], "val_len": cols["val_len"][idx],
          "ts_ms": cols["ts_ms"][idx], "key_off": off.astype(np.uint32), "key_bytes": kb[:int(kl.sum())], "seq": seq[idx]}
-h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=True)
 if nranks > 1:
     if rank == 0:
         uid = kta.HipMetricHandler.comm_unique_id()
@@ -192,7 +192,7 @@ uid = kta.HipMetricHandler.comm_unique_id()
 errors, stats = [], [None] * nranks
 def run(rank):
     try:
-        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=True)
         h.comm_create(nranks, rank, uid)
         b, nb = h.upload_batch(shard_of(rank), with_keys=True)
         h.submit_device(b, nb, 0)

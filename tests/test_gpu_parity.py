@@ -17,11 +17,28 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hc():
-    """One -c context (32 GiB last-writer table) shared by the module; reset between tests."""
+    """One -c context in the default state — the reference's bit set, batches applied in submission order —
+    shared by the module; reset between tests."""
     h = kta.HipMetricHandler(256, count_alive_keys=True, batch_capacity=1 << 16,
                              key_bytes_capacity=1 << 22, n_staging=3, now=NOW)
     yield h
     h.close()
+
+
+@pytest.fixture(scope="module")
+def ht():
+    """One -c context in the table state (KTA_FLAG_ALIVE_TABLE: 32 GiB of sequence-numbered entries, what a rank
+    of a sharded run keeps), shared by the module."""
+    h = kta.HipMetricHandler(256, count_alive_keys=True, batch_capacity=1 << 16,
+                             key_bytes_capacity=1 << 22, n_staging=3, now=NOW, alive_table=True)
+    yield h
+    h.close()
+
+
+@pytest.fixture(params=["bitset", "table"])
+def hs(request, hc, ht):
+    """Both states of the alive set, for what has to hold in either."""
+    return hc if request.param == "bitset" else ht
 
 
 def _compare(h, o, P, check_bitmap=False):
@@ -185,9 +202,10 @@ def test_reset_and_accumulation_across_batches(hc):
 
 
 # ------------------------------------------------------------------------------------- alive-key order
-def test_last_writer_wins_is_by_sequence_not_by_submission_order(hc):
-    """Two device batches with explicit seq columns, submitted in the WRONG order, must still
+def test_last_writer_wins_is_by_sequence_not_by_submission_order(ht):
+    """Table state: two device batches with explicit seq columns, submitted in the WRONG order, must still
     reproduce sequential BitSet semantics (what a partition-sharded multi-GPU merge relies on)."""
+    hc = ht
     rng = np.random.default_rng(21)
     cols = random_cols(rng, 60000, 4, key_space=500, tomb=0.5)
     o = Oracle(NOW, True)
@@ -211,7 +229,16 @@ def test_last_writer_wins_is_by_sequence_not_by_submission_order(hc):
         hc.device_batch_free(b)
 
 
-def test_collision_across_partitions_and_batches(hc):
+def test_bit_set_state_refuses_what_needs_sequence_numbers(hc):
+    """The default state is the reference's bit set: no table to hand out, export or import."""
+    for call in (hc.alive_table, hc.alive_export_entries, lambda: hc.alive_count_range(0, 10)):
+        with pytest.raises(kta.KtaError) as e:
+            call()
+        assert e.value.code == N.KTA_ERR_INVALID and "KTA_FLAG_ALIVE_TABLE" in str(e.value)
+
+
+def test_collision_across_partitions_and_batches(hs):
+    hc = hs
     g = load_golden("scenarios.json")["scenarios"]
     recs = scenario_records(g["hash_collision_later_wins_dead"])
     (p0, t0, ka, _), (p1, t1, kb, _) = recs
@@ -225,9 +252,10 @@ def test_collision_across_partitions_and_batches(hc):
         assert res.alive_keys == want
 
 
-def test_running_alive_count_equals_table_scan(hc):
-    """The running count kept by returning atomics (default) == popcount of the table (recount), also
-    after interleaving counting and non-counting update kernels."""
+def test_running_alive_count_equals_table_scan(hs):
+    """The running count == a recount of the state (popcount of the bit set / of the table's alive flags), also
+    (table state) after interleaving counting and non-counting update kernels."""
+    hc = hs
     rng = np.random.default_rng(77)
     cols = random_cols(rng, 200000, 16, key_space=3000, tomb=0.4)
     o = Oracle(NOW, True)
@@ -247,13 +275,14 @@ def test_running_alive_count_equals_table_scan(hc):
     assert r3.alive_keys == o.alive_keys()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 13, 14])
-def test_alive_kernels_under_heavy_slot_contention(hc, variant):
-    """Every alive-update kernel (plain atomicMax; returning atomicMax + running count; the same walked
-    backwards with a pre-read that skips superseded records; the partitioned pass with 2^10 / 2^9
-    buckets, forced onto small batches) leaves exactly the table sequential BitSet semantics leaves — 40
-    keys over 120k records is heavy same-slot contention (and, partitioned, overflows the 16-pair
-    rings of the hot keys' buckets into the direct path)."""
+@pytest.mark.parametrize("state,variant", [("table", 0), ("table", 1), ("table", 2), ("table", 13), ("bitset", 3)])
+def test_alive_kernels_under_heavy_slot_contention(hc, ht, state, variant):
+    """Every alive-update kernel (table state: plain atomicMax; returning atomicMax + running count; the same
+    walked backwards with a pre-read that skips superseded records; the partitioned pass forced onto small
+    batches — and the bit set state, which always takes the partitioned pass) leaves exactly what sequential
+    BitSet semantics leaves — 40 keys over 120k records is heavy same-slot contention: the hot keys' buckets
+    overflow their segments into the pool, i.e. the direct path (table) / the fallback kernel (bit set)."""
+    hc = ht if state == "table" else hc
     rng = np.random.default_rng(500 + variant)
     o = Oracle(NOW, True)
     hc.reset()
@@ -269,13 +298,16 @@ def test_alive_kernels_under_heavy_slot_contention(hc, variant):
     assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
 
 
-@pytest.mark.parametrize("variant,wgs", [(3, 0), (14, 100), (13, 37)])
-def test_partitioned_alive_pass_across_batches_vs_oracle(hc, variant, wgs):
+@pytest.mark.parametrize("state,variant,wgs", [("table", 3, 0), ("table", 13, 100), ("table", 13, 37),
+                                               ("bitset", 3, 0), ("bitset", 3, 100), ("bitset", 3, 37)])
+def test_partitioned_alive_pass_across_batches_vs_oracle(hc, ht, state, variant, wgs):
     """The partitioned pass (kta_alive_partition + kta_alive_apply) over several batches that revisit each
     other's keys — tombstones killing earlier batches' keys, re-insertions, empty and null keys, key
     lengths 0..40 at every alignment — against the oracle's BitSet: count, running count and all 2^32 bits.
-    Batches below the partitioning threshold take the single-kernel path on the same table, and so do (variant 3,
-    the automatic choice) the batches after one whose keys were mostly unique; 13 / 14 partition every batch."""
+    Table state: batches below the partitioning threshold take the single-kernel path on the same table, and so
+    do (variant 3, the automatic choice) the batches after one whose keys were mostly unique; 13 partitions every
+    batch.  Bit set state: every batch is partitioned."""
+    hc = ht if state == "table" else hc
     rng = np.random.default_rng(900 + variant + wgs)
     o = Oracle(NOW, True)
     hc.reset()
@@ -297,12 +329,14 @@ def test_partitioned_alive_pass_across_batches_vs_oracle(hc, variant, wgs):
     assert hc.finish()[0].alive_keys == o.alive_keys()       # the running count equals a recount of the table
 
 
+@pytest.mark.parametrize("state", ["bitset", "table"])
 @pytest.mark.parametrize("preset,log2n", [("c3", 25), ("c5", 25)])
-def test_partitioned_alive_pass_at_scale_vs_oracle(hc, preset, log2n):
+def test_partitioned_alive_pass_at_scale_vs_oracle(hc, ht, state, preset, log2n):
     """2^25 records of the config-3 topic (10 M distinct keys: everything merges in LDS) and of the config-5
     key law (100 M distinct: the buckets hold more distinct slots than the LDS table, so the overflow of
     the table into the direct path carries most of the batch), in two submissions, against the
     single-threaded BitSet oracle on the same records: alive count and every bit of the set."""
+    hc = ht if state == "table" else hc
     sp, _ = kta.synth_preset(preset)
     n = 1 << log2n
     host = kta.synth_fill_host(sp, 0, n, with_keys=True)
@@ -412,10 +446,12 @@ def test_full_size_properties_metrics_scan():
         h.device_batch_free(b)
 
 
-def test_full_size_properties_alive_pass(hc):
+@pytest.mark.parametrize("state", ["bitset", "table"])
+def test_full_size_properties_alive_pass(hc, ht, state):
     """2^26 records, 16 B keys, 10M distinct (BASELINE config 3 shape): oracle on a prefix, then
     idempotence (replaying the same records with the same seq changes nothing) and the
     A-then-all-tombstones round trip (every key dead => 0 alive)."""
+    hc = ht if state == "table" else hc
     sp, _ = kta.synth_preset("c3")
     n = 1 << 26
     hc.reset()
@@ -487,8 +523,8 @@ def test_analytics_histograms_and_partition_extrema(P, n, runs):
 
 
 # ------------------------------------------------------------------------------------- compact table exchange
-def test_alive_export_import_merges_partition_shards(hc):
-    """Two partition shards with GLOBAL sequence numbers in two contexts; exporting one shard's written
+def test_alive_export_import_merges_partition_shards(ht):
+    """Table state.  Two partition shards with GLOBAL sequence numbers in two contexts; exporting one shard's written
     entries (compact) and importing them into the other reproduces the unsharded alive set exactly."""
     rng = np.random.default_rng(31)
     P = 6
@@ -512,10 +548,11 @@ def test_alive_export_import_merges_partition_shards(hc):
                 "seq": seq[idx]}
 
     a_cols, b_cols = shard(cols["partition"] % 2 == 0), shard(cols["partition"] % 2 == 1)
+    hc = ht
     hc.reset()
     ba, na = hc.upload_batch(a_cols, with_keys=True)
     hc.submit_device(ba, na, 0)
-    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as hb:
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=True) as hb:
         bb, nb = hb.upload_batch(b_cols, with_keys=True)
         hb.submit_device(bb, nb, 0)
         rb, _ = hb.finish()

@@ -1,7 +1,7 @@
 // Developer harness (not product code): the partitioned alive-key pass of kta_alive.hip on synthetic
 // 16-byte keys, with the per-phase tick counters compiled in.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I kafka_topic_analyzer_amd/csrc tools/ubench_alive.hip -o /tmp/uba
-//   /tmp/uba [log2 n = 26] [distinct keys = 10000000] [bucket_log2 = 10] [segment workgroups = 0]
+//   /tmp/uba [log2 n = 26] [distinct keys = 10000000] [state: 0 bit set, 1 table] [segment workgroups = 0]
 #ifndef KTA_NO_PHASES
 #define KTA_ALIVE_PHASES 1
 #endif
@@ -37,23 +37,28 @@ int main(int argc, char **argv)
 {
     const int log2n = argc > 1 ? atoi(argv[1]) : 26;
     const uint64_t distinct = argc > 2 ? strtoull(argv[2], 0, 10) : 10000000ull;
-    const int blog2 = argc > 3 ? atoi(argv[3]) : 10;
+    const int table_state = argc > 3 ? atoi(argv[3]) : 0;     // 0: bit set state, 1: table state
     const int wgs = argc > 4 ? atoi(argv[4]) : 0;
     const uint64_t n = 1ull << log2n;
     int32_t *kl, *vl;
-    uint32_t *ko;
-    uint64_t *kb, *table, *pairs;
-    uint32_t *counts;
+    uint32_t *ko, *bitmap = nullptr, *counts, *fail_from;
+    uint64_t *kb, *table = nullptr, *pairs, *pool;
+    void *ctl;
     int64_t *running;
     CK(hipMalloc(&kl, n * 4)); CK(hipMalloc(&vl, n * 4)); CK(hipMalloc(&ko, n * 4)); CK(hipMalloc(&kb, n * 16 + 64));
-    CK(hipMalloc(&table, 8ull << 32)); CK(hipMalloc(&running, 8));
-    CK(hipMemset(table, 0, 8ull << 32)); CK(hipMemset(running, 0, 8));
+    if (table_state) { CK(hipMalloc(&table, 8ull << 32)); CK(hipMemset(table, 0, 8ull << 32)); }
+    else { CK(hipMalloc(&bitmap, 1ull << 29)); CK(hipMemset(bitmap, 0, 1ull << 29)); }
+    CK(hipMalloc(&running, 8)); CK(hipMemset(running, 0, 8));
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, kl, vl, ko, kb, n, distinct);
-    kta::AlivePartitionPlan pl = kta::plan_alive_partition(n, blog2, wgs, 256);
-    CK(hipMalloc(&pairs, pl.pair_words * 8)); CK(hipMalloc(&counts, pl.count_words * 4));
-    printf("n=2^%d distinct=%llu buckets=2^%u segment_wgs=%u cap=%u workspace=%.0f MB\n", log2n, (unsigned long long)distinct,
-           pl.bucket_log2, pl.segment_wgs, pl.cap, pl.pair_words * 8 / 1e6);
+    kta::AlivePartitionPlan pl = kta::plan_alive_partition(n, wgs, 256);
+    CK(hipMalloc(&pairs, pl.pair_words * 8)); CK(hipMalloc(&counts, pl.count_words * 4)); CK(hipMalloc(&pool, (pl.pool_words + 8) * 8));
+    CK(hipMalloc(&ctl, pl.ctl_bytes)); CK(hipMalloc(&fail_from, 4u << pl.bucket_log2));
+    printf("n=2^%d distinct=%llu %s state buckets=2^%u segment_wgs=%u tiles/wg=%u cap=%u workspace=%.0f MB\n", log2n,
+           (unsigned long long)distinct, table_state ? "table" : "bit set", pl.bucket_log2, pl.segment_wgs, pl.tiles_per_wg, pl.cap,
+           pl.pair_words * 8 / 1e6);
     kta::AliveColumns c{kl, vl, ko, reinterpret_cast<const uint8_t *>(kb), nullptr};
+    kta::AliveState st{table, bitmap, running};
+    kta::AliveWorkspace ws{pairs, counts, pool, ctl, fail_from};
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 4; rep++) {
@@ -63,23 +68,24 @@ int main(int argc, char **argv)
 #endif
         CK(hipDeviceSynchronize());
         hipEventRecord(a);
-        CK(kta::launch_alive_partitioned(c, n, (uint64_t)rep * n, table, running, pl, pairs, counts, nullptr, 0));
+        CK(kta::launch_alive_partitioned(c, n, (uint64_t)rep * n, st, pl, ws, nullptr, 0));
         hipEventRecord(b);
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        unsigned long long ph[16] = {0};
+        unsigned long long ph[16] = {0}, pc[2] = {0};
 #ifdef KTA_ALIVE_PHASES
         CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_kta_phase), sizeof ph));
 #endif
         long long alive;
         CK(hipMemcpy(&alive, running, 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(pc, ctl, 16, hipMemcpyDeviceToHost));
         const double w1 = pl.segment_wgs, w2 = (double)(1u << pl.bucket_log2);
-        printf("rep %d: %.3f ms = %.1f G records/s  alive=%lld\n", rep, ms, n / ms / 1e6, alive);
-        printf("   partition per workgroup (us): wait+hash %.1f  issue %.1f  flush %.1f  barrierA %.1f  arrivals %.1f  barrierB %.1f  close %.1f  tail %.1f\n",
-               ph[0] / w1 / 100, ph[1] / w1 / 100, ph[2] / w1 / 100, ph[3] / w1 / 100, ph[4] / w1 / 100, ph[5] / w1 / 100,
-               ph[6] / w1 / 100, ph[7] / w1 / 100);
-        printf("   apply per workgroup (us):     init %.1f  merge %.1f  sweep %.1f   (x %.0f workgroups / 256 CUs)\n",
+        printf("rep %d: %.3f ms = %.1f G records/s  alive=%lld  pool pairs=%llu  buckets given to the fallback=%llu\n", rep, ms,
+               n / ms / 1e6, alive, pc[0], pc[1]);
+        printf("   partition per workgroup (us, thread 0's wave): wait+hash %.1f  arrivals %.1f  tail %.1f\n",
+               ph[0] / w1 / 100, ph[4] / w1 / 100, ph[7] / w1 / 100);
+        printf("   apply per workgroup (us):     init %.1f  merge %.1f  end %.1f   (x %.0f workgroups / 256 CUs)\n",
                ph[8] / w2 / 100, ph[9] / w2 / 100, ph[10] / w2 / 100, w2);
     }
     return 0;
