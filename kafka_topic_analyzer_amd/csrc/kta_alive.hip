@@ -160,6 +160,13 @@ __device__ __forceinline__ void add_running(long long delta, long long *running,
 // too, but it also waits for the wave's outstanding global loads (vmcnt(0)) — the prefetches.
 #define KTA_LDS_ORDER() asm volatile("" ::: "memory")
 
+// Workgroup barrier for LDS state only.  __syncthreads() is a fence over all memory: the compiler waits for the
+// wave's outstanding global loads (vmcnt(0)) — the prefetches that are meant to stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_add(uint32_t *p, uint32_t v)
 {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -218,8 +225,16 @@ __device__ __forceinline__ void load_keys(const AliveColumns &c, const TileCols 
     __builtin_memcpy(&k.k[3], c.key_bytes + (r.kl.w > 0 ? r.ko.w : 0u), 16);
 }
 
+// LDS address (in pairs) of position p of bucket b's ring.  A ring is one 128-byte row, so without a twist every
+// bucket's position k would sit in the same two banks; rows are rotated by 2 * (b & 7) pairs (an even rotation
+// keeps the 16-byte pieces of a block aligned).
+__device__ __forceinline__ uint32_t ring_at(uint32_t b, uint32_t p)
+{
+    return b * kRing + ((p + 2u * (b & 7u)) & (kRing - 1));
+}
+
 // pool control words (device memory, zeroed before every launch pair)
-enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_WORDS = 2 };
+enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS = 3 };
 
 // pair = h << 32 | (batch-local index + 1) << 1 | alive       (index < 2^31 - 1: a pair is never zero)
 //
@@ -255,32 +270,77 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
     uint32_t *queue = s_queue + wave * kQueue;
     uint32_t qn = 0;                                                              // wave-uniform
 
-    // write the wave's queued blocks out: four lanes per block, 16 bytes each, whole aligned 64-byte blocks
-    auto flush_queue = [&]() __attribute__((always_inline)) {
-        for (uint32_t q0 = 0; q0 < qn; q0 += 16) {
-            const uint32_t e = q0 + (lane >> 2), piece = lane & 3u;
-            const bool on = e < qn;
-            const uint32_t ent = queue[on ? e : 0u];
-            const uint32_t b = ent & (B - 1), k = ent >> BLOG2;                   // bucket, block number
-            const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(s_ring + b * kRing + (k & 1u) * 8u + piece * 2u);
-            unsigned long long *dst;
-            if ((k + 1u) * 8u <= cap) {
-                dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 8u;
-            } else {                                                              // the segment is full: to the pool
-                unsigned long long at = 0;
-                if (on && piece == 0u) {
-                    at = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
-                    atomicAdd(&pool_hist[b], 8u);
-                }
-                at = __shfl(at, (int)(lane & ~3u));
-                dst = pool + at;
-            }
-            if (on) *reinterpret_cast<ulonglong2 *>(dst + piece * 2u) = d;
-            KTA_LDS_ORDER();
-            if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);    // the half is free again
+    // Completed blocks leave in two halves.  take_blocks (end of a step): up to 48 queued blocks are read from
+    // their rings into registers — four lanes per block, 16 bytes each — and their ring halves are free again at
+    // once.  put_blocks (next step, right before that step's prefetch loads are issued): the registers are
+    // stored, whole aligned 64-byte blocks.  Loads and stores share one in-order counter (vmcnt): a store issued
+    // AFTER a prefetch load would be waited for together with it at the top of the next step, and a varying
+    // number of stores would hide the load from the compiler's count altogether.
+#ifndef KTA_PART_STAGE
+#define KTA_PART_STAGE 2
+#endif
+    constexpr uint32_t kTake = KTA_PART_STAGE;        // 16-block groups staged in registers at the end of a step
+    // (named registers, not arrays: indexed through the lambdas below, arrays ended up in scratch memory; the
+    // destination is kept as one word: its offset in 16-byte units, bit 31 = in the pool, all ones = none)
+    ulonglong2 st_d0, st_d1;
+    uint32_t st_o0 = ~0u, st_o1 = ~0u;
+    auto put_one = [&](const ulonglong2 &sd, uint32_t &so) __attribute__((always_inline)) {
+        if (so != ~0u) {
+            unsigned long long *base = so >> 31 ? pool : pairs;
+            *reinterpret_cast<ulonglong2 *>(base + (size_t)(so & 0x7FFFFFFFu) * 2u) = sd;
         }
-        qn = 0;
+        so = ~0u;
     };
+    // one group of up to 16 queued blocks, four lanes per block: ring -> registers, the ring half is free again
+    auto take_one = [&](uint32_t i, ulonglong2 &sd, uint32_t &so) __attribute__((always_inline)) {
+        const uint32_t e = i * 16u + (lane >> 2), piece = lane & 3u;
+        const bool on = e < qn;
+        const uint32_t ent = queue[on ? e : 0u];
+        const uint32_t b = ent & (B - 1), k = ent >> BLOG2;                   // bucket, block number
+        sd = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(b, k * 8u + piece * 2u));
+        uint32_t off;
+        if ((k + 1u) * 8u <= cap) {
+            off = (uint32_t)((((uint64_t)b * W + w) * cap + (uint64_t)k * 8u) >> 1);
+        } else {                                                              // the segment is full: to the pool
+            unsigned long long at = 0;
+            if (on && piece == 0u) {
+                at = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
+                atomicAdd(&pool_hist[b], 8u);
+            }
+            at = __shfl(at, (int)(lane & ~3u));
+            off = (uint32_t)(at >> 1) | 0x80000000u;
+        }
+        so = on ? off + piece : ~0u;
+        KTA_LDS_ORDER();
+        if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);    // the half is free again
+    };
+    auto drop_taken = [&](uint32_t groups) __attribute__((always_inline)) {      // the queue's first groups are gone
+        const uint32_t took = qn < 16u * groups ? qn : 16u * groups;
+        for (uint32_t e0 = took; e0 < qn; e0 += 64) {                             // the rest moves up
+            const uint32_t v = e0 + lane < qn ? queue[e0 + lane] : 0u;
+            KTA_LDS_ORDER();
+            if (e0 + lane < qn) queue[e0 + lane - took] = v;
+            KTA_LDS_ORDER();
+        }
+        qn -= took;
+    };
+    auto put_blocks = [&]() __attribute__((always_inline)) {                       // start of a step, before its prefetch loads
+        put_one(st_d0, st_o0);
+        put_one(st_d1, st_o1);
+        while (qn) {                                                                // what was not staged: ring -> memory
+            ulonglong2 d;
+            uint32_t o;
+            take_one(0, d, o);
+            put_one(d, o);
+            drop_taken(1);
+        }
+    };
+    auto take_blocks = [&]() __attribute__((always_inline)) {                      // end of a step
+        if (kTake >= 1) take_one(0, st_d0, st_o0);
+        if (kTake >= 2) take_one(1, st_d1, st_o1);
+        if (kTake) drop_taken(kTake);
+    };
+    auto flush_queue = [&]() __attribute__((always_inline)) { put_blocks(); };     // everything, now
 
 #ifdef KTA_DBG_NOLDS
     long long dummy = 0;
@@ -292,9 +352,16 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
         // make the wave wait for the prefetch at the very place it was issued.
         TileCols cols_a, cols_b;
         TileKeys keys_a, keys_b;
-        uint64_t tile = first + wave;
-        load_cols(c, n, skip, tile, true, cols_a);
-        load_cols(c, n, skip, tile + kPartWaves, tile + kPartWaves < end, cols_b);
+        // The workgroup's range is walked from a start that differs from workgroup to workgroup (and around): the
+        // ranges lie a power of two apart, and in step all workgroups would ask the same few memory channels.
+        const uint64_t span = end - first, rot = span > 64u ? ((uint64_t)w * 37u * kPartWaves) % span : 0u;
+        auto at = [&](uint64_t i) __attribute__((always_inline)) -> uint64_t {   // i-th tile of this workgroup's walk
+            const uint64_t r = i + rot;
+            return first + (r < span ? r : r - span);
+        };
+        uint64_t tile = wave;                            // index into the walk
+        load_cols(c, n, skip, at(tile), true, cols_a);
+        load_cols(c, n, skip, at(tile + kPartWaves < span ? tile + kPartWaves : tile), tile + kPartWaves < span, cols_b);
         load_keys(c, cols_a, keys_a);
         auto step = [&](TileCols &r, TileKeys &keys, TileCols &r_next, TileKeys &keys_next, uint64_t t) __attribute__((always_inline)) {
             const int32_t kl[4] = {r.kl.x, r.kl.y, r.kl.z, r.kl.w}, vl[4] = {r.vl.x, r.vl.y, r.vl.z, r.vl.w};
@@ -302,7 +369,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             uint32_t h[4];
             unsigned long long pr[4];
             bool keyed[4];
-            const uint64_t i0 = t * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
+            const uint64_t i0 = at(t) * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 keyed[j] = kl[j] >= 0;
@@ -311,7 +378,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             }
             KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
             load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
-            load_cols(c, n, skip, t + 2 * kPartWaves, t + 2 * kPartWaves < end, r);   // r is spent: hashed
+            load_cols(c, n, skip, at(t + 2 * kPartWaves < span ? t + 2 * kPartWaves : t), t + 2 * kPartWaves < span, r);   // r is spent: hashed
+            // The blocks taken at the end of the last step are stored AFTER this step's loads were issued: loads
+            // and stores share one in-order counter (vmcnt), and the compiler cannot count a varying number of
+            // stores — issued before the loads, the wait for "the columns that came before them" becomes a wait
+            // for the stores themselves.  Issued last, they are what a later vmcnt(N) lets pend.
+            put_blocks();
 #ifdef KTA_DBG_NOLDS   /* ablation build of tools/ubench_alive.hip only: stream + hash, nothing else */
             dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
             return;
@@ -326,11 +398,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 #pragma unroll
             for (int j = 0; j < 4; j++) hw[j] = s_half[2 * bk[j] + ((p[j] >> 3) & 1u)];   // plain reads: four in flight
             KTA_LDS_ORDER();
+            KTA_PHASE(0, 1);   // positions + half words
             uint32_t pending = 0;
             bool done[4];
             // insert record j at its position once its ring half is free; true when that completed the block
             auto insert = [&](int j) __attribute__((always_inline)) -> bool {
-                s_ring[bk[j] * kRing + (p[j] & (kRing - 1))] = pr[j];
+                s_ring[ring_at(bk[j], p[j])] = pr[j];
                 KTA_LDS_ORDER();
                 return (lds_add(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)], 1u) & 15u) == 7u;
             };
@@ -355,8 +428,11 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                 }
                 KTA_LDS_ORDER();
             };
+            KTA_PHASE(0, 2);   // inserts
             enqueue();
-            flush_queue();   // every step: a completed block frees its ring half only when it is written out
+            KTA_PHASE(0, 3);   // queueing
+            take_blocks();   // every step: a completed block frees its ring half when it leaves the ring
+            KTA_PHASE(0, 5);   // ring -> registers
             // Rare: a position whose ring half still holds the block before last (sixteen arrivals of one
             // bucket in flight).  Whoever holds a position in an older block never waits for a younger one, so
             // the oldest unwritten block always completes; its writers may sit in this very wave, which is why
@@ -374,13 +450,13 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                 flush_queue();
                 __builtin_amdgcn_s_sleep(1);
             }
-            KTA_PHASE(0, 4);   // arrivals: LDS atomics, ring writes, queueing
+            KTA_PHASE(0, 4);   // waiting for a ring half
         };
         for (;; tile += 2 * kPartWaves) {
             step(cols_a, keys_a, cols_b, keys_b, tile);
-            if (tile + kPartWaves >= end) break;
+            if (tile + kPartWaves >= span) break;
             step(cols_b, keys_b, cols_a, keys_a, tile + kPartWaves);
-            if (tile + 2 * kPartWaves >= end) break;
+            if (tile + 2 * kPartWaves >= span) break;
         }
         flush_queue();
     }
@@ -396,10 +472,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             if ((k + 1u) * 8u <= cap) {
                 dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 8u;
             } else {
-                dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)rem);
+                // an even number of pairs: the pool's blocks are addressed in 16-byte units (a zero pair is no pair)
+                dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)((rem + 1u) & ~1u));
                 atomicAdd(&pool_hist[b], rem);
+                if (rem & 1u) dst[rem] = 0ull;
             }
-            for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring[b * kRing + (k & 1u) * 8u + q];
+            for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring[ring_at(b, k * 8u + q)];
         }
         counts[(uint64_t)b * W + w] = f < cap ? f : cap;
     }
@@ -411,14 +489,19 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 // ------------------------------------------------------------------------------------------------------
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
-constexpr int kApplyUnroll = 4;                    // 16-byte loads a lane has in flight = 8 pairs per lane and unit
+constexpr int kApplyUnroll = 2;                    // 16-byte loads of a unit: 256 pairs, 4 per lane
 constexpr uint32_t kMaxSegWGs = 1024;              // partition workgroups (segments per bucket) at most
 constexpr uint32_t kSetLog2 = 11;                  // 2048 sets of 8 entries = 16384 entries
 constexpr uint32_t kSets = 1u << kSetLog2;
 constexpr uint32_t kEntries = kSets * 8u;
-constexpr uint32_t kOvf = 1024;                    // records that found their set full
+constexpr uint32_t kOvfLog2 = 11;
+constexpr uint32_t kOvf = 1u << kOvfLog2;          // side table for the slots that found their set full
+constexpr uint32_t kOvfSubLog2 = kOvfLog2 - 4;      // one sub-table per slice of 128 sets
+constexpr uint32_t kOvfSub = 1u << kOvfSubLog2;
+constexpr uint32_t kOvfProbes = 32;                // linear probes before the side table counts as full
 constexpr uint32_t kSliceSets = 128;               // sets of one bitmap slice
 constexpr uint32_t kNoFail = 0xFFFFFFFFu;
+constexpr uint32_t kMissQueue = 256;               // pairs a wave queues for the long way of the merge
 
 typedef unsigned short __attribute__((ext_vector_type(2))) ushort2v;
 
@@ -446,7 +529,14 @@ __device__ __forceinline__ uint32_t find_tag(const uint4 &t, uint32_t tag)
 }
 
 struct ApplyShared {
-    uint32_t occ, pairs, claims, ovf_n, fail, decision, slice_mask, growth;
+    uint32_t pairs, claims, instalments, ovf_total;
+    // Counters of the current instalment in three rotating slots: between checkpoint t - 1 and t the waves add to
+    // slot t % 3; after the barrier of checkpoint t everybody reads it, and thread 0 clears slot (t + 2) % 3 — the
+    // one of interval t - 1, which nobody reads any more (all are past that) and nobody adds to before the barrier
+    // of checkpoint t + 1 is behind them.  One barrier per checkpoint.
+    uint32_t occ[3], ovf_n[3], fail[3];
+    uint32_t any_ovf;        // the side table holds something (this instalment)
+    uint32_t next_seg;       // fast attempt: the next segment to hand out
     long long w[kApplyWaves];
 };
 
@@ -469,7 +559,6 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     constexpr uint32_t RBITS = 32 - BLOG2;             // hash bits below the bucket
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
     static_assert(TAGBITS <= 15, "tags are 16 bit");
-    constexpr uint32_t kSlices = kSets / kSliceSets;
     constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
     static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
     // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
@@ -478,8 +567,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     KTA_PHASE_BEGIN;
     extern __shared__ __attribute__((aligned(128))) uint32_t s_val[];        // kEntries values
     unsigned short *s_tag = reinterpret_cast<unsigned short *>(s_val + kEntries);   // kEntries tags
-    uint32_t *s_setcnt = reinterpret_cast<uint32_t *>(s_tag + kEntries);     // entries handed out per set
-    unsigned long long *s_ovf = reinterpret_cast<unsigned long long *>(s_setcnt + kSets);   // kOvf pairs
+    unsigned long long *s_ovf = reinterpret_cast<unsigned long long *>(s_tag + kEntries);   // kOvf pairs
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ovf + kOvf);            // W segment fills
     uint32_t *s_slice = s_cnt + ((W + 31u) & ~31u);                          // BITMAP: one slice of the region
     __shared__ ApplyShared sh;
@@ -496,16 +584,15 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
         if (threadIdx.x == 0) fail_from[b] = kNoFail;
     }
-    for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + kSets; e += kApplyThreads) s_val[e] = 0u;   // values, tags, set counts
+    for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + 2 * kOvf; e += kApplyThreads) s_val[e] = 0u;   // values, tags, side table
     if (threadIdx.x == 0) {
-        sh.occ = 0;
         sh.pairs = 0;
         sh.claims = 0;
-        sh.ovf_n = 0;
-        sh.fail = 0;
-        sh.decision = 0;
-        sh.slice_mask = 0;
-        sh.growth = 0;
+        sh.instalments = 0;
+        sh.ovf_total = 0;
+        sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = sh.fail[0] = sh.fail[1] = sh.fail[2] = 0;
+        sh.any_ovf = 0;
+        sh.next_seg = 0;
     }
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
@@ -520,7 +607,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     long long delta = 0;
 
     // global value of a survivor (table state): ((sequence + 1) << 1) | alive
-    auto global_val = [&](uint32_t lo) -> unsigned long long {
+    auto global_val = [&](uint32_t lo) __attribute__((always_inline)) -> unsigned long long {
         const uint64_t idx = (uint64_t)(lo >> 1) - 1u;
         const uint64_t s = seq_col ? seq_col[idx] : base_seq + idx;
         return ((unsigned long long)(s + 1) << 1) | (lo & 1u);
@@ -530,100 +617,103 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // (every lambda of this kernel is forced inline: out of line, its captures live in scratch memory and the LDS
     // pointers among them lose their address space — flat instead of ds instructions)
     auto end_instalment = [&]() __attribute__((always_inline)) {
-        // (1) duplicates.  Lookups run ahead of claims (four pairs of a lane are looked up together, waves
-        // race), so one slot can hold two entries of its set: keep the larger value in the first.
-        for (uint32_t s = threadIdx.x; s < kSets; s += kApplyThreads) {
-            const uint4 t4 = *reinterpret_cast<const uint4 *>(s_tag + s * 8u);
-            if ((t4.x | t4.y | t4.z | t4.w) == 0u) continue;
-            if (BITMAP) atomicOr(&sh.slice_mask, 1u << (s / kSliceSets));
-            const uint32_t t[8] = {t4.x & 0xFFFFu, t4.x >> 16, t4.y & 0xFFFFu, t4.y >> 16,
-                                   t4.z & 0xFFFFu, t4.z >> 16, t4.w & 0xFFFFu, t4.w >> 16};
-            bool dup = false;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = i + 1; j < 8; j++) dup |= t[i] != 0u && t[i] == t[j];
-            if (!dup) continue;
-            for (int i = 0; i < 8; i++)
-                for (int j = i + 1; j < 8; j++) {
-                    if (s_tag[s * 8u + i] == 0 || s_tag[s * 8u + i] != s_tag[s * 8u + j]) continue;
-                    const uint32_t vi = s_val[s * 8u + i], vj = s_val[s * 8u + j];
-                    s_val[s * 8u + i] = vi > vj ? vi : vj;
-                    s_tag[s * 8u + j] = 0;
-                    s_val[s * 8u + j] = 0u;
-                }
-        }
-        __syncthreads();
-        // (2) the records that found their set full: the slot may have entered the set meanwhile (-> max into
-        // its entry); otherwise the record with the largest value per slot of the list survives on its own.
-        const uint32_t novf = sh.ovf_n < kOvf ? sh.ovf_n : kOvf;
-        for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
-            const unsigned long long pr = s_ovf[k];
-            const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u), lo = (uint32_t)pr;
-            const uint32_t set = h >> TAGBITS, tag = (h & ((1u << TAGBITS) - 1u)) + 1u;
-            const uint32_t e = find_tag(*reinterpret_cast<const uint4 *>(s_tag + set * 8u), tag);
-            bool keep = e == 8u;
-            if (!keep) atomicMax(&s_val[set * 8u + e], lo);
-            for (uint32_t q = 0; keep && q < novf; q++) {
-                const unsigned long long o = s_ovf[q];
-                // the same slot with a larger value (or the same pair at a lower position) wins
-                if ((uint32_t)(o >> 32) == (uint32_t)(pr >> 32) && ((uint32_t)o > lo || ((uint32_t)o == lo && q < k))) keep = false;
-            }
-            if (!keep) s_ovf[k] = 0ull;                 // (a pair is never zero)
-        }
-        __syncthreads();
+        lds_barrier();                                  // every wave's merges are done
+        // The slots that found their set full sit in the side table, one entry per slot (never also in a set: tags
+        // do not leave a set during an instalment, so a slot that was refused once is refused every time).
+        const uint32_t novf = sh.any_ovf ? kOvf : 0u;
         if (BITMAP) {
-            // (3) the region of the bit set, slice by slice through LDS: a slice = the slots of 128 consecutive sets
-            uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
-            const uint32_t mask = sh.slice_mask | (novf ? (1u << kSlices) - 1u : 0u);
-            uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
-            uint32_t s = mask ? (uint32_t)__builtin_ctz(mask) : kSlices;
-            if (s < kSlices) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(region + (size_t)s * kSliceWords);
-                pre0 = src[threadIdx.x];
-                pre1 = src[threadIdx.x + kApplyThreads];
+            // The bucket's region of the bit set goes through LDS, and no workgroup barrier is needed for it: wave v
+            // owns the slots of the sets [128 v, 128 v + 128) and walks them in 16 pieces of 8 sets = 2 KiB of bit
+            // set = 32 bytes per lane; the piece's 64 table entries are one per lane.  The next piece is requested
+            // while this one is worked on.
+            uint32_t *mine = bitmap + ((size_t)b << (RBITS - 5)) + (size_t)wave * kSliceWords;
+            uint32_t *buf = s_slice + wave * (kSliceWords / kSliceSets * 8u);       // 512 words of this wave
+            constexpr uint32_t kPieces = kSliceSets / 8u;                          // 16
+            constexpr uint32_t kPieceWords = kSliceWords / kPieces;                // 512
+            // Which of the wave's pieces hold entries at all (a small batch leaves most of the region alone).  The
+            // pieces are walked from a start that differs from wave to wave and bucket to bucket: in step, 4096
+            // waves would otherwise ask for addresses that differ by multiples of 32 KiB — a handful of the
+            // memory's channels — at every moment.  Bit i of `occupied` = piece (i + start) % 16.
+            const uint32_t start = (wave + b * 5u) & (kPieces - 1u);
+            uint32_t occupied = 0;
+#pragma unroll 4
+            for (uint32_t i = 0; i < kPieces; i++)
+                occupied |= (__any(s_tag[(wave * kSliceSets + ((i + start) & (kPieces - 1u)) * 8u) * 8u + lane] != 0) ? 1u : 0u) << i;
+            const uint4 *src = reinterpret_cast<const uint4 *>(mine);
+            // The occupied pieces, one request ahead.  Loads and stores share one in-order counter (vmcnt): the next
+            // piece is requested BEFORE this piece's stores, so the wait for it lets exactly those stores pend.
+            auto next_piece = [&](uint32_t after) __attribute__((always_inline)) -> uint32_t {   // kPieces: none
+                const uint32_t rest = after + 1u < 32u ? occupied & ~((2u << after) - 1u) : 0u;
+                return rest ? (uint32_t)__builtin_ctz(rest) : kPieces;
+            };
+            auto request = [&](uint32_t i, uint4 &q0, uint4 &q1) __attribute__((always_inline)) {   // unconditional: countable
+                const uint32_t mc = ((i < kPieces ? i : 0u) + start) & (kPieces - 1u);
+                q0 = src[(size_t)mc * (kPieceWords / 4u) + lane];
+                q1 = src[(size_t)mc * (kPieceWords / 4u) + lane + 64u];
+            };
+            // the side table's entries of this wave's slots: two per lane (their sets are full, so their pieces are
+            // among the occupied ones)
+            static_assert(kOvfSub == 128, "two side entries per lane");
+            const unsigned long long side0 = novf ? s_ovf[wave * kOvfSub + lane] : 0ull;
+            const unsigned long long side1 = novf ? s_ovf[wave * kOvfSub + 64u + lane] : 0ull;
+            auto apply_side = [&](unsigned long long pr, uint32_t m) __attribute__((always_inline)) {
+                if (pr == 0ull) return;
+                const uint32_t h = (uint32_t)(pr >> 32) - 1u, lo = (uint32_t)pr;
+                const uint32_t set_local = (h >> TAGBITS) & (kSliceSets - 1u);
+                if ((set_local >> 3) != m) return;
+                const uint32_t bit = ((set_local & 7u) << TAGBITS) | (h & ((1u << TAGBITS) - 1u));
+                const uint32_t mk = 1u << (bit & 31u);
+                const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
+                delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
+            };
+            auto piece = [&](uint32_t i, const uint4 &q0, const uint4 &q1) __attribute__((always_inline)) {
+                const uint32_t m = (i + start) & (kPieces - 1u);
+                uint4 *sl = reinterpret_cast<uint4 *>(buf);
+                sl[lane] = q0;
+                sl[lane + 64u] = q1;
+                KTA_LDS_ORDER();
+                const uint32_t e = (wave * kSliceSets + m * 8u) * 8u + lane;
+                const uint32_t tag = s_tag[e], lo = s_val[e];
+                if (tag) {
+                    const uint32_t bit = ((lane >> 3) << TAGBITS) | (tag - 1u);
+                    const uint32_t mk = 1u << (bit & 31u);
+                    const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
+                    delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
+                    s_tag[e] = 0;
+                    s_val[e] = 0u;
+                }
+                apply_side(side0, m);
+                apply_side(side1, m);
+                KTA_LDS_ORDER();
+                uint4 *dst = reinterpret_cast<uint4 *>(mine + (size_t)m * kPieceWords);
+                dst[lane] = sl[lane];
+                dst[lane + 64u] = sl[lane + 64u];
+                KTA_LDS_ORDER();
+            };
+            // The first piece is peeled off the loop so that every path into the loop's top has the same operations
+            // outstanding — [this piece's two loads, the previous piece's two stores] — and the compiler's wait for
+            // the loads is exactly "all but the two stores" (merging a path without stores, it would wait for one).
+            uint32_t m = occupied ? (uint32_t)__builtin_ctz(occupied) : kPieces;
+            if (m < kPieces) {
+                uint4 a0, a1;
+                request(m, a0, a1);
+                {
+                    const uint32_t mn = next_piece(m);
+                    const uint4 t0 = a0, t1 = a1;
+                    request(mn, a0, a1);
+                    piece(m, t0, t1);
+                    m = mn;
+                }
+#pragma unroll 1
+                while (m < kPieces) {
+                    const uint32_t mn = next_piece(m);
+                    const uint4 t0 = a0, t1 = a1;
+                    request(mn, a0, a1);
+                    piece(m, t0, t1);
+                    m = mn;
+                }
             }
-            while (s < kSlices) {
-                uint4 *sl = reinterpret_cast<uint4 *>(s_slice);
-                sl[threadIdx.x] = pre0;
-                sl[threadIdx.x + kApplyThreads] = pre1;
-                const uint32_t rest = mask & ~((2u << s) - 1u);
-                const uint32_t nxt = rest ? (uint32_t)__builtin_ctz(rest) : kSlices;
-                if (nxt < kSlices) {                     // the next slice is requested while this one is worked on
-                    const uint4 *src = reinterpret_cast<const uint4 *>(region + (size_t)nxt * kSliceWords);
-                    pre0 = src[threadIdx.x];
-                    pre1 = src[threadIdx.x + kApplyThreads];
-                }
-                __syncthreads();
-                {   // one entry per thread: the slice's 128 sets x 8 entries
-                    const uint32_t e = s * (kSliceSets * 8u) + threadIdx.x;
-                    const uint32_t tag = s_tag[e], lo = s_val[e];
-                    if (tag) {
-                        const uint32_t bit = ((threadIdx.x >> 3) << TAGBITS) | (tag - 1u);
-                        const uint32_t m = 1u << (bit & 31u);
-                        const uint32_t old = lo & 1u ? atomicOr(&s_slice[bit >> 5], m) : atomicAnd(&s_slice[bit >> 5], ~m);
-                        delta += (long long)(lo & 1u) - (long long)((old & m) != 0u);
-                        s_tag[e] = 0;
-                        s_val[e] = 0u;
-                    }
-                }
-                for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
-                    const unsigned long long pr = s_ovf[k];
-                    if (pr == 0ull) continue;
-                    const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u), lo = (uint32_t)pr;
-                    if ((h >> TAGBITS) / kSliceSets != s) continue;
-                    const uint32_t bit = h & ((kSliceSets << TAGBITS) - 1u);
-                    const uint32_t m = 1u << (bit & 31u);
-                    const uint32_t old = lo & 1u ? atomicOr(&s_slice[bit >> 5], m) : atomicAnd(&s_slice[bit >> 5], ~m);
-                    delta += (long long)(lo & 1u) - (long long)((old & m) != 0u);
-                }
-                __syncthreads();
-                uint4 *dst = reinterpret_cast<uint4 *>(region + (size_t)s * kSliceWords);
-                dst[threadIdx.x] = sl[threadIdx.x];
-                dst[threadIdx.x + kApplyThreads] = sl[threadIdx.x + kApplyThreads];
-                __syncthreads();                        // the slice is read out before the next one lands in it
-                s = nxt;
-            }
+            lds_barrier();                              // all waves have read the side table
         } else {
             // (3) the workgroup is its region's only writer during this kernel (its own direct-path atomics
             // are complete: barrier), so read / compare / write needs no RMW atomic.  Loads and stores are
@@ -652,26 +742,25 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                         delta += (long long)(v[u] & 1ull) - (long long)(old[u] & 1ull);
                     }
             }
-            __syncthreads();                            // the plain writes are out before the list's atomics
+            lds_barrier();
             for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
                 const unsigned long long pr = s_ovf[k];
-                if (pr) delta += direct_update(table, (b << RBITS) | ((uint32_t)(pr >> 32) & ((1u << RBITS) - 1u)), global_val((uint32_t)pr));
+                if (pr) delta += direct_update(table, (b << RBITS) | ((uint32_t)(pr >> 32) - 1u), global_val((uint32_t)pr));
             }
         }
-        for (uint32_t s = threadIdx.x; s < kSets; s += kApplyThreads) s_setcnt[s] = 0u;
-        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) s_ovf[k] = 0ull;
         if (threadIdx.x == 0) {
-            sh.claims += sh.occ;
-            sh.occ = 0;
-            sh.ovf_n = 0;
-            sh.slice_mask = 0;
-            sh.growth = 0;
+            sh.claims += sh.occ[0] + sh.occ[1] + sh.occ[2];
+            sh.instalments++;
+            sh.ovf_total += sh.ovf_n[0] + sh.ovf_n[1] + sh.ovf_n[2];
+            sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = 0;
+            sh.any_ovf = 0;
         }
-        __syncthreads();
+        lds_barrier();
     };
 
-    // A wave reads its segments (every kApplyWaves-th of the bucket, in ascending order) in units of up to
-    // kApplyUnroll 16-byte loads per lane = 512 pairs, masked by the segment's fill (cap is a multiple of 128).
+    // A wave reads its segments in units of kApplyUnroll 16-byte loads per lane = 256 pairs, masked by the segment's
+    // fill (cap is a multiple of 128).
     // The loads of unit u + 1 are issued before unit u is merged, so a wave always has a unit in flight.
     const unsigned long long *region_pairs = pairs + (uint64_t)b * W * cap;
     const uint32_t loads = cap >> 7;
@@ -680,116 +769,240 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     const uint32_t units = groups * chunks;                                     // the same for every wave
     ulonglong2 p[kApplyUnroll], pn[kApplyUnroll];
     uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2
-    auto issue = [&](uint32_t u, ulonglong2 (&q)[kApplyUnroll], uint32_t (&qv)[kApplyUnroll]) {
-        const uint32_t w = (u / chunks) * kApplyWaves + wave, r0 = (u % chunks) * kApplyUnroll;
-        const uint32_t cnt = u < units && w < W ? s_cnt[w] : 0u;
-        const unsigned long long *seg = region_pairs + (uint64_t)(u < units && w < W ? w : 0u) * cap;
+    // Which segment a unit reads: in careful mode wave v takes the segments v, v + 16, ... (every group of 16 is
+    // older than the next); in the fast attempt the order does not matter and the waves take whatever segment is
+    // next (they finish together instead of waiting for whoever had the slow records).
+    uint32_t seg = 0, seg_unit = 0, seg_units = 0;       // wave-uniform
+    bool dynamic = false;
+    auto issue = [&](uint32_t u, ulonglong2 (&q)[kApplyUnroll], uint32_t (&qv)[kApplyUnroll]) __attribute__((always_inline)) {
+        uint32_t r0;
+        if (dynamic) {                                   // a handed-out segment is read in as many units as it has pairs for
+            if (seg_unit >= seg_units) {
+                uint32_t g = 0;
+                if (lane == 0) g = lds_add(&sh.next_seg, 1u);
+                seg = __builtin_amdgcn_readfirstlane(g);
+                const uint32_t c = __builtin_amdgcn_readfirstlane(s_cnt[seg < W ? seg : 0u]);
+                seg_units = (c + 128u * kApplyUnroll - 1u) / (128u * kApplyUnroll);
+                if (seg_units == 0u) seg_units = 1u;
+                seg_unit = 0;
+            }
+            r0 = seg_unit * kApplyUnroll;
+            seg_unit++;
+        } else {
+            r0 = (u % chunks) * kApplyUnroll;
+            seg = (u / chunks) * kApplyWaves + wave;
+        }
+        const bool on = seg < W && (dynamic || u < units);
+        const uint32_t cnt = on ? s_cnt[on ? seg : 0u] : 0u;
+        const unsigned long long *sp = region_pairs + (uint64_t)(on ? seg : 0u) * cap;
 #pragma unroll
         for (int x = 0; x < kApplyUnroll; x++) {
             const uint32_t k = ((r0 + (uint32_t)x) << 7) + 2u * lane;
             qv[x] = (r0 + (uint32_t)x) < loads && k < cnt ? (cnt - k >= 2u ? 2u : 1u) : 0u;
             // unconditional (clamped address, masked by qv): a predicated load is a branch, and the wait for this
             // unit's data would then be vmcnt(0) — it would wait for the NEXT unit's loads as well
-            q[x] = *reinterpret_cast<const ulonglong2 *>(seg + (qv[x] ? k : 2u * lane));
+            q[x] = *reinterpret_cast<const ulonglong2 *>(sp + (qv[x] ? k : 2u * lane));
         }
     };
-    issue(0, p, nv);
     uint32_t claimed = 0;
-    // merge the unit held in (q, qv): two groups of four pairs, each group's four lookups in flight together
-    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll]) {
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            uint32_t set[4], tag[4], lo[4];
-            uint4 t[4];
-            bool valid[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int x = g * 4 + i;
-                const unsigned long long pr = x & 1 ? q[x >> 1].y : q[x >> 1].x;
-                const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u);
-                valid[i] = qv[x >> 1] > (uint32_t)(x & 1);
-                lo[i] = (uint32_t)pr;
-                set[i] = h >> TAGBITS;
-                tag[i] = (h & ((1u << TAGBITS) - 1u)) + 1u;
-                t[i] = *reinterpret_cast<const uint4 *>(s_tag + set[i] * 8u);
+    bool careful = pool_ctl[POOL_DENSE] != 0ull;       // an earlier bucket of this batch overflowed its table: check as we go
+    // The merge of one pair that found no entry for its slot.  A new slot takes the set's first free entry with a
+    // compare-and-swap on the dword that holds it.  All racers for one slot pick the same entry (first free), so
+    // exactly one wins and the others find its tag when they look again: a slot never holds two entries.
+    auto merge_new = [&](uint32_t h, uint32_t lo, uint32_t par) __attribute__((always_inline)) {
+        const uint32_t set = h >> TAGBITS, tag = (h & ((1u << TAGBITS) - 1u)) + 1u;
+        uint32_t e;
+        for (;;) {
+            KTA_LDS_ORDER();
+            const uint4 tt = *reinterpret_cast<const uint4 *>(s_tag + set * 8u);
+            KTA_LDS_ORDER();
+            e = find_tag(tt, tag);
+            if (e < 8u) break;
+            const uint32_t f = find_tag(tt, 0u);
+            if (f == 8u) break;                           // the set is full
+            const uint32_t d = f >> 1;
+            const uint32_t old = d == 0u ? tt.x : (d == 1u ? tt.y : (d == 2u ? tt.z : tt.w));
+            uint32_t *word = reinterpret_cast<uint32_t *>(s_tag + set * 8u) + d;
+            if (atomicCAS(word, old, old | (tag << (16u * (f & 1u)))) == old) {
+                e = f;
+                claimed++;
+                break;
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (!valid[i]) continue;
-                uint32_t e = find_tag(t[i], tag[i]);
-                if (e == 8u) {                            // a new slot: the set hands out its next entry
-                    e = lds_add(&s_setcnt[set[i]], 1u);
-                    if (e < 8u) {
-                        s_tag[set[i] * 8u + e] = (unsigned short)tag[i];
-                        claimed++;
-                    } else {                              // the set is full: to the list (or, the list full too, give up here)
-                        const uint32_t k = lds_add(&sh.ovf_n, 1u);
-                        const unsigned long long pr = ((unsigned long long)((set[i] << TAGBITS) | (tag[i] - 1u)) << 32) | lo[i];
-                        if (k < kOvf) s_ovf[k] = pr;
-                        else if (BITMAP) sh.fail = 1u;
-                        else delta += direct_update(table, (b << RBITS) | (uint32_t)(pr >> 32), global_val(lo[i]));
-                        continue;
-                    }
+        }
+        if (e < 8u) {
+            atomicMax(&s_val[set * 8u + e], lo);
+            return;
+        }
+        // The set is full: the slot goes to the side table — open addressing over 64-bit entries (slot + 1) << 32 |
+        // value, claimed with a compare-and-swap, the value kept with a 64-bit max (same slot, same upper half);
+        // one sub-table of kOvf / 16 entries per slice of 128 sets (the wave that sweeps a slice of the bit set
+        // reads its sub-table into registers).  Full as well: the attempt is given up (fast attempt; bit set state)
+        // or the record takes the direct path (table state, careful mode).
+        const unsigned long long pr = ((unsigned long long)(h + 1u) << 32) | lo;
+        const uint32_t sub = (set / kSliceSets) * kOvfSub;
+        uint32_t pos = sub + ((h * 0x9E3779B1u) >> (32 - kOvfSubLog2));
+        bool placed = false;
+        for (uint32_t probe = 0; probe < kOvfProbes; probe++) {
+            unsigned long long cur = s_ovf[pos];
+            if (cur == 0ull) {
+                cur = atomicCAS(&s_ovf[pos], 0ull, pr);
+                if (cur == 0ull) {
+                    lds_add(&sh.ovf_n[par], 1u);
+                    sh.any_ovf = 1u;
+                    placed = true;
+                    break;
                 }
-                atomicMax(&s_val[set[i] * 8u + e], lo[i]);
+            }
+            if ((uint32_t)(cur >> 32) == h + 1u) {
+                atomicMax(&s_ovf[pos], pr);
+                placed = true;
+                break;
+            }
+            pos = sub + ((pos + 1u) & (kOvfSub - 1u));
+        }
+        if (!placed) {
+            if (BITMAP || !careful) sh.fail[par] = 1u;
+            else delta += direct_update(table, (b << RBITS) | h, global_val(lo));
+        }
+    };
+    // Pairs whose slot has an entry (most of a compacted topic's) are merged where they stand: one lookup, one
+    // max.  The others are queued, per wave, and handled 64 at a time: a lane that needs the long way would
+    // otherwise make its whole wave walk it — and with 64 lanes there is always one.  The queues live in the LDS
+    // the sweep uses later (2 KiB = 256 pairs per wave).
+    unsigned long long *missq = reinterpret_cast<unsigned long long *>(s_slice) + wave * kMissQueue;
+    uint32_t mq = 0;                                     // wave-uniform
+    auto drain = [&](uint32_t par) __attribute__((always_inline)) {
+        KTA_LDS_ORDER();
+        for (uint32_t q0 = 0; q0 < mq; q0 += 64u) {
+            const bool on = q0 + lane < mq;
+            const unsigned long long pr = missq[on ? q0 + lane : 0u];
+            if (on) merge_new((uint32_t)(pr >> 32), (uint32_t)pr, par);
+        }
+        KTA_LDS_ORDER();
+        mq = 0;
+    };
+    // merge the unit held in (q, qv): four pairs per lane, their four lookups in flight together, then the misses
+    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par) __attribute__((always_inline)) {
+        static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the queue");
+        const unsigned long long pr[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
+        const bool valid[4] = {qv[0] > 0u, qv[0] > 1u, qv[1] > 0u, qv[1] > 1u};
+        uint32_t set[4], tag[4], hr[4];
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hr[i] = (uint32_t)(pr[i] >> 32) & ((1u << RBITS) - 1u);
+            set[i] = hr[i] >> TAGBITS;
+            tag[i] = (hr[i] & ((1u << TAGBITS) - 1u)) + 1u;
+            t[i] = *reinterpret_cast<const uint4 *>(s_tag + set[i] * 8u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = valid[i] ? find_tag(t[i], tag[i]) : 0u;
+            if (valid[i] && e < 8u) atomicMax(&s_val[set[i] * 8u + e], (uint32_t)pr[i]);
+            const bool miss = valid[i] && e == 8u;
+            const unsigned long long m = __ballot(miss);
+            if (miss) missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
+            mq += (uint32_t)__popcll(m);
+        }
+        drain(par);
+    };
+    // The driver.  First without checkpoints (no barrier until the end: a compacted topic's bucket fits the table);
+    // a bucket that overflows table AND side table that way starts over in careful mode, and tells the buckets
+    // still to come (POOL_DENSE).  Careful mode: after every trip that ends on a group boundary (every wave has
+    // finished whole segments: everything merged so far is older than everything that follows — what the bit set
+    // state needs) the workgroup decides whether the table is emptied before it goes on.  Every thread keeps the
+    // instalment's totals in registers, fed from the counter slot of the interval just ended (ApplyShared).
+    uint32_t inst_start = 0;                            // first segment of the current instalment
+    uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
+    uint32_t u = 0;
+    for (;;) {                                          // one pass per instalment (one more per restart)
+        // Two units per trip, the buffers alternating: copying the prefetched registers into the current ones at the
+        // end of an iteration would make the compiler wait for the prefetch right where it was issued.
+        // The prefetch is issued unconditionally (a unit past the end loads a clamped address and merges nothing):
+        // under a branch the compiler could not count it and would wait with vmcnt(0).
+        dynamic = !careful;
+        issue(u, p, nv);
+        bool flush = false, failed = false;
+        while (dynamic ? seg < W : u < units) {
+            if (!careful && sh.fail[0]) break;            // (fast attempt) some wave ran out of room: stop early
+            issue(u + 1, pn, nvn);
+            merge(p, nv, par);
+            issue(u + 2, p, nv);
+            merge(pn, nvn, par);
+            u += 2;
+            KTA_PHASE(1, 3);
+            if (careful && u % chunks == 0u && u < units) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
+                if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
+                claimed = 0;
+                lds_barrier();
+                tot_occ += sh.occ[par];
+                tot_ovf += sh.ovf_n[par];
+                failed = sh.fail[par] != 0u;
+                if (threadIdx.x == 0) sh.occ[(par + 2u) % 3u] = sh.ovf_n[(par + 2u) % 3u] = 0;
+                par = (par + 1u) % 3u;
+                // empty the table when the next interval, growing like the last one, would take it past kFlushAt
+                const uint32_t grew = tot_occ - last_occ;
+                last_occ = tot_occ;
+                flush = tot_occ + grew + grew / 4 > kFlushAt || tot_ovf > kOvf / 2;
+                KTA_PHASE(1, 4);
+                if (failed || flush) break;
             }
         }
-    };
-    // After a group of segments (every wave has finished one segment): has the table to be emptied?  In bitmap
-    // state only here, between two groups: everything merged so far is older than everything that follows.
-    uint32_t inst_start = 0;                            // first segment of the current instalment
-    auto checkpoint = [&](uint32_t u) __attribute__((always_inline)) -> bool {         // false: the bucket is given up (bitmap state)
+        if (dynamic && !flush) u = units;                // (segments were handed out: every wave counted its own units)
+        if (!failed && !flush) {                         // the last units are in: did everything fit?
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
-        if (lane == 0 && claimed) atomicAdd(&sh.occ, claimed);
-        claimed = 0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // flush when the next group, growing like the last one, would take the table past kFlushAt
-            const uint32_t grew = sh.occ - sh.growth;
-            sh.growth = sh.occ;
-            const bool more = u + 1 < units;
-            const bool full = sh.occ + grew + grew / 4 > kFlushAt || sh.ovf_n > kOvf / 2;
-            sh.decision = (sh.fail ? 2u : 0u) | (more && full ? 1u : 0u);
+            for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
+            if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
+            claimed = 0;
+            lds_barrier();
+            failed = (sh.fail[0] | sh.fail[1] | sh.fail[2]) != 0u;
         }
-        __syncthreads();
-        const uint32_t d = sh.decision;
-        if (d & 2u) return false;
-        if (d & 1u) {
-            end_instalment();
-            inst_start = ((u + 1) / chunks) * kApplyWaves;
+        if (failed) {
+            if (careful) {
+                if (BITMAP) {                            // handed to kta_alive_fallback from this instalment on
+                    if (threadIdx.x == 0) {
+                        fail_from[b] = inst_start;
+                        atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
+                    }
+                    return;
+                }
+                // (table state never fails in careful mode: its last resort is the direct path)
+            } else {                                     // the fast attempt did not fit: start over, carefully
+                lds_barrier();                           // everybody has seen the verdict
+                for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + 2 * kOvf; e += kApplyThreads) s_val[e] = 0u;
+                if (threadIdx.x == 0) {
+                    sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = sh.fail[0] = sh.fail[1] = sh.fail[2] = 0;
+                    sh.any_ovf = 0;
+                    pool_ctl[POOL_DENSE] = 1ull;
+                }
+                {
+                    mq = 0;
+                }
+                careful = true;
+                u = 0;
+                lds_barrier();
+                continue;
+            }
         }
-        return true;
-    };
-    // Two units per trip, the buffers alternating: copying the prefetched registers into the current ones at the
-    // end of an iteration would make the compiler wait for the prefetch right where it was issued.
-    // The prefetch is issued unconditionally (a unit past the end loads a clamped address and merges nothing):
-    // under a branch the compiler could not count it and would wait with vmcnt(0).
-    bool ok = true;
-    for (uint32_t u = 0; u < units && ok; u += 2) {
-        issue(u + 1, pn, nvn);
-        merge(p, nv);
-        if ((u + 1) % chunks == 0u) ok = checkpoint(u);
-        if (!ok) break;
-        issue(u + 2, p, nv);
-        merge(pn, nvn);
-        if (u + 1 < units && (u + 2) % chunks == 0u) ok = checkpoint(u + 1);
+        KTA_PHASE(1, 1);
+        end_instalment();                                // (the one call site: the sweep is long)
+        if (u >= units) break;
+        inst_start = (u / chunks) * kApplyWaves;
+        tot_occ = tot_ovf = last_occ = 0;
     }
-    if (BITMAP && !ok) {                                // handed to kta_alive_fallback from this instalment on
-        if (threadIdx.x == 0) {
-            fail_from[b] = inst_start;
-            atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
-        }
-        return;
-    }
-    KTA_PHASE(1, 1);
-    end_instalment();
     add_running(delta, running, sh.w);
     // what the host's choice of kernel for the NEXT batch feeds on: pairs read, entries claimed (one per
     // distinct slot and instalment) — their ratio says how much of the batch died in LDS
     if (stats && threadIdx.x == 0) {
         atomicAdd(&stats[0], (unsigned long long)sh.pairs);
         atomicAdd(&stats[1], (unsigned long long)sh.claims);
+#ifdef KTA_ALIVE_PHASES
+        atomicAdd(&stats[2], (unsigned long long)sh.instalments);
+        atomicAdd(&stats[3], (unsigned long long)sh.ovf_total);
+#endif
     }
     KTA_PHASE(1, 2);
 }
@@ -808,6 +1021,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_pool_direct(const unsigned long
     long long delta = 0;
     for (unsigned long long k = (unsigned long long)blockIdx.x * kWG + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * kWG) {
         const unsigned long long pr = pool[k];
+        if (pr == 0ull) continue;
         const uint64_t idx = (uint64_t)((uint32_t)pr >> 1) - 1u;
         const uint64_t s = seq_col ? seq_col[idx] : base_seq + idx;
         delta += direct_update(table, (uint32_t)(pr >> 32), ((unsigned long long)(s + 1) << 1) | (pr & 1ull));
@@ -853,7 +1067,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const unsign
         for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
             const unsigned long long pr = pool[k];
             const uint32_t hh = (uint32_t)(pr >> 32);
-            if ((hh >> RBITS) != b) continue;
+            if (pr == 0ull || (hh >> RBITS) != b) continue;
             const uint32_t h = hh & ((1u << RBITS) - 1u);
             if (h / kSub == r) atomicMax(&s_max[h % kSub], (uint32_t)pr);
         }
@@ -941,8 +1155,8 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                        ws.counts, pl.cap, pool, ctl, hist);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds2 = (size_t)kEntries * 6 + (size_t)kSets * 4 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
-                        (bitmap ? (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8 : 0);
+    const size_t lds2 = (size_t)kEntries * 6 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
+                        (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8;   // the slice area doubles as the waves' miss queues
     if (bitmap) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1003,7 +1217,7 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count)
     pl.cap = (uint32_t)((mean + mean / 8 + 48 + 127) & ~127ull);
     pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap;
     pl.count_words = (uint64_t)pl.segment_wgs << pl.bucket_log2;
-    pl.pool_words = n;
+    pl.pool_words = n + ((uint64_t)pl.segment_wgs << pl.bucket_log2);   // + one padding pair per segment tail
     pl.ctl_bytes = POOL_WORDS * 8 + ((size_t)4 << pl.bucket_log2) + 4;
     return pl;
 }

@@ -59,6 +59,8 @@ int main(int argc, char **argv)
     kta::AliveColumns c{kl, vl, ko, reinterpret_cast<const uint8_t *>(kb), nullptr};
     kta::AliveState st{table, bitmap, running};
     kta::AliveWorkspace ws{pairs, counts, pool, ctl, fail_from};
+    uint64_t *d_stats;
+    CK(hipMalloc(&d_stats, 32));
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 4; rep++) {
@@ -68,7 +70,8 @@ int main(int argc, char **argv)
 #endif
         CK(hipDeviceSynchronize());
         hipEventRecord(a);
-        CK(kta::launch_alive_partitioned(c, n, (uint64_t)rep * n, st, pl, ws, nullptr, 0));
+        CK(hipMemset(d_stats, 0, 32));
+        CK(kta::launch_alive_partitioned(c, n, (uint64_t)rep * n, st, pl, ws, d_stats, 0));
         hipEventRecord(b);
         CK(hipEventSynchronize(b));
         float ms;
@@ -80,13 +83,16 @@ int main(int argc, char **argv)
         long long alive;
         CK(hipMemcpy(&alive, running, 8, hipMemcpyDeviceToHost));
         CK(hipMemcpy(pc, ctl, 16, hipMemcpyDeviceToHost));
+        unsigned long long stt[4];
+        CK(hipMemcpy(stt, d_stats, 32, hipMemcpyDeviceToHost));
+        printf("   pairs %llu claims %llu instalments %llu list entries %llu\n", stt[0], stt[1], stt[2], stt[3]);
         const double w1 = pl.segment_wgs, w2 = (double)(1u << pl.bucket_log2);
         printf("rep %d: %.3f ms = %.1f G records/s  alive=%lld  pool pairs=%llu  buckets given to the fallback=%llu\n", rep, ms,
                n / ms / 1e6, alive, pc[0], pc[1]);
-        printf("   partition per workgroup (us, thread 0's wave): wait+hash %.1f  arrivals %.1f  tail %.1f\n",
-               ph[0] / w1 / 100, ph[4] / w1 / 100, ph[7] / w1 / 100);
-        printf("   apply per workgroup (us):     init %.1f  merge %.1f  end %.1f   (x %.0f workgroups / 256 CUs)\n",
-               ph[8] / w2 / 100, ph[9] / w2 / 100, ph[10] / w2 / 100, w2);
+        printf("   partition per workgroup (us, thread 0's wave): wait+hash %.1f  positions %.1f  inserts %.1f  queueing %.1f  write-out %.1f  ring wait %.1f  tail %.1f\n",
+               ph[0] / w1 / 100, ph[1] / w1 / 100, ph[2] / w1 / 100, ph[3] / w1 / 100, ph[5] / w1 / 100, ph[4] / w1 / 100, ph[7] / w1 / 100);
+        printf("   apply per workgroup (us):     init %.1f  loads+merge %.1f  checkpoints %.1f  rest %.1f  end %.1f   (x %.0f workgroups / 256 CUs)\n",
+               ph[8] / w2 / 100, ph[11] / w2 / 100, ph[12] / w2 / 100, ph[9] / w2 / 100, ph[10] / w2 / 100, w2);
     }
     return 0;
 }
