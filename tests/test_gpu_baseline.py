@@ -1,8 +1,13 @@
-"""Parity at the sizes BASELINE.json names (configs[1..3]), against the C oracle on the SAME records:
+"""Parity at the shapes BASELINE.json names (configs[0..4]), against the C oracle on the SAME records:
 
+    c1   1 partition, 1 M records, 64-byte keys, -c                    counters + alive count + all 2^32 bits, both
+                                                                       states of the alive set
     c2   8 partitions, 100 M records, mixed key / value sizes          counters + extrema, bit-exact
-    c3   64 partitions, 2^28 records, --count-alive-keys, 10 M keys    alive count + all 2^32 bits of the set
+    c3   64 partitions, 2^30 records, --count-alive-keys, 10 M keys    alive count + all 2^32 bits of the set
     c4   256 partitions, 2^30 records (one GPU's worth of config 4)    counters + extrema, bit-exact
+    c5   256 partitions, 2^26 records of config 5's key law (100 M     two partition-sharded ranks with seq columns
+         distinct keys, 50 % tombstones), -c                           + kta_exchange (RCCL test double): the
+                                                                       unsharded oracle's counters, count and bits
 
 The oracle is single-threaded like the reference (src/kafka.rs:92-135).  For the counter configs it runs as
 T independent instances over consecutive chunks of the topic (its state is sums and extrema, so the
@@ -88,17 +93,54 @@ def test_baseline_config_4_256_partitions_2e30_records():
     _check_counters("c4", 1 << 30, 256)
 
 
-def test_baseline_config_3_alive_keys_2e28_records():
+@pytest.mark.parametrize("state,variant", [("bitset", 3), ("table", 3), ("table", 13), ("table", 2)])
+def test_baseline_config_1_one_partition_1m_records_64_byte_keys(state, variant):
+    """BASELINE.json configs[0] through the GPU path with -c: 64-byte keys take the general-length hash path of the
+    partition kernel (fnv32_more behind the 16 prefetched bytes).  Bit set state, and the table state with the
+    automatic choice (3: a batch of 10^6 records takes the single-kernel update), the partitioned pass forced
+    (13) and the filtered kernel (2)."""
+    sp, n = kta.synth_preset("c1")
+    assert n == 1_000_000 and sp.n_partitions == 1
+    host = kta.synth_fill_host(sp, 0, n, with_keys=True)
+    assert int(host["key_len"].min()) == int(host["key_len"].max()) == 64
+    o = Oracle(NOW, True)
+    o.run_soa(host)
+    with kta.HipMetricHandler(1, count_alive_keys=True, now=NOW, alive_table=(state == "table")) as h:
+        h.set_tuning(alive_variant=variant)
+        b = h.device_batch_alloc(n, n * 64)
+        assert h.synth_fill_device(sp, 0, n, b) == n * 64
+        cut = 600_003                                 # two submissions, the second at an odd record offset
+        h.submit_device(b, cut, 0, which=2)
+        rest = kta.KtaBatch()
+        for f, sz in (("partition", 4), ("key_len", 4), ("val_len", 4), ("key_off", 4), ("ts_ms", 8)):
+            setattr(rest, f, getattr(b, f) + cut * sz)
+        rest.key_bytes = b.key_bytes
+        with pytest.raises(kta.KtaError):             # the metric columns must be 16-byte aligned ...
+            h.submit_device(rest, n - cut, cut)
+        h.submit_device(rest, n - cut, cut, which=2)  # ... the alive pass takes any common alignment
+        res, c = h.finish()
+        assert res.alive_keys == o.alive_keys() and res.alive_keys > 0
+        assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
+        h.device_batch_free(b)
+    # counters of the config, through a fresh context
+    with kta.HipMetricHandler(1, now=NOW) as h:
+        h.submit_columns(host["partition"], host["key_len"], host["val_len"], host["ts_ms"])
+        res, c = h.finish()
+        assert np.array_equal(c, o.counters(1)) and res.overall_count == n
+    o.close()
+
+
+def test_baseline_config_3_alive_keys_2e30_records():
     sp, _ = kta.synth_preset("c3")
-    n, P = 1 << 28, 64
+    n, P = 1 << 30, 64
     o = Oracle(NOW, True)
     # the oracle's BitSet consumes the topic in order; three generator threads run a few chunks ahead of it
     from concurrent.futures import ThreadPoolExecutor
     chunks = [(lo, min(CHUNK * 4, n - lo)) for lo in range(0, n, CHUNK * 4)]
-    pool = ThreadPoolExecutor(3)
-    ahead = [pool.submit(kta.synth_fill_host, sp, lo, m, True) for lo, m in chunks[:4]]
+    pool = ThreadPoolExecutor(6)
+    ahead = [pool.submit(kta.synth_fill_host, sp, lo, m, True) for lo, m in chunks[:8]]
     with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
-        slice_n = 1 << 26                      # one device batch at a time: 2^26 records, 1 GiB of keys
+        slice_n = 1 << 27                      # one device batch at a time: 2^27 records, 2 GiB of keys (key_off is u32)
         b = h.device_batch_alloc(slice_n, slice_n * 16)
         for lo in range(0, n, slice_n):
             assert h.synth_fill_device(sp, lo, slice_n, b) == slice_n * 16
@@ -106,8 +148,8 @@ def test_baseline_config_3_alive_keys_2e28_records():
             h.sync()
         for k in range(len(chunks)):
             cols = ahead.pop(0).result()
-            if k + 4 < len(chunks):
-                ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 4][0], chunks[k + 4][1], True))
+            if k + 8 < len(chunks):
+                ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 8][0], chunks[k + 8][1], True))
             o.run_soa(cols)
         pool.shutdown()
         res, c = h.finish()
@@ -116,3 +158,71 @@ def test_baseline_config_3_alive_keys_2e28_records():
         assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
         h.device_batch_free(b)
     o.close()
+
+
+_C5_WORKER = r'''
+import os, sys, threading
+root, log2n = sys.argv[1], int(sys.argv[2])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import kafka_topic_analyzer_amd as kta
+from helpers import NOW
+from oracle_c import Oracle
+sp, _ = kta.synth_preset("c5")
+P, n, nranks = int(sp.n_partitions), 1 << log2n, 2
+host = kta.synth_fill_host(sp, 0, n, with_keys=True, with_seq=True)
+assert int(host["key_len"].min()) == int(host["key_len"].max()) == 16 and np.array_equal(host["seq"], np.arange(n, dtype=np.uint64))
+o = Oracle(NOW, True); o.run_soa(host)
+keys = host["key_bytes"].reshape(n, 16)
+def shard_of(rank):       # partition p on rank p % nranks, every record with its GLOBAL sequence number
+    idx = np.nonzero(host["partition"] % nranks == rank)[0]
+    return {"partition": host["partition"][idx], "key_len": host["key_len"][idx], "val_len": host["val_len"][idx],
+            "ts_ms": host["ts_ms"][idx], "key_off": (np.arange(len(idx), dtype=np.uint64) * 16).astype(np.uint32),
+            "key_bytes": np.ascontiguousarray(keys[idx]).reshape(-1), "seq": host["seq"][idx]}
+uid = kta.HipMetricHandler.comm_unique_id()
+errors, stats = [], [None] * nranks
+def run(rank):
+    try:
+        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, seq_column=True)
+        h.comm_create(nranks, rank, uid)
+        sh = shard_of(rank)
+        assert len(sh["partition"]) >= 1 << 21          # large enough for the partitioned pass (seq column: order checked on the device)
+        b, nb = h.upload_batch(sh, with_keys=True)
+        h.submit_device(b, nb, 0)
+        h.exchange()
+        res, c = h.exchange_result()
+        assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
+        assert np.array_equal(c, o.counters(P)) and res.overall_count == n
+        lo, hi = -((-rank * (1 << 32)) // nranks), -((-(rank + 1) * (1 << 32)) // nranks)
+        words, want = h.export_alive_bitmap(), o.alive_words()
+        assert np.array_equal(words[(lo + 31) // 32:hi // 32], want[(lo + 31) // 32:hi // 32]), rank
+        stats[rank] = h.comm_info()
+        h.device_batch_free(b); h.comm_destroy(); h.close()
+    except BaseException as e:
+        errors.append((rank, repr(e)))
+        os._exit(2)
+ts = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errors, errors
+print("OK", o.alive_keys(), stats)
+'''
+
+
+def test_baseline_config_5_key_law_sharded_over_two_ranks_with_exchange(tmp_path):
+    """BASELINE.json configs[4]'s key law (100 M distinct 16-byte keys, 50 % tombstones, 256 partitions) at 2^26
+    records: two partition-sharded contexts on the one reachable GPU, each fed its partitions' records with a
+    seq column of GLOBAL sequence numbers (>= 2^21 records per rank: the partitioned pass with the device's order
+    check), then kta_exchange over tests/mock_rccl.cpp — every rank must hold the UNSHARDED oracle's counters and
+    alive count, and the oracle's BitSet on the hash range it owns."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "libmock_rccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(root, "tests", "mock_rccl.cpp"),
+                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    script = tmp_path / "w.py"
+    script.write_text(_C5_WORKER)
+    env = dict(os.environ, KTA_RCCL_LIBRARY=str(lib))
+    r = subprocess.run([sys.executable, str(script), root, "26"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
