@@ -40,20 +40,32 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB
 BYTES_PER_RECORD = 20        # partition i32 + key_len i32 + val_len i32 + ts_ms i64
 
 
-TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r02.sh, " \
-                 "not measured in this run)"
+TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r03.sh, " \
+                 "not measured in this run; null when the kernel's source file changed since those passes)"
+
+
+def _source_hash(rel):
+    """sha256 of a kernel source file as it lies in the tree (what tools/make_traffic.py recorded)."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def _traffic(kernels, records_per_launch):
-    """HBM bytes per launch, summed over `kernels`, from the committed PMC passes (profiles/traffic.json);
-    None when the file lacks one of the kernels at this launch size.  Replayed, not measured here: the
-    counters need their own rocprofv3 passes."""
+    """HBM bytes per launch, summed over `kernels`, from the committed PMC passes (profiles/traffic.json).
+    Replayed, not measured here: the counters need their own rocprofv3 passes.  None when the file lacks one of
+    the kernels at this launch size, or when the kernel's source file is not the one the passes were taken with
+    (every entry carries the file's hash): a changed kernel must not inherit an old number."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         total = 0
         for k in ([kernels] if isinstance(kernels, str) else kernels):
             e = table[k]
             if e["records_per_launch"] != records_per_launch:
+                return None
+            if not e.get("source_sha256_16") or e["source_sha256_16"] != _source_hash(e.get("source_file", "")):
                 return None
             total += e["hbm_bytes_per_launch"]
         return total
@@ -98,15 +110,15 @@ def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
 
 
 def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
-    """The --count-alive-keys pass (FNV + last-writer table) on the config-3 shape."""
+    """The --count-alive-keys pass (FNV + the reference's bit set) on the config-3 shape.  The batch is as large as
+    the ABI takes with 16-byte keys (key_off is a u32: < 4 GiB of key bytes): the bit set's 512 MiB are streamed
+    through LDS once per batch, whatever its size."""
     from oracle_c import Oracle
     spec, _ = kta.synth_preset("c3")
     h = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
     b = h.device_batch_alloc(n_records, n_records * 16)
     kb = h.synth_fill_device(spec, 0, n_records, b)
-    # Every pass presents the records with LATER sequence numbers than the table holds (a topic keeps
-    # growing): replaying identical sequence numbers would let the pre-read of the default kernel skip
-    # every record after the first pass.
+    # (bit set state: batches are applied in submission order, the base sequence number is not looked at)
     for k in range(warmup):
         h.submit_device(b, n_records, k * n_records, which=2)
     h.sync()
@@ -131,10 +143,11 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
                         "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
                         "traffic": _traffic(["kta_alive_partition", "kta_alive_apply"], n_records),
                         "traffic_source": TRAFFIC_SOURCE,
-                        "note": "kernel_ms is the HIP-event time of the PAIR of kernels of one batch (hash + partition, "
-                                "then per-bucket merge + table update); the 8 bytes per record of partitioned pairs "
-                                "written and read back, and the reads / partial writes of the 32 GiB last-writer table, "
-                                "are traffic, not algorithmic bytes"}}
+                        "note": "kernel_ms is the HIP-event time of the kernels of one batch (hash + partition, then "
+                                "per-bucket merge + the bucket's region of the 512 MiB bit set streamed through LDS; "
+                                "the fallback kernel returns at once); the 8 bytes per record of partitioned pairs "
+                                "written and read back and the bit set's 2 x 512 MiB per batch are traffic, not "
+                                "algorithmic bytes"}}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)
     passes, t_total = 0, 0.0
@@ -330,6 +343,100 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     return rep
 
 
+def host_fed_report(kta, device, batches=24, log2_batch=22):
+    """PCIe-inclusive: kta_batch_acquire / kta_batch_submit over the pinned staging ring (the path a Rust
+    MetricHandler shim feeds), the batches' contents left in place between submits so that the host does no work
+    but the submit itself: staging slab -> one H2D copy -> scan + fold (+ the alive pass).  Never `value`."""
+    from kafka_topic_analyzer_amd import _native as N
+    lib = N.load()
+    n = 1 << log2_batch
+    out = {}
+    for alive in (False, True):
+        sp, _ = kta.synth_preset("c3" if alive else "c4")
+        h = kta.HipMetricHandler(int(sp.n_partitions), count_alive_keys=alive, device=device, batch_capacity=n,
+                                 key_bytes_capacity=16 * n)
+        cols = kta.synth_fill_host(sp, 0, n, with_keys=alive)
+        stages = 2
+        for k in range(batches + stages):
+            if k == stages:
+                h.sync()
+                t0 = time.perf_counter()
+            b = N.KtaBatch()
+            h._check(lib.kta_batch_acquire(h._ctx, C.byref(b)))
+            if k < stages:      # fill each staging batch once; afterwards only the submit is timed
+                for name in ("partition", "key_len", "val_len", "ts_ms"):
+                    C.memmove(getattr(b, name), cols[name].ctypes.data, cols[name].nbytes)
+                if alive:
+                    C.memmove(b.key_off, cols["key_off"].ctypes.data, cols["key_off"].nbytes)
+                    C.memmove(b.key_bytes, cols["key_bytes"].ctypes.data, cols["key_bytes"].nbytes)
+            h._check(lib.kta_batch_submit(h._ctx, n, cols["n_key_bytes"] if alive else 0, k * n))
+        h.sync()
+        dt = time.perf_counter() - t0
+        res, _ = h.finish()
+        assert res.overall_count == (batches + stages) * n
+        per = (20 + (4 + 16 if alive else 0)) * n
+        out["count_alive_keys" if alive else "metrics"] = {
+            "workload": ("c3 shape, 16 B keys, -c" if alive else "c4") + f": {batches} staging batches of 2^{log2_batch} records",
+            "records": batches * n, "bytes_over_pcie": batches * per, "ms": dt * 1e3,
+            "records_per_s": batches * n / dt, "GBps_over_pcie": batches * per / dt / 1e9}
+        h.close()
+    return out
+
+
+def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
+    """PCIe-inclusive, the step before the path included: raw Kafka v2 record batches (what a Fetch response or a
+    broker *.log segment holds) in the pinned blobs of kta_kafka_blob_acquire / submit -> header index on the host
+    -> H2D -> decode kernel -> scan + fold (-> alive pass).  The blobs are filled once and resubmitted, so the host
+    does what a fetcher that writes straight into the blobs would do: index and submit.  Never `value`."""
+    import numpy as np
+    from kafka_topic_analyzer_amd import _native as N
+    lib = N.load()
+    spec, _ = kta.synth_preset("c4")
+    rpb = 60
+    ln = C.c_uint64()
+    lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n_records, rpb, None, 0, C.byref(ln))
+    buf = np.zeros(ln.value + 64, np.uint8)
+    lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n_records, rpb, buf.ctypes.data, ln.value, C.byref(ln))
+    out = {}
+    for alive in (False, True):
+        h = kta.HipMetricHandler(256, count_alive_keys=alive, device=device)
+        h._check(lib.kta_kafka_configure(h._ctx, 0, 3))
+        filled, sizes, recs = 0, [], []
+        total_bytes = total_recs = 0
+        stages, at, k = 3, 0, 0
+        t0 = None
+        for k in range(stages + passes * stages):
+            if k == stages:
+                h.sync()
+                t0 = time.perf_counter()
+            ptr, cap = C.c_void_p(), C.c_uint64()
+            h._check(lib.kta_kafka_blob_acquire(h._ctx, C.byref(ptr), C.byref(cap)))
+            if k < stages:      # fill each pinned blob once with the next stretch of the log
+                take = min(cap.value, ln.value - at)
+                C.memmove(ptr, buf.ctypes.data + at, take)
+                sizes.append(take)
+            st = N.KtaKafkaIndexStats()
+            h._check(lib.kta_kafka_blob_submit(h._ctx, sizes[k % stages], k % 256, C.byref(st)))
+            if k < stages:
+                sizes[k] = st.bytes_consumed          # whole batches only; the next blob starts at the tail
+                recs.append(st.n_records)
+                at += st.bytes_consumed
+            else:
+                total_bytes += st.bytes_consumed
+                total_recs += st.n_records
+        h.sync()
+        dt = time.perf_counter() - t0
+        res, _ = h.finish(allow_bad_partition=True)
+        assert res.overall_count == sum(recs) * (passes + 1)
+        out["count_alive_keys" if alive else "metrics"] = {
+            "workload": f"c4 records as v2 record batches of {rpb} (~16 KiB), uncompressed; {passes * stages} pinned blobs of "
+                        f"{sizes[0]} bytes resubmitted" + (", -c (keys zero-copy from the blob)" if alive else ""),
+            "records": total_recs, "raw_log_bytes": total_bytes, "ms": dt * 1e3,
+            "records_per_s": total_recs / dt, "raw_log_GBps": total_bytes / dt / 1e9}
+        h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,12 +447,23 @@ def main():
     ap.add_argument("--records-per-gpu", type=int, default=1 << 30,
                     help="records resident per GPU (default 2^30 = 1.07 B: BASELINE config 4's 1 B-record "
                          "256-partition topic fits one MI355X: 21.5 GB of 288 GB)")
+    ap.add_argument("--config", choices=["c4", "c5"], default="c4",
+                    help="c4 (default, the headline): 256-partition topic, metrics handler; c5: config 5's key law "
+                         "(100 M distinct 16-byte keys, 50 %% tombstones, 256 partitions) with --count-alive-keys: both "
+                         "handlers per step and, for N > 1 (or KTA_BENCH_FORCE_COLLECTIVES=1), the whole kta_exchange "
+                         "(hash-range exchange of the alive entries + the counter all-reduces)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --records-per-gpu on every rank; strong: that many records in TOTAL, "
+                         "1/N of them per rank (config 4 as stated: 1 B records over 8 GPUs)")
     ap.add_argument("--part-mode", choices=["random", "runs"], default="random",
                     help="partition interleaving of the synthetic topic (random = worst case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alive", action="store_true", help="skip the --count-alive-keys sub-benchmark")
-    ap.add_argument("--alive-records", type=int, default=1 << 26)
+    ap.add_argument("--alive-records", type=int, default=15 << 24,
+                    help="records per batch of the alive-key pass (default 15 x 2^24: 3.75 GiB of 16-byte keys, the most a "
+                         "batch's u32 key offsets address)")
     ap.add_argument("--no-decode", action="store_true", help="skip the Kafka record-batch decode sub-benchmark")
+    ap.add_argument("--no-hostfed", action="store_true", help="skip the PCIe-inclusive legs (host_fed, raw_log_e2e)")
     ap.add_argument("--decode-records", type=int, default=4_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -382,13 +500,19 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     P = 256
+    c5 = args.config == "c5"
     n = args.records_per_gpu
-    spec, _ = kta.synth_preset("c4")
+    if c5:
+        n = min(n, 15 << 24)                               # 16-byte keys: a batch's u32 key offsets address < 4 GiB
+    if args.scaling == "strong":
+        n //= world
+    spec, _ = kta.synth_preset(args.config)
     spec = D.shard_spec(spec, rank, world)                 # partition p -> rank p % world
     if args.part_mode == "runs":
         spec.part_mode, spec.part_run_len = N.KTA_PART_RUNS, 500
-    h = kta.HipMetricHandler(P, device=local_rank)
-    batch = h.device_batch_alloc(n)
+    # c5: a rank of a sharded -c run keeps the sequence-numbered table (global sequence numbers across ranks)
+    h = kta.HipMetricHandler(P, count_alive_keys=c5, device=local_rank, alive_table=c5)
+    batch = h.device_batch_alloc(n, n * 16 if c5 else 0)
     h.synth_fill_device(spec, rank * n, n, batch)          # rank-disjoint record index ranges
     h.sync()
 
@@ -407,12 +531,21 @@ def main():
             os.environ["KTA_COMM_FORCE_RCCL"] = "1"        # forced mode: a real one-rank communicator
         h.comm_create(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
+    passes = [0]
+
     def step():
-        """One whole job: fresh state, scan + fold of the resident shard, cross-GPU exchange."""
-        h.reset()                                          # MessageMetrics::new state (tiny kernel)
-        h.submit_device(batch, n, 0, which=1)              # scan + fold
+        """c4: one whole job — fresh state, scan + fold of the resident shard, cross-GPU exchange.
+        c5: one more batch of the job — both handlers over the resident shard, every pass with later global sequence
+        numbers than the table holds (the topic keeps growing; the state is NOT reset: clearing the 32 GiB table
+        is no part of a batch), then the whole exchange: alive entries to their hash-range owners + all-reduces."""
+        if c5:
+            h.submit_device(batch, n, (passes[0] * world + rank) * n, which=3)
+            passes[0] += 1
+        else:
+            h.reset()                                      # MessageMetrics::new state (tiny kernel)
+            h.submit_device(batch, n, 0, which=1)          # scan + fold
         if exchange:
-            h.exchange()                                   # snapshot + C1 SUM (counters) + C2 MAX (four extrema), same stream
+            h.exchange()                                   # snapshot + [c5: alive entries] + C1 SUM (counters) + C2 MAX (extrema), same stream
 
     def barrier():
         if exchange:
@@ -443,15 +576,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    alive_total = None
     if exchange:
         # the exchange result itself: after one more step every rank must hold the whole job's totals
         step()
         barrier()
         xres, xc = h.exchange_result()
         got = int(xc[:, N.KTA_C_TOTAL].sum())
-        assert got == n * world == xres.overall_count, "exchange step lost records: %d != %d" % (got, n * world)
+        want = n * world * (passes[0] if c5 else 1)
+        assert got == want == xres.overall_count, "exchange step lost records: %d != %d" % (got, want)
         assert (xc[:, N.KTA_C_TOTAL] > 0).all(), "a partition of another rank is missing from the exchanged result"
+        alive_total = int(xres.alive_keys) if c5 else None
+        assert not c5 or 0 < alive_total <= 100_000_000
         h.comm_destroy()
+    elif c5:
+        alive_total = int(h.finish()[0].alive_keys)
     # sanity inside the bench: a single fresh pass must count exactly n records on this rank
     h.reset()
     h.submit_device(batch, n, 0, which=1)
@@ -468,33 +607,50 @@ def main():
         line = {
             "metric": METRIC, "value": total_records / elapsed, "unit": "records/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "preroll_steps": args.preroll, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "c4: 256-partition synthetic topic, mixed key/value sizes (mean record "
-                                   "~256 B), partitions sharded p % n_gpus", "records_per_gpu": n,
+            "config": {"workload": ("c5: 256-partition log-compacted topic, 100 M distinct 16-byte keys, 50 % tombstones, "
+                                    "--count-alive-keys (both handlers + the alive-set exchange), partitions sharded p % n_gpus"
+                                    if c5 else
+                                    "c4: 256-partition synthetic topic, mixed key/value sizes (mean record "
+                                    "~256 B), partitions sharded p % n_gpus"), "records_per_gpu": n,
                        "total_records_per_step": n * world, "partitions": P, "partition_order": args.part_mode,
                        "bytes_per_record": BYTES_PER_RECORD, "parallelism": f"partition-sharded x{world}",
                        "forced_collectives": bool(force_coll),
                        "exchange": "none (1 GPU)" if not exchange else
-                                   "per step: kta_exchange = one grouped RCCL launch of all-reduce SUM u64[%d] + all-reduce "
+                                   ("per step: kta_exchange = alive entries to their hash-range owners (count all-gather, "
+                                    "grouped ncclSend / ncclRecv, owner merge + range count), then " if c5 else "per step: kta_exchange = ") +
+                                   "one grouped RCCL launch of all-reduce SUM u64[%d] + all-reduce "
                                    "MAX i64[4] on the compute stream (csrc/kta_comm.hip)" % n_sum},
             "roofline": {"bound": "hbm", "kernel": "kta_metrics_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE,
                          "bytes_per_launch": BYTES_PER_RECORD * n, "kernel_ms": scan_ms, "launches": int(cnt[0]),
                          "fold_kernel_ms": avg_ms[1], "frac_of_measured_achievable_6290": achieved / 6290.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if c5:
+            alive_ms = avg_ms[2]
+            algo = (12 + 16) * n
+            line["alive_pass"] = {"alive_keys": alive_total, "kernel_ms": alive_ms, "launches": int(cnt[2]),
+                                  "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply (table state)",
+                                               "achieved": algo / (alive_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": algo / (alive_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "bytes_per_launch": algo, "traffic": None}}
+        if world == 1 and not args.no_cpu_baseline and not c5:
             line["cpu_baseline"] = cpu_baseline_metrics(h, batch, min(n, 1 << 26), P, args.cpu_seconds)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     h.device_batch_free(batch)
     h.close()
     if rank == 0:
-        if world == 1 and not args.no_alive:
+        if world == 1 and not args.no_alive and not c5:
             line["alive_pass"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                    args.alive_records, args.cpu_seconds)
-        if world == 1 and not args.no_decode:
+        if world == 1 and not args.no_decode and not c5:
             line["kafka_decode"] = kafka_decode_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                        args.decode_records, args.cpu_seconds)
+        if world == 1 and not args.no_hostfed and not c5:
+            # PCIe-inclusive legs (the link is the bound: never `value`)
+            line["host_fed"] = host_fed_report(kta, local_rank)
+            line["raw_log_e2e"] = raw_log_e2e_report(kta, local_rank)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if exchange:

@@ -225,8 +225,11 @@ int kta_sync(kta_ctx *ctx);
  * Non-destructive: more batches may follow and kta_finish may be called again. */
 int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out);
 /* Device pointer and length (in u64) of the SNAPSHOT of the counter vector that kta_finish_device
- * takes: collectives may reduce it in place, the live accumulator is never touched (so kta_finish and
- * further batches after an exchange stay correct). */
+ * takes: collectives may reduce it in place, the live accumulator is never touched, so the counters of
+ * kta_finish and of further batches after an exchange stay correct.  One exception, -c after an exchange with
+ * nranks > 1: the exchange merges other ranks' entries of this rank's hash range INTO this rank's table, so the
+ * `alive_keys` of a later kta_finish on this context is neither the rank's own count nor the job's — read the
+ * job's count from kta_exchange_result (every exchange recomputes it). */
 int kta_result_vector(kta_ctx *ctx, void **device_ptr, size_t *n_u64);
 /* As kta_finish but leaves the snapshot on the device (no D2H, asynchronous). */
 int kta_finish_device(kta_ctx *ctx);
@@ -243,6 +246,11 @@ int kta_finish_device(kta_ctx *ctx);
  *                       [ceil(r 2^32 / R), ceil((r+1) 2^32 / R)); one grouped ncclSend / ncclRecv), the
  *                       owner merges by last writer and counts its range; then ONE grouped launch of
  *                       all-reduce SUM over vec[0 : P*7+4] and all-reduce MAX over vec[P*7+4 : P*7+8]
+ *                       What a rank sends is found through the list of slots the context wrote for the first
+ *                       time (4 bytes per distinct key hash), not by sweeping the 32 GiB table; the one host
+ *                       synchronisation of the step is for the sizes of the sends.  A rank that fails locally
+ *                       aborts its communicator (ncclCommAbort), so that its peers get an error instead of
+ *                       waiting in their collectives; the context's communicator is unusable afterwards.
  *   kta_exchange_result the decoded snapshot: after kta_exchange the whole job's result on every rank
  * RCCL is bound at run time (KTA_RCCL_LIBRARY, /opt/rocm/lib/librccl.so.1). */
 #define KTA_COMM_ID_BYTES 128

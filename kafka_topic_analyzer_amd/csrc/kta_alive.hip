@@ -133,11 +133,12 @@ __device__ __forceinline__ uint32_t fnv32_prefetched(const uint4 &k16, const uin
 }
 
 // The direct path of the table state: what kta_alive_update_filtered does for one record.
-__device__ __forceinline__ long long direct_update(unsigned long long *table, uint32_t h, unsigned long long v)
+__device__ __forceinline__ long long direct_update(unsigned long long *table, uint32_t h, unsigned long long v, const WrittenList &wl)
 {
     const unsigned long long seen = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen >= v) return 0;
     const unsigned long long old = atomicMax(&table[h], v);
+    note_new_slot(wl, old == 0ull, h);
     return v > old ? (long long)(v & 1ull) - (long long)(old & 1ull) : 0;
 }
 
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                                                                  const uint32_t *__restrict__ pool_hist,
                                                                  uint32_t *__restrict__ fail_from,
                                                                  unsigned long long *__restrict__ pool_ctl,
-                                                                 const uint32_t *__restrict__ skip_flag)
+                                                                 const uint32_t *__restrict__ skip_flag, WrittenList wl)
 {
     constexpr uint32_t RBITS = 32 - BLOG2;             // hash bits below the bucket
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
@@ -739,13 +740,14 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 for (int u = 0; u < 4; u++)
                     if (tg[u] && v[u] > old[u]) {
                         __hip_atomic_store(&table[slot[u]], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        note_new_slot(wl, old[u] == 0ull, slot[u]);
                         delta += (long long)(v[u] & 1ull) - (long long)(old[u] & 1ull);
                     }
             }
             lds_barrier();
             for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
                 const unsigned long long pr = s_ovf[k];
-                if (pr) delta += direct_update(table, (b << RBITS) | ((uint32_t)(pr >> 32) - 1u), global_val((uint32_t)pr));
+                if (pr) delta += direct_update(table, (b << RBITS) | ((uint32_t)(pr >> 32) - 1u), global_val((uint32_t)pr), wl);
             }
         }
         for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) s_ovf[k] = 0ull;
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
         if (!placed) {
             if (BITMAP || !careful) sh.fail[par] = 1u;
-            else delta += direct_update(table, (b << RBITS) | h, global_val(lo));
+            else delta += direct_update(table, (b << RBITS) | h, global_val(lo), wl);
         }
     };
     // Pairs whose slot has an entry (most of a compacted topic's) are merged where they stand: one lookup, one
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_pool_direct(const unsigned long
                                                              uint64_t base_seq, const uint64_t *__restrict__ seq_col,
                                                              unsigned long long *__restrict__ table,
                                                              long long *__restrict__ running,
-                                                             const uint32_t *__restrict__ skip_flag)
+                                                             const uint32_t *__restrict__ skip_flag, WrittenList wl)
 {
     __shared__ long long s_w[kWG / 64];
     const unsigned long long n = pool_ctl[POOL_CURSOR];
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_pool_direct(const unsigned long
         if (pr == 0ull) continue;
         const uint64_t idx = (uint64_t)((uint32_t)pr >> 1) - 1u;
         const uint64_t s = seq_col ? seq_col[idx] : base_seq + idx;
-        delta += direct_update(table, (uint32_t)(pr >> 32), ((unsigned long long)(s + 1) << 1) | (pr & 1ull));
+        delta += direct_update(table, (uint32_t)(pr >> 32), ((unsigned long long)(s + 1) << 1) | (pr & 1ull), wl);
     }
     add_running(delta, running, s_w);
 }
@@ -1163,7 +1165,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
                            pl.segment_wgs, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
-                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, skip);
+                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, skip, WrittenList{nullptr, nullptr, 0});
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         const size_t lds3 = (size_t)4 << 15;
@@ -1179,10 +1181,10 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
         hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
                            pl.segment_wgs, base_seq, c.seq, t, (uint32_t *)nullptr, run,
-                           reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip);
+                           reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip, st.written);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip);
+        hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip, st.written);
     }
     return hipGetLastError();
 }

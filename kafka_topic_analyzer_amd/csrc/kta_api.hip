@@ -59,6 +59,11 @@ struct kta_ctx {
     uint64_t *d_table = nullptr;
     int64_t *d_alive_running = nullptr; // running alive count
     bool running_valid = true;          // false once an update ran without counting
+    // table state: the slots ever written (what the exchange exports); invalid once somebody else wrote the table
+    uint32_t *d_written = nullptr;
+    unsigned long long *d_written_n = nullptr;
+    uint64_t written_cap = 0;
+    bool written_valid = true;
     uint32_t *d_exp_slots = nullptr;    // kta_alive_export_entries buffers
     uint64_t *d_exp_vals = nullptr, *d_exp_count = nullptr;
     uint64_t exp_cap = 0;
@@ -193,6 +198,8 @@ int timer_pair(kta_ctx *ctx, int k, hipEvent_t *a, hipEvent_t *b)
     return KTA_OK;
 }
 
+kta::WrittenList written_list(kta_ctx *ctx) { return kta::WrittenList{ctx->d_written, ctx->d_written_n, ctx->written_cap}; }
+
 // Launch the handlers over device-resident columns on the compute stream.
 int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base_seq, int which)
 {
@@ -301,14 +308,14 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes,
                                      ctx->alive_table && c->seq ? c->seq + at : nullptr};
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,
-                                   ctx->d_alive_running};
+                                   ctx->d_alive_running, written_list(ctx)};
                 kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from};
                 KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws,
                                                            report ? ctx->d_alive_stats : nullptr, ctx->s_compute));
                 if (sl.seq)   // the batch's seq column did not ascend: the pair did nothing, this runs instead
                     KTA_HIP(ctx, kta::launch_alive_update(sl, take, base_seq + at, ctx->d_table, 0, 2, nullptr,
                                                           ctx->d_alive_running, ctx->s_compute,
-                                                          kta::alive_order_flag(ws, (int)pl.bucket_log2)));
+                                                          kta::alive_order_flag(ws, (int)pl.bucket_log2), written_list(ctx)));
                 at += take;
             }
             if (report) {
@@ -320,7 +327,8 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         } else {
             const int v = part_kind ? 2 : ctx->alive_variant;
             KTA_HIP(ctx, kta::launch_alive_update(ac, n, base_seq, ctx->d_table, ctx->alive_wgs > 2048 ? 0 : ctx->alive_wgs,
-                                                  v, ctx->d_hash_scratch, ctx->d_alive_running, ctx->s_compute, nullptr));
+                                                  v, ctx->d_hash_scratch, ctx->d_alive_running, ctx->s_compute, nullptr,
+                                                  written_list(ctx)));
         }
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
@@ -331,8 +339,13 @@ int reset_state(kta_ctx *ctx)
 {
     KTA_HIP(ctx, kta::launch_init_vector(ctx->d_vec, ctx->P, ctx->d_avec, ctx->s_compute));
     if (ctx->alive) {
-        if (ctx->alive_table) KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
-        else KTA_HIP(ctx, hipMemsetAsync(ctx->d_bitmap, 0, (size_t)(kta::kAliveSlots / 8), ctx->s_compute));
+        if (ctx->alive_table) {
+            KTA_HIP(ctx, hipMemsetAsync(ctx->d_table, 0, kta::kAliveSlots * sizeof(uint64_t), ctx->s_compute));
+            KTA_HIP(ctx, hipMemsetAsync(ctx->d_written_n, 0, sizeof(unsigned long long), ctx->s_compute));
+            ctx->written_valid = true;
+        } else {
+            KTA_HIP(ctx, hipMemsetAsync(ctx->d_bitmap, 0, (size_t)(kta::kAliveSlots / 8), ctx->s_compute));
+        }
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
         ctx->running_valid = true;
     }
@@ -418,8 +431,14 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     if (ctx->analytics)
         KTA_TRY(hipMalloc((void **)&ctx->d_avec, (size_t)kta::analytics_len(ctx->P) * sizeof(uint64_t)));
     if (ctx->alive) {
-        if (ctx->alive_table) KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
-        else KTA_TRY(hipMalloc((void **)&ctx->d_bitmap, (size_t)(kta::kAliveSlots / 8)));
+        if (ctx->alive_table) {
+            KTA_TRY(hipMalloc((void **)&ctx->d_table, kta::kAliveSlots * sizeof(uint64_t)));
+            ctx->written_cap = 1ull << 28;                 // 1 GiB of slot numbers; beyond that the exchange sweeps the table
+            KTA_TRY(hipMalloc((void **)&ctx->d_written, ctx->written_cap * sizeof(uint32_t)));
+            KTA_TRY(hipMalloc((void **)&ctx->d_written_n, sizeof(unsigned long long)));
+        } else {
+            KTA_TRY(hipMalloc((void **)&ctx->d_bitmap, (size_t)(kta::kAliveSlots / 8)));
+        }
         KTA_TRY(hipMalloc((void **)&ctx->d_alive_running, sizeof(int64_t)));
     }
 #undef KTA_TRY
@@ -450,6 +469,8 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_avec) (void)hipFree(ctx->d_avec);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
     if (ctx->d_bitmap) (void)hipFree(ctx->d_bitmap);
+    if (ctx->d_written) (void)hipFree(ctx->d_written);
+    if (ctx->d_written_n) (void)hipFree(ctx->d_written_n);
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->d_pool_ctl) (void)hipFree(ctx->d_pool_ctl);
     if (ctx->d_fail_from) (void)hipFree(ctx->d_fail_from);
@@ -915,7 +936,7 @@ int kta_alive_import_entries(kta_ctx *ctx, const void *d_slots, const void *d_va
     int rc = kta_flush(ctx);
     if (rc != KTA_OK) return rc;
     KTA_HIP(ctx, kta::launch_alive_import(static_cast<const uint32_t *>(d_slots), static_cast<const uint64_t *>(d_vals),
-                                          n, ctx->d_table, ctx->d_alive_running, ctx->s_compute));
+                                          n, ctx->d_table, ctx->d_alive_running, written_list(ctx), ctx->s_compute));
     return KTA_OK;
 }
 
@@ -940,6 +961,7 @@ int kta_alive_table_modified(kta_ctx *ctx)
     if (!ctx) return KTA_ERR_INVALID;
     if (!ctx->alive) return fail(ctx, KTA_ERR_INVALID, "context was created without count_alive_keys");
     ctx->running_valid = false;  // the next kta_finish recounts from the table
+    ctx->written_valid = false;  // and the exchange sweeps it: somebody else wrote entries
     return KTA_OK;
 }
 
@@ -1021,6 +1043,11 @@ uint64_t *kta_internal_vec_out(kta_ctx *ctx) { return ctx->d_vec_out; }
 uint32_t kta_internal_partitions(kta_ctx *ctx) { return ctx->P; }
 uint64_t *kta_internal_table(kta_ctx *ctx) { return ctx->d_table; }
 bool kta_internal_alive_table(kta_ctx *ctx) { return ctx->alive_table; }
+bool kta_internal_written(kta_ctx *ctx, kta::WrittenList *out)
+{
+    *out = kta::WrittenList{ctx->d_written, ctx->d_written_n, ctx->written_cap};
+    return ctx->written_valid && ctx->d_written != nullptr;
+}
 int64_t *kta_internal_running(kta_ctx *ctx) { return ctx->d_alive_running; }
 uint64_t kta_internal_take_seq(kta_ctx *ctx, uint64_t n)
 {

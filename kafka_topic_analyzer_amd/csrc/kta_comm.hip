@@ -40,6 +40,7 @@ uint64_t *kta_internal_vec_out(kta_ctx *ctx);
 uint32_t kta_internal_partitions(kta_ctx *ctx);
 uint64_t *kta_internal_table(kta_ctx *ctx);
 int64_t *kta_internal_running(kta_ctx *ctx);
+bool kta_internal_written(kta_ctx *ctx, kta::WrittenList *out);
 
 namespace {
 
@@ -189,18 +190,39 @@ int grow(kta_ctx *ctx, uint32_t **slots, uint64_t **vals, uint64_t *cap, uint64_
 
 // The alive-set half of the exchange.  Leaves this rank's table merged for its own hash range and the
 // count of that range in the snapshot vector.
+//
+// What a rank sends is "the entries it ever wrote": the context keeps the list of slots it wrote for the first
+// time (WrittenList), so counting per owner, exporting per owner and counting the own range are passes over that
+// list (4 bytes per distinct key hash) with gathers from the table — not sweeps of the 32 GiB table, whose cost
+// would not depend on how few keys the rank saw.  The sweeps remain as the fallback for a list that overflowed or
+// a table somebody else wrote into (kta_alive_table_modified).  One host synchronisation remains in either form:
+// the sizes of the sends and receives have to be known to the host that issues them.
 int exchange_alive(kta_ctx *ctx, CommState *st)
 {
     Rccl *R = rccl();
     hipStream_t s = kta_internal_stream(ctx);
     uint64_t *table = kta_internal_table(ctx);
     const int n = st->nranks;
-    if (!st->d_counts) CH(ctx, hipMalloc((void **)&st->d_counts, (size_t)(n + n * n) * sizeof(uint64_t)));
+    if (!st->d_counts) CH(ctx, hipMalloc((void **)&st->d_counts, (size_t)(3 * n + n * n) * sizeof(uint64_t)));
     if (!st->d_scalar) CH(ctx, hipMalloc((void **)&st->d_scalar, sizeof(uint64_t)));
+    kta::WrittenList wl;
+    bool listed = kta_internal_written(ctx, &wl);
+    uint64_t *d_owner_at = st->d_counts + n + n * n, *d_cursors = d_owner_at + n;
     // 1. how many entries does this rank hold for every owner
     std::vector<uint64_t> send(n), matrix((size_t)n * n);
-    for (int r = 0; r < n; r++)
-        CH(ctx, kta::launch_alive_count_written_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_counts + r, s));
+    uint64_t n_written = 0;
+    if (listed) {
+        CH(ctx, hipMemcpyAsync(&n_written, wl.n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CH(ctx, hipStreamSynchronize(s));
+        listed = n_written <= wl.cap;                    // the list overflowed: sweep
+    }
+    if (listed) {
+        CH(ctx, hipMemsetAsync(st->d_counts, 0, (size_t)n * sizeof(uint64_t), s));
+        CH(ctx, kta::launch_written_count(wl, n_written, n, st->d_counts, s));
+    } else {
+        for (int r = 0; r < n; r++)
+            CH(ctx, kta::launch_alive_count_written_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_counts + r, s));
+    }
     CN(ctx, R->AllGather(st->d_counts, st->d_counts + n, (size_t)n, ncclUint64, st->comm, s));
     CH(ctx, hipMemcpyAsync(send.data(), st->d_counts, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CH(ctx, hipMemcpyAsync(matrix.data(), st->d_counts + n, (size_t)n * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -218,10 +240,20 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
     rc = grow(ctx, &st->d_recv_slots, &st->d_recv_vals, &st->recv_cap, recv_total);
     if (rc != KTA_OK) return rc;
     // 2. one contiguous list per owner (the rank's own range stays where it is)
-    for (int r = 0; r < n; r++) {
-        if (r == st->rank || send[r] == 0) continue;
-        CH(ctx, kta::launch_alive_export_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_send_slots + send_at[r],
-                                              st->d_send_vals + send_at[r], st->d_scalar, send[r], s));
+    if (listed) {
+        if (send_total) {
+            CH(ctx, hipMemcpyAsync(d_owner_at, send_at.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            CH(ctx, hipMemsetAsync(d_cursors, 0, (size_t)n * sizeof(uint64_t), s));
+            CH(ctx, kta::launch_written_export(wl, n_written, table, n, st->rank, d_owner_at, d_cursors, st->d_send_slots,
+                                               st->d_send_vals, s));
+            CH(ctx, hipStreamSynchronize(s));             // send_at (host memory) was the source of an async copy
+        }
+    } else {
+        for (int r = 0; r < n; r++) {
+            if (r == st->rank || send[r] == 0) continue;
+            CH(ctx, kta::launch_alive_export_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_send_slots + send_at[r],
+                                                  st->d_send_vals + send_at[r], st->d_scalar, send[r], s));
+        }
     }
     // 3. every list to its owner: one grouped launch, all links at once
     CN(ctx, R->GroupStart());
@@ -238,11 +270,16 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
         }
     }
     CN(ctx, R->GroupEnd());
-    // 4. the owner merges (last writer by global sequence number) and counts its range
+    // 4. the owner merges (last writer by global sequence number; new slots join its list) and counts its range
     if (recv_total)
-        CH(ctx, kta::launch_alive_import(st->d_recv_slots, st->d_recv_vals, recv_total, table, kta_internal_running(ctx), s));
+        CH(ctx, kta::launch_alive_import(st->d_recv_slots, st->d_recv_vals, recv_total, table, kta_internal_running(ctx), wl, s));
     uint64_t *dst = kta_internal_vec_out(ctx) + (size_t)kta_internal_partitions(ctx) * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
-    CH(ctx, kta::launch_alive_count_span(table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
+    if (listed && n_written + recv_total <= wl.cap) {
+        // (the list may have grown by the import: the kernel reads its length on the device, bounded by this sum)
+        CH(ctx, kta::launch_written_alive_count(wl, n_written + recv_total, table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
+    } else {
+        CH(ctx, kta::launch_alive_count_span(table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
+    }
     st->last_sent = send_total;
     st->last_received = recv_total;
     return KTA_OK;

@@ -32,6 +32,30 @@ struct AliveColumns {
     const uint64_t *seq; // may be null
 };
 
+// Table state: the slots this context ever wrote, in the order they were first written — what a rank exports in the
+// exchange instead of sweeping its 32 GiB table.  Every kernel that writes the table appends a slot when it finds the
+// entry 0 (never written).  n counts past cap when the list overflows (the exchange then sweeps the table).
+struct WrittenList {
+    uint32_t *slots;            // null: not tracked
+    unsigned long long *n;      // device counter
+    uint64_t cap;
+};
+
+#ifdef __HIPCC__
+// wave-aggregated append (works under divergence: the ballot covers the active lanes)
+__device__ __forceinline__ void note_new_slot(const WrittenList &wl, bool is_new, uint32_t slot)
+{
+    if (!wl.slots) return;
+    const unsigned long long m = __ballot(is_new);
+    if (m == 0ull) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    unsigned long long base = 0;
+    if (is_new && rank == 0u) base = atomicAdd(wl.n, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (is_new && base + rank < wl.cap) wl.slots[base + rank] = slot;
+}
+#endif
+
 struct ScanPlan {
     uint32_t workgroups;   // grid size
     uint32_t rep_log2;     // LDS replication of each partition's slots
@@ -68,7 +92,8 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *analytics_vec
 // (hash -> scratch, scratch -> table)
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
                                int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s,
-                               const uint32_t *only_if /* variant 2: device word, run only when non-zero; may be null */);
+                               const uint32_t *only_if /* variant 2: device word, run only when non-zero; may be null */,
+                               const WrittenList &written);
 // K2'+K3' (kta_alive.hip): the same update as two kernels — hash + partition the batch's (hash, index, alive)
 // pairs by the hash's top bits into workgroup-private segments, then one workgroup per bucket merges its
 // pairs in LDS and applies the survivors to the region of the persistent state it alone writes.  The state is
@@ -91,6 +116,7 @@ struct AliveState {
     uint64_t *table;        // u64[2^32], or null
     uint32_t *bitmap;       // u32[2^27] = 2^32 bits, or null (exactly one of the two)
     int64_t *running;       // running alive count
+    WrittenList written;    // table state: the slots ever written
 };
 struct AliveWorkspace {
     uint64_t *pairs;
@@ -118,7 +144,15 @@ hipError_t launch_alive_export_span(const uint64_t *table, uint64_t lo, uint64_t
                                     uint64_t *out_vals, uint64_t *counter, uint64_t cap, hipStream_t s);
 hipError_t launch_alive_count_written_span(const uint64_t *table, uint64_t lo, uint64_t hi, uint64_t *out, hipStream_t s);
 hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint64_t n, uint64_t *table,
-                               int64_t *running, hipStream_t s);
+                               int64_t *running, const WrittenList &written, hipStream_t s);
+// the exchange over the written list: entries per owner rank (owner(slot) = (slot * R) >> 32), their export as
+// one contiguous (slot, value) list per owner, and the alive count of one owner's range
+hipError_t launch_written_count(const WrittenList &wl, uint64_t n, int nranks, uint64_t *counts /* [nranks] += */, hipStream_t s);
+hipError_t launch_written_export(const WrittenList &wl, uint64_t n, const uint64_t *table, int nranks, int skip_rank,
+                                 const uint64_t *owner_at /* device [nranks] */, uint64_t *cursors /* device [nranks], zero */,
+                                 uint32_t *out_slots, uint64_t *out_vals, hipStream_t s);
+hipError_t launch_written_alive_count(const WrittenList &wl, uint64_t n, const uint64_t *table, uint64_t lo, uint64_t hi,
+                                      uint64_t *out /* = */, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)
 hipError_t launch_alive_bitmap(const uint64_t *table, uint64_t n_slots, uint32_t *bitmap, hipStream_t s);
 // hash only (tests)

@@ -551,7 +551,7 @@ __device__ __forceinline__ uint32_t fnv32_global(const uint8_t *k, uint32_t len)
 // number is the last writer in consumption order, which is exactly what sequential
 // BitSet insert/remove leaves behind (metric.rs:273-280, 291-303).  0 == never written.
 __global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t n, uint64_t base_seq,
-                                                        unsigned long long *__restrict__ table)
+                                                        unsigned long long *__restrict__ table, WrittenList wl)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kWG;
     for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t
         const uint32_t h = fnv32_global(c.key_bytes + c.key_off[i], (uint32_t)kl);
         const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
         const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
-        atomicMax(&table[h], v);
+        note_new_slot(wl, atomicMax(&table[h], v) == 0ull, h);
     }
 }
 
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_update(AliveColumns c, uint64_t
 // (metric.rs:282-284) without scanning the 32 GiB table.
 __global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c, uint64_t n, uint64_t base_seq,
                                                                  unsigned long long *__restrict__ table,
-                                                                 long long *__restrict__ running)
+                                                                 long long *__restrict__ running, WrittenList wl)
 {
     __shared__ long long s_w[kWG / 64];
     const uint64_t stride = (uint64_t)gridDim.x * kWG;
@@ -583,6 +583,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c,
         const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
         const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
         const unsigned long long old = atomicMax(&table[h], v);
+        note_new_slot(wl, old == 0ull, h);
         if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
     }
 #pragma unroll
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_update_counting(AliveColumns c,
 __global__ __launch_bounds__(kWG) void kta_alive_update_filtered(AliveColumns c, uint64_t n, uint64_t base_seq,
                                                                  unsigned long long *__restrict__ table,
                                                                  long long *__restrict__ running,
-                                                                 const uint32_t *__restrict__ only_if)
+                                                                 const uint32_t *__restrict__ only_if, WrittenList wl)
 {
     __shared__ long long s_w[kWG / 64];
     if (only_if && *only_if == 0u) return;   // stands in for the partitioned pass only when that gave the batch up
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_update_filtered(AliveColumns c,
         const unsigned long long seen = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen >= v) continue;
         const unsigned long long old = atomicMax(&table[h], v);
+        note_new_slot(wl, old == 0ull, h);
         if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
     }
 #pragma unroll
@@ -647,14 +649,14 @@ __global__ __launch_bounds__(kWG) void kta_alive_hash_only(AliveColumns c, uint6
 
 __global__ __launch_bounds__(kWG) void kta_alive_apply_only(AliveColumns c, uint64_t n, uint64_t base_seq,
                                                             const uint32_t *__restrict__ hin,
-                                                            unsigned long long *__restrict__ table)
+                                                            unsigned long long *__restrict__ table, WrittenList wl)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kWG;
     for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
         if (c.key_len[i] < 0) continue;
         const uint64_t s = c.seq ? c.seq[i] : base_seq + i;
         const unsigned long long v = ((unsigned long long)(s + 1) << 1) | (c.val_len[i] >= 0 ? 1ull : 0ull);
-        atomicMax(&table[hin[i]], v);
+        note_new_slot(wl, atomicMax(&table[hin[i]], v) == 0ull, hin[i]);
     }
 }
 
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_export(const unsigned long long
 __global__ __launch_bounds__(kWG) void kta_alive_import(const uint32_t *__restrict__ slots,
                                                         const unsigned long long *__restrict__ vals, uint64_t n,
                                                         unsigned long long *__restrict__ table,
-                                                        long long *__restrict__ running)
+                                                        long long *__restrict__ running, WrittenList wl)
 {
     __shared__ long long s_w[kWG / 64];
     const uint64_t stride = (uint64_t)gridDim.x * kWG;
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(kWG) void kta_alive_import(const uint32_t *__restri
         const unsigned long long v = vals[i];
         if (!v) continue;
         const unsigned long long old = atomicMax(&table[slots[i]], v);
+        note_new_slot(wl, old == 0ull, slots[i]);
         if (v > old) delta += (long long)(v & 1ull) - (long long)(old & 1ull);
     }
 #pragma unroll
@@ -917,7 +920,7 @@ hipError_t launch_init_vector(uint64_t *vec, uint32_t P, uint64_t *avec, hipStre
 
 hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_seq, uint64_t *table,
                                int workgroups, int variant, uint32_t *scratch, int64_t *running, hipStream_t s,
-                               const uint32_t *only_if)
+                               const uint32_t *only_if, const WrittenList &wl)
 {
     uint64_t wgs = (n + kWG - 1) / kWG;
     const uint64_t cap = workgroups > 0 ? (uint64_t)workgroups : 256ull * 8ull;
@@ -927,15 +930,15 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
     if (variant == 8 && scratch) {
         hipLaunchKernelGGL(kta_alive_hash_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, scratch);
     } else if (variant == 9 && scratch) {
-        hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t);
+        hipLaunchKernelGGL(kta_alive_apply_only, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, scratch, t, wl);
     } else if (variant == 2 && running) {
         hipLaunchKernelGGL(kta_alive_update_filtered, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
-                           reinterpret_cast<long long *>(running), only_if);
+                           reinterpret_cast<long long *>(running), only_if, wl);
     } else if (variant == 1 && running) {
         hipLaunchKernelGGL(kta_alive_update_counting, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t,
-                           reinterpret_cast<long long *>(running));
+                           reinterpret_cast<long long *>(running), wl);
     } else {
-        hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t);
+        hipLaunchKernelGGL(kta_alive_update, dim3((uint32_t)wgs), dim3(kWG), 0, s, c, n, base_seq, t, wl);
     }
     return hipGetLastError();
 }
@@ -998,14 +1001,123 @@ hipError_t launch_alive_export_span(const uint64_t *table, uint64_t lo, uint64_t
 }
 
 hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint64_t n, uint64_t *table,
-                               int64_t *running, hipStream_t s)
+                               int64_t *running, const WrittenList &wl, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     uint64_t wgs = (n + kWG - 1) / kWG;
     if (wgs > 256 * 8) wgs = 256 * 8;
     hipLaunchKernelGGL(kta_alive_import, dim3((uint32_t)wgs), dim3(kWG), 0, s, slots,
                        reinterpret_cast<const unsigned long long *>(vals), n,
-                       reinterpret_cast<unsigned long long *>(table), reinterpret_cast<long long *>(running));
+                       reinterpret_cast<unsigned long long *>(table), reinterpret_cast<long long *>(running), wl);
+    return hipGetLastError();
+}
+
+// ---- the exchange over the written list -----------------------------------------------------------------
+constexpr int kMaxOwners = 64;
+
+__global__ __launch_bounds__(kWG) void kta_written_count(WrittenList wl, uint64_t n, uint32_t nranks, unsigned long long *counts)
+{
+    __shared__ uint32_t s_c[kMaxOwners];
+    if (threadIdx.x < kMaxOwners) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kWG)
+        atomicAdd(&s_c[(uint32_t)(((uint64_t)wl.slots[i] * nranks) >> 32)], 1u);
+    __syncthreads();
+    if (threadIdx.x < nranks && s_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_c[threadIdx.x]);
+}
+
+// Every workgroup takes a contiguous piece of the list, counts its entries per owner in LDS, reserves their places
+// in the owners' lists with ONE device atomic per owner, and writes (slot, table[slot]).
+__global__ __launch_bounds__(kWG) void kta_written_export(WrittenList wl, uint64_t n, const unsigned long long *__restrict__ table,
+                                                          uint32_t nranks, uint32_t skip_rank,
+                                                          const unsigned long long *__restrict__ owner_at,
+                                                          unsigned long long *__restrict__ cursors, uint32_t *__restrict__ out_slots,
+                                                          unsigned long long *__restrict__ out_vals)
+{
+    __shared__ uint32_t s_c[kMaxOwners];
+    __shared__ unsigned long long s_base[kMaxOwners];
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    constexpr uint64_t kChunk = (uint64_t)kWG * 8;
+    for (uint64_t c0 = lo; c0 < hi; c0 += kChunk) {                    // uniform trip count per workgroup
+        if (threadIdx.x < kMaxOwners) s_c[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t slot[8], own[8], at[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint64_t i = c0 + (uint64_t)u * kWG + threadIdx.x;
+            slot[u] = i < hi ? wl.slots[i] : 0u;
+            own[u] = i < hi ? (uint32_t)(((uint64_t)slot[u] * nranks) >> 32) : skip_rank;
+            at[u] = own[u] != skip_rank ? atomicAdd(&s_c[own[u]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x < nranks && s_c[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)s_c[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (own[u] == skip_rank) continue;
+            const unsigned long long k = owner_at[own[u]] + s_base[own[u]] + at[u];
+            out_slots[k] = slot[u];
+            out_vals[k] = table[slot[u]];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kWG) void kta_written_alive_count(WrittenList wl, uint64_t n, const unsigned long long *__restrict__ table,
+                                                               uint64_t lo, uint64_t hi, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    unsigned long long cnt = 0;
+    const uint64_t len = *wl.n < n ? *wl.n : n;           // n: an upper bound known to the host
+    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < len; i += (uint64_t)gridDim.x * kWG) {
+        const uint64_t slot = wl.slots[i];
+        if (slot >= lo && slot < hi) cnt += table[slot] & 1ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+hipError_t launch_written_count(const WrittenList &wl, uint64_t n, int nranks, uint64_t *counts, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (nranks > kMaxOwners) return hipErrorInvalidValue;
+    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(kta_written_count, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n, (uint32_t)nranks,
+                       reinterpret_cast<unsigned long long *>(counts));
+    return hipGetLastError();
+}
+
+hipError_t launch_written_export(const WrittenList &wl, uint64_t n, const uint64_t *table, int nranks, int skip_rank,
+                                 const uint64_t *owner_at, uint64_t *cursors, uint32_t *out_slots, uint64_t *out_vals, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (nranks > kMaxOwners) return hipErrorInvalidValue;
+    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(kta_written_export, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n, reinterpret_cast<const unsigned long long *>(table),
+                       (uint32_t)nranks, (uint32_t)skip_rank, reinterpret_cast<const unsigned long long *>(owner_at),
+                       reinterpret_cast<unsigned long long *>(cursors), out_slots, reinterpret_cast<unsigned long long *>(out_vals));
+    return hipGetLastError();
+}
+
+hipError_t launch_written_alive_count(const WrittenList &wl, uint64_t n, const uint64_t *table, uint64_t lo, uint64_t hi,
+                                      uint64_t *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess || n == 0 || lo >= hi) return e;
+    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(kta_written_alive_count, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n,
+                       reinterpret_cast<const unsigned long long *>(table), lo, hi, reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }
 
