@@ -7,12 +7,22 @@
  *     src/fnv32.rs:76-101    FnvHasher (32 bit, multiplier == offset basis)
  *     src/kafka.rs:107-109   handler dispatch order
  *
- * PARITY STATUS: **parity unpinned**.  The reference ships no tests, no golden
- * vectors and no fixtures for this path and its Rust toolchain is
- * not available in the build image, so the reference itself cannot be executed.
- * The oracle is pinned instead by (a) known-answer vectors derived by hand from
- * the source (tests/golden/), and (b) agreement with a second, independently
- * written pure-Python restatement (oracle/oracle_py.py) on randomised inputs.
+ * PARITY STATUS: **parity unpinned for handle_message; accessors and report pinned by the one output of the
+ * reference that the reference ships.**  The reference has no tests, golden vectors or fixtures for this path
+ *  and its Rust toolchain is not available in the build image, so the reference itself cannot be
+ * executed.  What pins the oracle:
+ *   (a) REFERENCE-PRODUCED: /root/reference/demo_output.png (README.md:28), a real run against a 10-partition
+ *       topic, transcribed into tests/golden/reference_demo_output.json (the transcription checks itself against
+ *       the screenshot's own sums).  tests/test_reference_demo.py asserts, through this oracle, the Python oracle
+ *       and the product: floor division of the three averages by `alive` (metric.rs:132-157), the `0.0000` dirty
+ *       ratio (metric.rs:159-167), Msg/s and Topic Size (main.rs:130,137), P-Bytes, the DateTime display and the
+ *       table geometry (main.rs:125-178) — rows a8 and f1 of SURVEY §8.  The topic behind the screenshot is gone:
+ *       it cannot pin handle_message (rows a2-a7, a9-a13);
+ *   (b) known-answer vectors derived by hand from the source (tests/golden/);
+ *   (c) agreement with a second, independently written pure-Python restatement (oracle/oracle_py.py) on
+ *       randomised inputs.
+ * oracle/ref_gen/ compiles the reference's OWN metric.rs / fnv32.rs for a box with cargo; until its output is
+ * committed, (b) and (c) are all that stands behind the handlers.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link,
  * import or call anything in oracle/.  The product (libkta_hip.so and everything

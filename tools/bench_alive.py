@@ -1,5 +1,5 @@
 """Alive-key pass (--count-alive-keys) kernel comparison on HBM-resident batches: the single-kernel filtered
-update (variant 2) against the partitioned pass (3 / 4 = 2^10 / 2^9 buckets), on the config-3
+update (variant 2) against the partitioned pass (3 automatic, 13 forced) in the TABLE state, on the config-3
 shape (10 M distinct keys, a compacted topic) and the config-5 key law (100 M distinct, mostly unique per
 batch).  Kernel time from HIP events on the compute stream; every variant must report the same alive count.
 
@@ -14,7 +14,7 @@ import kafka_topic_analyzer_amd as kta  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=26)
-ap.add_argument("--variants", default="2,3,4")
+ap.add_argument("--variants", default="2,3,13")
 ap.add_argument("--wgs", default="0")
 ap.add_argument("--presets", default="c3,c5")
 ap.add_argument("--reps", type=int, default=8)
@@ -22,7 +22,7 @@ args = ap.parse_args()
 n = 1 << args.n
 for preset in args.presets.split(","):
     sp, _ = kta.synth_preset(preset)
-    h = kta.HipMetricHandler(256, count_alive_keys=True)
+    h = kta.HipMetricHandler(256, count_alive_keys=True, alive_table=True)
     b = h.device_batch_alloc(n, n * 16)
     h.synth_fill_device(sp, 0, n, b)
     want = None

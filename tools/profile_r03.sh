@@ -8,13 +8,19 @@ OUT=$ROOT/gpurun_out/prof_r03
 RAW=/tmp/prof_r03
 mkdir -p $OUT $RAW
 cd $ROOT
-python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 tail -c 600 $OUT/bench_n1.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $RAW/stats -o r -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_stats_run.json 2> $OUT/stats.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $RAW/stats -o r -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hostfed > $OUT/bench_stats_run.json 2> $OUT/stats.err
 python $ROOT/tools/summarize_rocprof.py stats $(find $RAW/stats -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $RAW/pmc_$c -o r -- python $ROOT/bench.py --steps 5 --warmup 1 --preroll 5 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  timeout 400 rocprofv3 --pmc $c --kernel-trace -d $RAW/pmc_$c -o r -- python $ROOT/bench.py --steps 5 --warmup 1 --preroll 5 --no-cpu-baseline --no-hostfed > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python $ROOT/tools/summarize_rocprof.py pmc $(find $RAW/pmc_* -name '*.db') > $OUT/pmc_hbm.txt 2>&1
+# the multi-GPU modes with ONE rank and the collectives forced (a 1-GPU box): config 5 (both handlers + the whole
+# exchange) and config 4 as stated (strong scaling); "forced_collectives": true, not headline numbers
+cd $ROOT
+export KTA_BENCH_FORCE_COLLECTIVES=1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --preroll 5 --config c5 > $OUT/bench_c5_forced.json 2> $OUT/bench_c5_forced.err
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 3 --scaling strong --no-alive --no-decode --no-hostfed --no-cpu-baseline > $OUT/bench_c4_strong_forced.json 2> $OUT/bench_c4_strong_forced.err
 ls -la $OUT
