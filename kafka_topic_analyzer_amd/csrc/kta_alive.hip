@@ -172,10 +172,7 @@ __device__ __forceinline__ uint32_t lds_add(uint32_t *p, uint32_t v)
 {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ uint32_t lds_load(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+
 
 // ------------------------------------------------------------------------------------------------------
 // pass 1: hash + partition with software write combining, no workgroup barrier in the loop
@@ -242,7 +239,8 @@ enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS =
 // Per bucket in LDS: a ring of 16 pairs (two blocks of 8 = 64 bytes), a position counter, and one word per
 // ring half = (times this half was written out) << 4 | (pairs of the current block that have arrived).
 // Position p of a bucket belongs to block p >> 3, which uses half (p >> 3) & 1 once that half has been
-// written out (p >> 4) times.
+// written out (p >> 4) times.  (All three in ONE 64-bit word, so that the atomic that reserves a position also
+// returns the half's state — one LDS round trip less per record — measured the same: 3.07 vs 3.08 ms at 2^28.)
 template <int BLOG2>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint32_t skip, uint32_t tiles_per_wg,
                                                                     unsigned long long *__restrict__ pairs,
@@ -254,9 +252,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
     constexpr uint32_t B = 1u << BLOG2;
     KTA_PHASE_BEGIN;
     extern __shared__ __attribute__((aligned(128))) unsigned long long s_ring[];   // B x kRing pairs
-    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);   // B positions handed out
-    uint32_t *s_half = s_pos + B;                                                 // 2B half words
-    uint32_t *s_queue = s_half + 2 * B;                                           // kPartWaves x kQueue
+    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);
+    uint32_t *s_half = s_pos + B;
+    uint32_t *s_queue = s_half + 2 * B;
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         s_pos[b] = 0;
         s_half[2 * b] = 0;
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
         }
         so = on ? off + piece : ~0u;
         KTA_LDS_ORDER();
-        if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);    // the half is free again
+        if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);
     };
     auto drop_taken = [&](uint32_t groups) __attribute__((always_inline)) {      // the queue's first groups are gone
         const uint32_t took = qn < 16u * groups ? qn : 16u * groups;
@@ -410,7 +408,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             };
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool free_now = (hw[j] >> 4) == (p[j] >> 4);
+                const bool free_now = (hw[j] >> 4) == (p[j] >> 4);          // (both below 2^17)
                 done[j] = false;
                 if (keyed[j]) {
                     if (free_now) done[j] = insert(j);
@@ -442,7 +440,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (!((pending >> j) & 1u)) continue;
-                    const uint32_t word = lds_load(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)]);
+                    const uint32_t word = __hip_atomic_load(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((word >> 4) != (p[j] >> 4)) continue;
                     done[j] = insert(j);
                     pending &= ~(1u << j);
@@ -504,29 +502,23 @@ constexpr uint32_t kSliceSets = 128;               // sets of one bitmap slice
 constexpr uint32_t kNoFail = 0xFFFFFFFFu;
 constexpr uint32_t kMissQueue = 256;               // pairs a wave queues for the long way of the merge
 
-typedef unsigned short __attribute__((ext_vector_type(2))) ushort2v;
-
 // One lookup: which of the set's eight 16-bit tags equals `tag` (8 = none).  t = the set's 16 bytes.  The
-// entries are numbered as the halves lie in memory: entry 2 d + s is half s of dword d.
+// entries are numbered as the halves lie in memory: entry 2 d + s is half s of dword d; of two matching entries the
+// low halves come first (tags are unique in a set; the order matters for tag 0 = "first free entry").
+// Zero halves of x = t ^ tag:tag are found arithmetically — (x - 0x00010001) & ~x & 0x80008000 sets bit 15 / 31 for a
+// zero low / high half; a zero low half can also flag a high half that is exactly 1 (the borrow), which is harmless
+// because the low half is preferred.  Three operations per dword; a packed min / compare formulation compiled to
+// eight 16-bit compares + selects + permutes.
 __device__ __forceinline__ uint32_t find_tag(const uint4 &t, uint32_t tag)
 {
     const uint32_t rep = tag * 0x10001u;
-    const ushort2v one = {1, 1};
-    const uint32_t x[4] = {t.x ^ rep, t.y ^ rep, t.z ^ rep, t.w ^ rep};
-    uint32_t acc = 0;                              // bit d of each half: that half of dword d does NOT match
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        ushort2v v;
-        __builtin_memcpy(&v, &x[d], 4);
-        v = __builtin_elementwise_min(v, one);
-        uint32_t z;
-        __builtin_memcpy(&z, &v, 4);
-        acc |= z << d;
-    }
-    const uint32_t m = ~acc & 0x000F000Fu;
-    const uint32_t lo = m & 0xFu, hi = m >> 16;    // dwords whose low / high half match
-    if ((lo | hi) == 0u) return 8u;
-    return lo ? 2u * (uint32_t)__builtin_ctz(lo) : 2u * (uint32_t)__builtin_ctz(hi) + 1u;
+    const uint32_t x0 = t.x ^ rep, x1 = t.y ^ rep, x2 = t.z ^ rep, x3 = t.w ^ rep;
+    const uint32_t z0 = (x0 - 0x00010001u) & ~x0 & 0x80008000u, z1 = (x1 - 0x00010001u) & ~x1 & 0x80008000u;
+    const uint32_t z2 = (x2 - 0x00010001u) & ~x2 & 0x80008000u, z3 = (x3 - 0x00010001u) & ~x3 & 0x80008000u;
+    const uint32_t m = (z0 >> 15) | (z1 >> 14) | (z2 >> 13) | (z3 >> 12);   // bits 0..3: low halves of dwords 0..3; 16..19: high halves
+    if (m == 0u) return 8u;
+    const uint32_t lo = m & 0xFu;
+    return lo ? 2u * (uint32_t)__builtin_ctz(lo) : 2u * (uint32_t)__builtin_ctz(m >> 16) + 1u;
 }
 
 struct ApplyShared {
@@ -883,9 +875,11 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         KTA_LDS_ORDER();
         mq = 0;
     };
-    // merge the unit held in (q, qv): four pairs per lane, their four lookups in flight together, then the misses
+    // merge the unit held in (q, qv): four pairs per lane, their four lookups in flight together.  Misses collect in
+    // the wave's queue over several units and are handled when it is half full (64 lanes at work, not the few of
+    // one unit); a miss that finds the queue full waits in its register until the queue has been handled.
     auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par) __attribute__((always_inline)) {
-        static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the queue");
+        static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the empty queue");
         const unsigned long long pr[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
         const bool valid[4] = {qv[0] > 0u, qv[0] > 1u, qv[1] > 0u, qv[1] > 1u};
         uint32_t set[4], tag[4], hr[4];
@@ -897,17 +891,36 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             tag[i] = (hr[i] & ((1u << TAGBITS) - 1u)) + 1u;
             t[i] = *reinterpret_cast<const uint4 *>(s_tag + set[i] * 8u);
         }
+        uint32_t waiting = 0;                             // bit i: pair i missed and found the queue full
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t e = valid[i] ? find_tag(t[i], tag[i]) : 0u;
             if (valid[i] && e < 8u) atomicMax(&s_val[set[i] * 8u + e], (uint32_t)pr[i]);
             const bool miss = valid[i] && e == 8u;
             const unsigned long long m = __ballot(miss);
-            if (miss) missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
-            mq += (uint32_t)__popcll(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t room = kMissQueue - mq, cnt = (uint32_t)__popcll(m);
+            if (miss) {
+                if (rank < room) missq[mq + rank] = ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
+                else waiting |= 1u << i;
+            }
+            mq += cnt < room ? cnt : room;
         }
-        drain(par);
+        if (mq > kMissQueue / 2 || __any(waiting != 0u)) {
+            for (;;) {
+                drain(par);
+                if (!__any(waiting != 0u)) break;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {             // (at most 4 x 64: they fit the empty queue)
+                    const bool w = (waiting >> i) & 1u;
+                    const unsigned long long m = __ballot(w);
+                    if (w) missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
+                    mq += (uint32_t)__popcll(m);
+                }
+                waiting = 0;
+            }
+        }
     };
     // The driver.  First without checkpoints (no barrier until the end: a compacted topic's bucket fits the table);
     // a bucket that overflows table AND side table that way starts over in careful mode, and tells the buckets
@@ -933,6 +946,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             issue(u + 2, p, nv);
             merge(pn, nvn, par);
             u += 2;
+            // the queued misses are in before anybody looks at the table as a whole
+            if ((dynamic ? seg >= W : u >= units) || (careful && u % chunks == 0u)) drain(par);
             KTA_PHASE(1, 3);
             if (careful && u % chunks == 0u && u < units) {
 #pragma unroll
