@@ -507,18 +507,23 @@ constexpr uint32_t kMissQueue = 256;               // pairs a wave queues for th
 // low halves come first (tags are unique in a set; the order matters for tag 0 = "first free entry").
 // Zero halves of x = t ^ tag:tag are found arithmetically — (x - 0x00010001) & ~x & 0x80008000 sets bit 15 / 31 for a
 // zero low / high half; a zero low half can also flag a high half that is exactly 1 (the borrow), which is harmless
-// because the low half is preferred.  Three operations per dword; a packed min / compare formulation compiled to
-// eight 16-bit compares + selects + permutes.
+// because the low half is preferred.  Three operations per dword (xor, add, bitop3); a packed min / compare
+// formulation compiled to eight 16-bit compares + selects + permutes.
 __device__ __forceinline__ uint32_t find_tag(const uint4 &t, uint32_t tag)
 {
     const uint32_t rep = tag * 0x10001u;
     const uint32_t x0 = t.x ^ rep, x1 = t.y ^ rep, x2 = t.z ^ rep, x3 = t.w ^ rep;
-    const uint32_t z0 = (x0 - 0x00010001u) & ~x0 & 0x80008000u, z1 = (x1 - 0x00010001u) & ~x1 & 0x80008000u;
-    const uint32_t z2 = (x2 - 0x00010001u) & ~x2 & 0x80008000u, z3 = (x3 - 0x00010001u) & ~x3 & 0x80008000u;
+    // a & ~b & c in one v_bitop3_b32 (truth table 0x20); the compiler spends three operations on it
+    const uint32_t z0 = __builtin_amdgcn_bitop3_b32(x0 - 0x00010001u, x0, 0x80008000u, 0x20);
+    const uint32_t z1 = __builtin_amdgcn_bitop3_b32(x1 - 0x00010001u, x1, 0x80008000u, 0x20);
+    const uint32_t z2 = __builtin_amdgcn_bitop3_b32(x2 - 0x00010001u, x2, 0x80008000u, 0x20);
+    const uint32_t z3 = __builtin_amdgcn_bitop3_b32(x3 - 0x00010001u, x3, 0x80008000u, 0x20);
     const uint32_t m = (z0 >> 15) | (z1 >> 14) | (z2 >> 13) | (z3 >> 12);   // bits 0..3: low halves of dwords 0..3; 16..19: high halves
-    if (m == 0u) return 8u;
-    const uint32_t lo = m & 0xFu;
-    return lo ? 2u * (uint32_t)__builtin_ctz(lo) : 2u * (uint32_t)__builtin_ctz(m >> 16) + 1u;
+    // no branch (the kernel is bound by instruction issue, and every divergent region costs scalar instructions
+    // too): low halves first, then high halves, then bit 8 = "none"
+    const uint32_t c = (m & 0xFu) | ((m >> 12) & 0xF0u) | 0x100u;
+    const uint32_t i = (uint32_t)__builtin_ctz(c);
+    return i == 8u ? 8u : (((i & 3u) << 1) | (i >> 2));
 }
 
 struct ApplyShared {
@@ -894,8 +899,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         uint32_t waiting = 0;                             // bit i: pair i missed and found the queue full
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t e = valid[i] ? find_tag(t[i], tag[i]) : 0u;
-            if (valid[i] && e < 8u) atomicMax(&s_val[set[i] * 8u + e], (uint32_t)pr[i]);
+            const uint32_t e = find_tag(t[i], valid[i] ? tag[i] : 0xFFFFu);     // (no tag is 0xFFFF: an invalid pair finds nothing)
+            if (e < 8u) atomicMax(&s_val[set[i] * 8u + e], (uint32_t)pr[i]);
             const bool miss = valid[i] && e == 8u;
             const unsigned long long m = __ballot(miss);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
