@@ -535,6 +535,7 @@ struct ApplyShared {
     uint32_t occ[3], ovf_n[3], fail[3];
     uint32_t any_ovf;        // the side table holds something (this instalment)
     uint32_t next_seg;       // fast attempt: the next segment to hand out
+    uint32_t dense;          // POOL_DENSE as thread 0 found it: ONE reading for the whole workgroup
     long long w[kApplyWaves];
 };
 
@@ -591,6 +592,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = sh.fail[0] = sh.fail[1] = sh.fail[2] = 0;
         sh.any_ovf = 0;
         sh.next_seg = 0;
+        // Another bucket's workgroup may set the word at any moment.  Waves that read it for themselves could
+        // disagree, and a workgroup whose waves run in different modes does not meet at the same barriers.
+        sh.dense = pool_ctl[POOL_DENSE] != 0ull ? 1u : 0u;
     }
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
     };
     uint32_t claimed = 0;
-    bool careful = pool_ctl[POOL_DENSE] != 0ull;       // an earlier bucket of this batch overflowed its table: check as we go
+    bool careful = sh.dense != 0u;                     // an earlier bucket of this batch overflowed its table: check as we go
     // The merge of one pair that found no entry for its slot.  A new slot takes the set's first free entry with a
     // compare-and-swap on the dword that holds it.  All racers for one slot pick the same entry (first free), so
     // exactly one wins and the others find its tag when they look again: a slot never holds two entries.

@@ -229,6 +229,38 @@ def test_last_writer_wins_is_by_sequence_not_by_submission_order(ht):
         hc.device_batch_free(b)
 
 
+def test_partitioned_pass_with_seq_columns_ascending_and_not(ht):
+    """Table state, the partitioned pass forced (variant 13) on batches that carry a seq column of GLOBAL sequence
+    numbers: the survivors' values come from the column (not base_seq + index).  Three batches submitted in the
+    wrong order: two whose column ascends (partition + per-bucket merge) and one whose ROWS are shuffled — its
+    column does not ascend, the device's order check hands it to the single-kernel update without a host round
+    trip.  Last writer by sequence number: the oracle's set and count, whatever the order."""
+    hc = ht
+    rng = np.random.default_rng(77)
+    cols = random_cols(rng, 300000, 8, key_space=6000, tomb=0.4)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    n = len(cols["partition"])
+    seq = 3 * np.arange(n, dtype=np.uint64) + 7            # global, ascending with the topic, not contiguous
+    a, b_ = n // 3, 2 * n // 3 + 1
+    last = np.arange(b_, n)
+    rng.shuffle(last)
+    hc.reset()
+    hc.set_tuning(alive_variant=13)
+    batches = []
+    for idx in (last, np.arange(a, b_), np.arange(0, a)):
+        sub = {k: cols[k][idx] for k in ("partition", "key_len", "val_len", "ts_ms", "key_off")}
+        sub["key_bytes"] = cols["key_bytes"]                # offsets into the whole blob
+        sub["seq"] = seq[idx]
+        b, m = hc.upload_batch(sub, with_keys=True)
+        hc.submit_device(b, m, 0)
+        batches.append(b)
+    _compare(hc, o, 8, check_bitmap=True)
+    hc.set_tuning()
+    for b in batches:
+        hc.device_batch_free(b)
+
+
 def test_bit_set_state_refuses_what_needs_sequence_numbers(hc):
     """The default state is the reference's bit set: no table to hand out, export or import."""
     for call in (hc.alive_table, hc.alive_export_entries, lambda: hc.alive_count_range(0, 10)):
