@@ -181,6 +181,8 @@ def shard_of(rank):       # partition p on rank p % nranks, every record with it
             "key_bytes": np.ascontiguousarray(keys[idx]).reshape(-1), "seq": host["seq"][idx]}
 uid = kta.HipMetricHandler.comm_unique_id()
 errors, stats = [], [None] * nranks
+def at(rank, stage):           # where a rank was when the process died (stderr is shown by the failing assert)
+    print("rank %d: %s" % (rank, stage), file=sys.stderr, flush=True)
 def run(rank):
     try:
         h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, seq_column=True)
@@ -188,8 +190,11 @@ def run(rank):
         sh = shard_of(rank)
         assert len(sh["partition"]) >= 1 << 21          # large enough for the partitioned pass (seq column: order checked on the device)
         b, nb = h.upload_batch(sh, with_keys=True)
+        at(rank, "uploaded %d records" % nb)
         h.submit_device(b, nb, 0)
+        at(rank, "submitted")
         h.exchange()
+        at(rank, "exchanged")
         res, c = h.exchange_result()
         assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
         assert np.array_equal(c, o.counters(P)) and res.overall_count == n
@@ -197,6 +202,7 @@ def run(rank):
         words, want = h.export_alive_bitmap(), o.alive_words()
         assert np.array_equal(words[(lo + 31) // 32:hi // 32], want[(lo + 31) // 32:hi // 32]), rank
         stats[rank] = h.comm_info()
+        at(rank, "verified")
         h.device_batch_free(b); h.comm_destroy(); h.close()
     except BaseException as e:
         errors.append((rank, repr(e)))
