@@ -46,6 +46,15 @@ extern "C" {
 #define KTA_ERR_CAPACITY (-6)      /* batch / key-byte capacity exceeded             */
 #define KTA_ERR_DIV_BY_ZERO (-7)   /* where the reference panics (metric.rs:135,144,153) */
 #define KTA_ERR_COMM (-8)          /* RCCL missing or a collective failed (see kta_last_error) */
+#define KTA_ERR_TIMESTAMP_RANGE (-9) /* where the reference panics: a record's ts / 1000 outside chrono's range (metric.rs:210, kafka.rs:104) */
+
+/* chrono 0.4.19 (Cargo.lock:84-85) NaiveDateTime::from_timestamp(secs, 0) — metric.rs:210, kafka.rs:104 —
+ * .expect()s a date inside NaiveDate's years [i32::MIN >> 13, i32::MAX >> 13] = [-262144, 262143]:
+ * -262144-01-01 00:00:00 .. 262143-12-31 23:59:59 in seconds since the epoch.  A record outside ends the
+ * reference ("invalid or out-of-range datetime"); this library counts it like any other and says so at
+ * kta_finish / kta_decode_vector (the extrema of the scan tell: one such record moves one of them out). */
+#define KTA_CHRONO_MIN_SEC (-8334632851200LL)
+#define KTA_CHRONO_MAX_SEC (8210298412799LL)
 
 /* Per-partition counters, in the field order of `struct MessageMetrics`
  * (metric.rs:13-19). */
@@ -221,7 +230,9 @@ int kta_set_compute_stream(kta_ctx *ctx, void *hip_stream);
 int kta_sync(kta_ctx *ctx);
 /* Fold everything submitted so far, count alive keys (with -c), copy the counter vector
  * to the host and decode it.  counters_out (may be NULL) receives P*7 u64.  Returns
- * KTA_ERR_BAD_PARTITION (results still filled in) if any record was out of range.
+ * KTA_ERR_BAD_PARTITION (results still filled in) if any record was out of range, and
+ * KTA_ERR_TIMESTAMP_RANGE (results filled in as well, and taking precedence) if the reference would not
+ * have got this far: some record's ts / 1000 lies outside [KTA_CHRONO_MIN_SEC, KTA_CHRONO_MAX_SEC].
  * Non-destructive: more batches may follow and kta_finish may be called again. */
 int kta_finish(kta_ctx *ctx, kta_result *out, uint64_t *counters_out);
 /* Device pointer and length (in u64) of the SNAPSHOT of the counter vector that kta_finish_device
@@ -322,7 +333,8 @@ int kta_fnv32_device(kta_ctx *ctx, const uint8_t *key_bytes_host, const uint32_t
  * prettytable.  `now_*` stands in for Utc::now() at MessageMetrics::new (metric.rs:39);
  * start/end offsets may be NULL (0 / per-partition record count).  *out_len receives the full
  * length; the text is truncated to out_cap-1 bytes + NUL.  Returns KTA_ERR_DIV_BY_ZERO where
- * the reference panics (a partition with key bytes but no alive record, metric.rs:135). */
+ * the reference panics (a partition with key bytes but no alive record, metric.rs:135) and
+ * KTA_ERR_TIMESTAMP_RANGE, without a text, for a vector the reference could not have produced (above). */
 int kta_render_report(const char *topic, uint64_t duration_secs, const uint64_t *vec,
                       uint32_t n_partitions, int count_alive_keys, int64_t now_sec, uint32_t now_ns,
                       const int64_t *start_offsets, const int64_t *end_offsets, char *out,

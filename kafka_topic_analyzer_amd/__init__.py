@@ -24,7 +24,7 @@ from . import _native as N
 from ._native import KtaBatch, KtaConfig, KtaResult, KtaSynthSpec  # noqa: F401
 
 __all__ = ["HipMetricHandler", "MessageMetrics", "LogCompactionInMemoryMetrics", "Message", "KtaError",
-           "DivideByZeroPanic", "synth_preset", "synth_fill_host", "fnv_reference_kats"]
+           "DivideByZeroPanic", "DateTimeRangePanic", "synth_preset", "synth_fill_host", "fnv_reference_kats"]
 
 U64_MAX = 0xFFFFFFFFFFFFFFFF
 
@@ -37,6 +37,12 @@ class KtaError(RuntimeError):
 
 class DivideByZeroPanic(ZeroDivisionError):
     """Where the reference panics with 'attempt to divide by zero' (metric.rs:135,144,153)."""
+
+
+class DateTimeRangePanic(KtaError):
+    """Where the reference panics with 'invalid or out-of-range datetime' (NaiveDateTime::from_timestamp,
+    metric.rs:210 / kafka.rs:104): a record's ts / 1000 outside chrono 0.4.19's range.  The library has counted
+    the record; kta_finish reports it with KTA_ERR_TIMESTAMP_RANGE."""
 
 
 class Message(NamedTuple):
@@ -80,7 +86,8 @@ class HipMetricHandler:
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int, allow=()):
         if rc != N.KTA_OK and rc not in allow:
-            raise KtaError(rc, self._lib.kta_last_error(self._ctx).decode())
+            kind = DateTimeRangePanic if rc == N.KTA_ERR_TIMESTAMP_RANGE else KtaError
+            raise kind(rc, self._lib.kta_last_error(self._ctx).decode())
         return rc
 
     def close(self):

@@ -21,6 +21,9 @@ KTA_ERR_BAD_PARTITION = -5
 KTA_ERR_CAPACITY = -6
 KTA_ERR_DIV_BY_ZERO = -7
 KTA_ERR_COMM = -8
+KTA_ERR_TIMESTAMP_RANGE = -9
+KTA_CHRONO_MIN_SEC = -8334632851200
+KTA_CHRONO_MAX_SEC = 8210298412799
 KTA_COMM_ID_BYTES = 128
 
 KTA_NCOUNTERS = 7

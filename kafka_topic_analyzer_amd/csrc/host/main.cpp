@@ -235,6 +235,8 @@ void run_rank(const ShardedJob &job, int rank, const uint8_t *uid, int ndev, kta
         }
         h->exchange(!job.synthetic);
         *out = h;
+    } catch (const kta::RustPanic &p) {      // (every rank sees the job's extrema: all of them end here)
+        rust_panic(p.what(), p.location);
     } catch (const std::exception &e) {
         fprintf(stderr, "rank %d: %s\n", rank, e.what());
         exit(2);   // the other ranks would wait for this one in the exchange for ever
@@ -588,6 +590,8 @@ int main(int argc, char **argv)
 
     try {
         handler->finish(segment);                // where main.rs:121 is: the trait has no end-of-stream hook
+    } catch (const kta::RustPanic &p) {          // a timestamp outside chrono's range: the reference died on that record
+        rust_panic(p.what(), p.location);
     } catch (const std::exception &e) {
         fprintf(stderr, "%s\n", e.what());
         return 2;

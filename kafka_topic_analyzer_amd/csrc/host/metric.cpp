@@ -94,6 +94,13 @@ void HipMetricHandler::check(int rc, const char *what)
     if (rc != KTA_OK) throw std::runtime_error(std::string(what) + ": " + kta_last_error(ctx_));
 }
 
+// NaiveDateTime::from_timestamp(timestamp / 1000, 0) of a record outside chrono 0.4.19's range: the reference
+// dies on that record (kafka.rs:104, before any handler; metric.rs:210 holds the same call).  The device counts the
+// record like any other; the extrema tell at the end of the stream, which is where this mirror can say it.  (The
+// reference's own location string is the expect() inside the chrono crate, under the builder's cargo registry.)
+static const char *const kDateTimePanic = "invalid or out-of-range datetime";
+static const char *const kDateTimePanicAt = "chrono-0.4.19/src/naive/datetime.rs (NaiveDateTime::from_timestamp, src/kafka.rs:104)";
+
 void HipMetricHandler::handle_message(const Message &m)
 {
     check(kta_handle_message(ctx_, m.partition, m.timestamp_ms, m.key, m.key ? m.key_len : -1, m.payload_len),
@@ -105,6 +112,7 @@ void HipMetricHandler::finish(bool tolerate_undelivered)
     kta_result r{};
     std::vector<uint64_t> counters((size_t)P_ * KTA_NCOUNTERS);
     const int rc = kta_finish(ctx_, &r, counters.data());
+    if (rc == KTA_ERR_TIMESTAMP_RANGE) throw RustPanic(kDateTimePanic, kDateTimePanicAt);
     if (!(rc == KTA_ERR_BAD_PARTITION && tolerate_undelivered)) check(rc, "kta_finish");
     undelivered_ = r.bad_partition_records;
     metrics_ = MessageMetrics(r, std::move(counters), now_);
@@ -122,6 +130,7 @@ void HipMetricHandler::exchange(bool tolerate_undelivered)
     kta_result r{};
     std::vector<uint64_t> counters((size_t)P_ * KTA_NCOUNTERS);
     const int rc = kta_exchange_result(ctx_, &r, counters.data());
+    if (rc == KTA_ERR_TIMESTAMP_RANGE) throw RustPanic(kDateTimePanic, kDateTimePanicAt);
     if (!(rc == KTA_ERR_BAD_PARTITION && tolerate_undelivered)) check(rc, "kta_exchange_result");
     undelivered_ = r.bad_partition_records;
     metrics_ = MessageMetrics(r, std::move(counters), now_);

@@ -281,6 +281,15 @@ uint64_t TopicAnalyzer::read_topic_into_metrics(const std::string &topic, const 
         msg.key = static_cast<const uint8_t *>(m->key);         // key(): None iff the pointer is null
         msg.key_len = m->key ? (int64_t)m->key_len : -1;
         msg.payload_len = m->payload ? (int64_t)m->len : -1;     // payload(): likewise; bytes are never read
+        // kafka.rs:103-105: the DateTime of the progress line.  NaiveDateTime::from_timestamp(timestamp / 1000, 0)
+        // [3P chrono 0.4.19] expects a date within the years [-262144, 262143] and panics otherwise — here,
+        // before any handler has seen the record.
+        const int64_t secs = (msg.timestamp_ms == -1 ? 0 : msg.timestamp_ms) / 1000;
+        if (secs < KTA_CHRONO_MIN_SEC || secs > KTA_CHRONO_MAX_SEC) {
+            api_->message_destroy(m);
+            throw RustPanic("invalid or out-of-range datetime",
+                            "chrono-0.4.19/src/naive/datetime.rs (NaiveDateTime::from_timestamp, src/kafka.rs:104)");
+        }
         for (MetricHandler *mh : metric_handlers_) mh->handle_message(msg);    // kafka.rs:107-109
         const rd_kafka_resp_err_t oerr = api_->offset_store(m->rkt, m->partition, m->offset);   // kafka.rs:115
         if (oerr != 0) fprintf(stderr, "[WARN] Error while storing offset: %s\n", api_->err2str(oerr));

@@ -781,6 +781,10 @@ int kta_decode_vector(const uint64_t *vec, uint32_t P, int count_alive_keys, kta
     out->overall_size = size;
     out->alive_keys = count_alive_keys ? g[KTA_G_ALIVE_KEYS] : 0;
     out->bad_partition_records = g[KTA_G_BAD_PARTITION];
+    // metric.rs:210 / kafka.rs:104: NaiveDateTime::from_timestamp panics outside chrono's range, on the first
+    // such record; one such record among those counted puts an extremum outside the range
+    if (out->any_records && (out->min_ts_sec < KTA_CHRONO_MIN_SEC || out->max_ts_sec > KTA_CHRONO_MAX_SEC))
+        return KTA_ERR_TIMESTAMP_RANGE;
     return out->bad_partition_records ? KTA_ERR_BAD_PARTITION : KTA_OK;
 }
 
@@ -817,6 +821,9 @@ int kta_exchange_result(kta_ctx *ctx, kta_result *out, uint64_t *counters_out)
         snprintf(buf, sizeof buf, "%llu record(s) had a partition id outside [0, %u)",
                  (unsigned long long)out->bad_partition_records, ctx->P);
         ctx->err = buf;
+    } else if (rc == KTA_ERR_TIMESTAMP_RANGE) {
+        ctx->err = "a record's timestamp / 1000 is outside chrono's NaiveDateTime range: the reference panics on it "
+                   "('invalid or out-of-range datetime', metric.rs:210)";
     }
     return rc;
 }

@@ -144,6 +144,7 @@ struct kto_metrics {
     pmap total_messages, tombstones, alive, key_null, key_non_null, key_size_sum, value_size_sum;
     kto_datetime earliest_message, latest_message;
     uint64_t smallest_message, largest_message, overall_size, overall_count;
+    int panicked; /* a record's timestamp was outside chrono's range: the process is gone (see handle_message) */
 };
 
 static int dt_gt(kto_datetime a, kto_datetime b)
@@ -212,6 +213,17 @@ void kto_metrics_handle_message(kto_metrics *m, int32_t partition, int64_t ts_ra
     kto_datetime timestamp_dt;
     timestamp_dt.sec = timestamp / 1000;
     timestamp_dt.ns = 0;
+    /* [3P chrono 0.4.19, Cargo.lock:84-85] NaiveDateTime::from_timestamp = from_timestamp_opt(secs, 0)
+     * .expect("invalid or out-of-range datetime"): the day number has to fit NaiveDate, whose years run from
+     * MIN_YEAR = i32::MIN >> 13 = -262144 to MAX_YEAR = i32::MAX >> 13 = 262143.  Outside
+     * [-262144-01-01 00:00:00, 262143-12-31 23:59:59] the reference panics here — before anything is counted
+     * (and, in the running program, already at the same call in kafka.rs:104, before any handler): the process
+     * ends, no later record is looked at. */
+    if (m->panicked) return;
+    if (timestamp_dt.sec < KTO_CHRONO_MIN_SEC || timestamp_dt.sec > KTO_CHRONO_MAX_SEC) {
+        m->panicked = 1;
+        return;
+    }
     uint64_t message_size = 0; /* :212 */
     int empty_value = 0;       /* :213 */
 
@@ -243,6 +255,8 @@ void kto_metrics_handle_message(kto_metrics *m, int32_t partition, int64_t ts_ra
 
     if (!empty_value) cmp_and_set_message_size(m, message_size); /* :249-251 */
 }
+
+int kto_metrics_panicked(const kto_metrics *m) { return m->panicked; }
 
 uint64_t kto_total(const kto_metrics *m, int32_t p) { return pmap_get(&m->total_messages, p); }
 uint64_t kto_tombstones(const kto_metrics *m, int32_t p) { return pmap_get(&m->tombstones, p); }
@@ -469,7 +483,10 @@ void kto_run_soa(kto_metrics *m, kto_logcompaction *lc, uint64_t n, const int32_
                  const uint32_t *key_off, const uint8_t *key_bytes)
 {
     for (uint64_t i = 0; i < n; i++) {
-        if (m) kto_metrics_handle_message(m, part[i], ts_ms[i], 1, key_len[i], val_len[i]);
+        if (m) {
+            kto_metrics_handle_message(m, part[i], ts_ms[i], 1, key_len[i], val_len[i]);
+            if (m->panicked) return; /* the process died in the first handler: the second never sees the record */
+        }
         if (lc) {
             const uint8_t *k = (key_len[i] >= 0 && key_bytes) ? key_bytes + key_off[i] : NULL;
             kto_lc_handle_message(lc, k, key_len[i], val_len[i]);

@@ -58,6 +58,15 @@ void kto_metrics_free(kto_metrics *m);
 void kto_metrics_handle_message(kto_metrics *m, int32_t partition, int64_t ts_raw_ms,
                                 int ts_available, int64_t key_len, int64_t val_len);
 
+/* metric.rs:210 (and kafka.rs:104): NaiveDateTime::from_timestamp(timestamp / 1000, 0) panics ("invalid or
+ * out-of-range datetime") outside chrono 0.4.19's NaiveDate years [i32::MIN >> 13, i32::MAX >> 13] =
+ * [-262144, 262143] ([3P], restated: the crate's source is not under /root/reference — parity unpinned):
+ *   -262144-01-01 00:00:00 = -8 334 632 851 200 s,  262143-12-31 23:59:59 = 8 210 298 412 799 s.
+ * A panicked oracle has stopped: the record that did it and everything after it is not counted. */
+#define KTO_CHRONO_MIN_SEC (-8334632851200LL)
+#define KTO_CHRONO_MAX_SEC (8210298412799LL)
+int kto_metrics_panicked(const kto_metrics *m);
+
 /* metric.rs:104-130 */
 uint64_t kto_total(const kto_metrics *m, int32_t p);
 uint64_t kto_tombstones(const kto_metrics *m, int32_t p);

@@ -64,6 +64,25 @@ class DivideByZeroPanic(Exception):
     """Rust: thread 'main' panicked at 'attempt to divide by zero' (metric.rs:135,144,153)."""
 
 
+class DateTimeRangePanic(Exception):
+    """Rust: thread 'main' panicked at 'invalid or out-of-range datetime' — chrono 0.4.19 [3P]
+    NaiveDateTime::from_timestamp (metric.rs:210, kafka.rs:104) outside NaiveDate's years
+    [i32::MIN >> 13, i32::MAX >> 13] = [-262144, 262143]."""
+
+
+def _days_from_civil(y: int, m: int, d: int) -> int:
+    """Days from 1970-01-01 in the proleptic Gregorian calendar (year 0 = 1 BCE, as chrono counts)."""
+    y -= m <= 2
+    era = y // 400
+    yoe = y - era * 400
+    doy = (153 * (m + (-3 if m > 2 else 9)) + 2) // 5 + d - 1
+    return era * 146097 + yoe * 365 + yoe // 4 - yoe // 100 + doy - 719468
+
+
+CHRONO_MIN_SEC = _days_from_civil(-262144, 1, 1) * 86400            # -8 334 632 851 200
+CHRONO_MAX_SEC = _days_from_civil(262143, 12, 31) * 86400 + 86399   # 8 210 298 412 799
+
+
 def _f32(x: float) -> float:
     return struct.unpack("<f", struct.pack("<f", x))[0]
 
@@ -96,6 +115,8 @@ class MessageMetrics:
         if timestamp_ms is None or timestamp_ms == -1:  # rdkafka 0.25 to_millis
             timestamp_ms = 0  # unwrap_or(0)  :209
         timestamp_dt = (_trunc_div(timestamp_ms, 1000), 0)  # :210-211
+        if not CHRONO_MIN_SEC <= timestamp_dt[0] <= CHRONO_MAX_SEC:
+            raise DateTimeRangePanic(timestamp_ms)  # .expect("invalid or out-of-range datetime") [3P chrono]
         message_size = 0
         empty_value = False
         self.overall_count_ += 1  # :215

@@ -9,6 +9,7 @@
 //   MOCK_RDKAFKA_ERR_EVERY   k: every k-th poll returns an error event (no record consumed)
 //   MOCK_RDKAFKA_NULL_EVERY  k: every k-th poll times out (NULL)
 //   MOCK_RDKAFKA_START       low watermark of every partition (offsets start there; default 0)
+//   MOCK_RDKAFKA_TS_AT       "k:ts": record k of the topic (0-based) carries the timestamp ts (ms) instead of its own
 // Records are delivered in the synthetic topic's global order, so a run equals `synthetic://`.
 #include <stdint.h>
 #include <stdio.h>
@@ -207,6 +208,11 @@ Message *rd_kafka_consumer_poll(void *rk, int)
     kta_synth_record(&h->spec, h->next, &p, &kl, &vl, &ts);
     Private *pv = new Private();
     pv->ts = ts;
+    if (const char *at = getenv("MOCK_RDKAFKA_TS_AT")) {
+        char *colon = nullptr;
+        const uint64_t k = strtoull(at, &colon, 10);
+        if (colon && *colon == ':' && k == h->next) pv->ts = strtoll(colon + 1, nullptr, 10);
+    }
     m->_private = pv;
     m->partition = p;
     m->offset = h->start + h->delivered[(size_t)p]++;

@@ -39,6 +39,8 @@ def lib():
             fn = getattr(L, "kto_" + f)
             fn.restype = C.c_uint64
             fn.argtypes = [C.c_void_p]
+        L.kto_metrics_panicked.restype = C.c_int
+        L.kto_metrics_panicked.argtypes = [C.c_void_p]
         L.kto_lc_new.restype = C.c_void_p
         L.kto_lc_free.argtypes = [C.c_void_p]
         L.kto_lc_handle_message.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64]
@@ -82,7 +84,7 @@ class Oracle:
         """ts None == timestamp not available; key None == key None; vlen None == payload None."""
         self.L.kto_metrics_handle_message(self.m, part, 0 if ts is None else ts, 0 if ts is None else 1,
                                           -1 if key is None else len(key), -1 if vlen is None else vlen)
-        if self.lc:
+        if self.lc and not self.panicked():     # (the process died in the first handler)
             self.L.kto_lc_handle_message(self.lc, key, -1 if key is None else len(key), -1 if vlen is None else vlen)
 
     def run_soa(self, cols):
@@ -95,6 +97,10 @@ class Oracle:
             kb = np.zeros(16, np.uint8).ctypes.data
         self.L.kto_run_soa(self.m, self.lc, n, a["partition"].ctypes.data, a["key_len"].ctypes.data,
                            a["val_len"].ctypes.data, a["ts_ms"].ctypes.data, koff, kb)
+
+    def panicked(self):
+        """A record's timestamp was outside chrono's range (metric.rs:210): the reference is gone."""
+        return bool(self.L.kto_metrics_panicked(self.m))
 
     def counters(self, P):
         out = np.zeros((P, 7), dtype=np.uint64)

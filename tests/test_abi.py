@@ -126,6 +126,23 @@ def test_decode_vector_empty_and_truncating_division():
     g[N.KTA_G_BAD_PARTITION] = 2
     assert lib.kta_decode_vector(v.ctypes.data, P, 0, C.byref(res), None) == N.KTA_ERR_BAD_PARTITION
     assert res.bad_partition_records == 2
+    # where the reference panics in NaiveDateTime::from_timestamp (metric.rs:210, kafka.rs:104; chrono 0.4.19's
+    # years [-262144, 262143]): the bounds pass — with up to 999 ms beyond them, the division truncates — one
+    # second more does not, and that verdict comes before the bad-partition one
+    lo, hi = N.KTA_CHRONO_MIN_SEC, N.KTA_CHRONO_MAX_SEC
+    for min_ms, max_ms, want in ((lo * 1000 - 999, hi * 1000 + 999, N.KTA_ERR_BAD_PARTITION),
+                                 ((lo - 1) * 1000, 1999, N.KTA_ERR_TIMESTAMP_RANGE),
+                                 (-1500, (hi + 1) * 1000, N.KTA_ERR_TIMESTAMP_RANGE),
+                                 (-2**63, 2**63 - 1, N.KTA_ERR_TIMESTAMP_RANGE)):
+        g[N.KTA_G_NOT_MIN_TS_MS] = _u(~np.int64(min_ms))
+        g[N.KTA_G_MAX_TS_MS] = _u(np.int64(max_ms))
+        assert lib.kta_decode_vector(v.ctypes.data, P, 0, C.byref(res), None) == want
+        assert res.overall_count == 1 and res.bad_partition_records == 2          # filled in either way
+    g[N.KTA_G_BAD_PARTITION] = 0
+    out_len = C.c_size_t()
+    buf = C.create_string_buffer(1 << 14)
+    assert lib.kta_render_report(b"t", 1, v.ctypes.data, P, 0, 4102444800, 0, None, None, buf, len(buf),
+                                 C.byref(out_len)) == N.KTA_ERR_TIMESTAMP_RANGE   # no report: the reference died before
 
 
 def test_merge_vectors_operators():

@@ -171,6 +171,31 @@ def test_empty_and_ragged_batch_sizes(hc, n):
     hc.device_batch_free(b)
 
 
+def test_timestamp_outside_chronos_range_is_reported_where_the_reference_panics(hc):
+    """metric.rs:210 / kafka.rs:104: NaiveDateTime::from_timestamp(ts / 1000, 0) panics outside chrono 0.4.19's
+    years [-262144, 262143].  The scan counts such a record like any other; kta_finish says that the reference
+    would not have got this far (the oracle stops at the record).  The bounds themselves are fine."""
+    lo, hi = N.KTA_CHRONO_MIN_SEC, N.KTA_CHRONO_MAX_SEC
+    ok = records_to_cols([(0, 1000, b"a", 1), (1, hi * 1000 + 999, b"b", 2), (2, lo * 1000 - 999, b"c", 3)])
+    o = Oracle(NOW, True)
+    o.run_soa(ok)
+    assert not o.panicked()
+    hc.reset()
+    hc.submit_columns(**ok)
+    _compare(hc, o, 5)
+    for ts in ((hi + 1) * 1000, (lo - 1) * 1000, 2**63 - 1, -2**63):
+        cols = records_to_cols([(0, 1000, b"a", 1), (1, ts, b"b", 2), (2, 3000, b"c", 3)])
+        o = Oracle(NOW, True)
+        o.run_soa(cols)
+        assert o.panicked() and o.get("overall_count") == 1
+        hc.reset()
+        hc.submit_columns(**cols)
+        with pytest.raises(kta.DateTimeRangePanic) as e:
+            hc.finish()
+        assert e.value.code == N.KTA_ERR_TIMESTAMP_RANGE and "out-of-range datetime" in str(e.value)
+    hc.reset()
+
+
 def test_bad_partition_is_reported_not_counted(hc):
     cols = records_to_cols([(0, 1000, b"a", 1), (256, 2000, b"b", 2), (-1, 3000, b"c", 3), (255, 4000, b"d", 4)])
     hc.reset()

@@ -126,6 +126,14 @@ def test_loop_failure_modes_panic_like_the_reference(built):
     assert r.returncode == 101 and "Consumer creation failed: No such configuration property" in r.stderr
     r = run("b:9092", "t", KTA_RDKAFKA_LIB="/nonexistent/librdkafka.so")
     assert r.returncode == 101 and "Consumer creation failed: librdkafka could not be loaded" in r.stderr
+    # kafka.rs:103-105: the progress line's NaiveDateTime::from_timestamp(ts / 1000, 0) panics outside chrono's
+    # range, before any handler sees the record — 40 records delivered, the 41st ends the run; the bound passes
+    hi = N.KTA_CHRONO_MAX_SEC
+    r = run("b:9092", "t", MOCK_RDKAFKA_TS_AT="40:%d" % ((hi + 1) * 1000))
+    assert r.returncode == 101 and "panicked at 'invalid or out-of-range datetime'" in r.stderr
+    assert "src/kafka.rs:104" in r.stderr and len(parse(r.stdout)[0]) == 2 * 40    # two handlers, 40 records each
+    r = run("b:9092", "t", MOCK_RDKAFKA_TS_AT="40:%d" % (hi * 1000 + 999))
+    assert r.returncode == 0 and parse(r.stdout)[2] == [(100, 100, 100)]
 
 
 def _normalise(text):
