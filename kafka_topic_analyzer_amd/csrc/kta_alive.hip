@@ -486,6 +486,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 // ------------------------------------------------------------------------------------------------------
 // pass 2: per-bucket merge in LDS, then the survivors go to the bucket's region
 // ------------------------------------------------------------------------------------------------------
+#ifndef KTA_APPLY_SITES
+#define KTA_APPLY_SITES 2                          // merge sites in the driver loop (1: not yet measured)
+#endif
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr int kApplyUnroll = 2;                    // 16-byte loads of a unit: 256 pairs, 4 per lane
@@ -952,9 +955,18 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             if (!careful && sh.fail[0]) break;            // (fast attempt) some wave ran out of room: stop early
             issue(u + 1, pn, nvn);
             merge(p, nv, par);
+#if KTA_APPLY_SITES == 1   /* experiment (tools/ubench_alive.hip): one merge site, the prefetched unit copied over */
+#pragma unroll
+            for (int x = 0; x < kApplyUnroll; x++) {
+                p[x] = pn[x];
+                nv[x] = nvn[x];
+            }
+            u += 1;
+#else
             issue(u + 2, p, nv);
             merge(pn, nvn, par);
             u += 2;
+#endif
             // the queued misses are in before anybody looks at the table as a whole
             if ((dynamic ? seg >= W : u >= units) || (careful && u % chunks == 0u)) drain(par);
             KTA_PHASE(1, 3);
