@@ -510,6 +510,8 @@ int main(int argc, char **argv)
             }
             try {
                 for (auto *mh : metric_handlers) mh->handle_message(m);
+            } catch (const kta::RustPanic &p) {
+                rust_panic(p.what(), p.location);
             } catch (const std::exception &e) {
                 fprintf(stderr, "%s\n", e.what());
                 return 2;

@@ -103,6 +103,11 @@ static const char *const kDateTimePanicAt = "chrono-0.4.19/src/naive/datetime.rs
 
 void HipMetricHandler::handle_message(const Message &m)
 {
+    // metric.rs:209-210: the handler's own NaiveDateTime::from_timestamp(timestamp / 1000, 0) — the message is in
+    // hand here, so a timestamp outside chrono's range ends the run on this very record, as in the reference
+    const int64_t secs = (m.timestamp_ms == -1 ? 0 : m.timestamp_ms) / 1000;
+    if (secs < KTA_CHRONO_MIN_SEC || secs > KTA_CHRONO_MAX_SEC)
+        throw RustPanic(kDateTimePanic, "chrono-0.4.19/src/naive/datetime.rs (NaiveDateTime::from_timestamp, src/metric.rs:210)");
     check(kta_handle_message(ctx_, m.partition, m.timestamp_ms, m.key, m.key ? m.key_len : -1, m.payload_len),
           "kta_handle_message");
 }
