@@ -890,7 +890,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // merge the unit held in (q, qv): four pairs per lane, their four lookups in flight together.  Misses collect in
     // the wave's queue over several units and are handled when it is half full (64 lanes at work, not the few of
     // one unit); a miss that finds the queue full waits in its register until the queue has been handled.
-    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par) __attribute__((always_inline)) {
+    // `edge`: nothing may stay queued past this unit (the one-site driver's last unit of a trip).
+    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par, bool edge) __attribute__((always_inline)) {
         static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the empty queue");
         const unsigned long long pr[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
         const bool valid[4] = {qv[0] > 0u, qv[0] > 1u, qv[1] > 0u, qv[1] > 1u};
@@ -918,8 +919,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             }
             mq += cnt < room ? cnt : room;
         }
-        if (mq > kMissQueue / 2 || __any(waiting != 0u)) {
-            for (;;) {
+        if (mq > kMissQueue / 2 || __any(waiting != 0u) || (edge && mq != 0u)) {
+            for (;;) {                                    // (leaves the queue empty)
                 drain(par);
                 if (!__any(waiting != 0u)) break;
 #pragma unroll
@@ -954,21 +955,26 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         while (dynamic ? seg < W : u < units) {
             if (!careful && sh.fail[0]) break;            // (fast attempt) some wave ran out of room: stop early
             issue(u + 1, pn, nvn);
-            merge(p, nv, par);
-#if KTA_APPLY_SITES == 1   /* experiment (tools/ubench_alive.hip): one merge site, the prefetched unit copied over */
+#if KTA_APPLY_SITES == 1   /* experiment (tools/ab_alive.sh): one merge site, the prefetched unit copied over, and */
+            {              /* the long way of new slots (drain -> merge_new) inlined once instead of three times    */
+                // the queued misses are in before anybody looks at the table as a whole: the trip's last unit flushes
+                const bool edge = (dynamic ? seg >= W : u + 1u >= units) || (careful && (u + 1u) % chunks == 0u);
+                merge(p, nv, par, edge);
 #pragma unroll
-            for (int x = 0; x < kApplyUnroll; x++) {
-                p[x] = pn[x];
-                nv[x] = nvn[x];
+                for (int x = 0; x < kApplyUnroll; x++) {
+                    p[x] = pn[x];
+                    nv[x] = nvn[x];
+                }
+                u += 1;
             }
-            u += 1;
 #else
+            merge(p, nv, par, false);
             issue(u + 2, p, nv);
-            merge(pn, nvn, par);
+            merge(pn, nvn, par, false);
             u += 2;
-#endif
             // the queued misses are in before anybody looks at the table as a whole
             if ((dynamic ? seg >= W : u >= units) || (careful && u % chunks == 0u)) drain(par);
+#endif
             KTA_PHASE(1, 3);
             if (careful && u % chunks == 0u && u < units) {
 #pragma unroll
