@@ -31,6 +31,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -67,6 +68,10 @@ void print_help()
                     "<BOOTSTRAP_SERVER> --topic <TOPIC>\n\nFor more information try --help\n", msg.c_str());
     exit(1);
 }
+
+std::mutex g_rank_panic_mutex;           // a panic of a rank thread of a sharded run, kept for the main thread
+bool g_rank_panicked = false;
+std::string g_rank_panic_msg, g_rank_panic_loc;
 
 [[noreturn]] void rust_panic(const std::string &msg, const std::string &loc)
 {
@@ -235,11 +240,19 @@ void run_rank(const ShardedJob &job, int rank, const uint8_t *uid, int ndev, kta
         }
         h->exchange(!job.synthetic);
         *out = h;
-    } catch (const kta::RustPanic &p) {      // (every rank sees the job's extrema: all of them end here)
-        rust_panic(p.what(), p.location);
+    } catch (const kta::RustPanic &p) {
+        // Every rank sees the job's extrema after the exchange, so all of them end here — and exit() is not to be
+        // called from several threads at once (handlers run at exit, the HIP runtime is torn down).  The panic is
+        // kept for the main thread, which prints it once after joining the ranks, like the reference's one line.
+        std::lock_guard<std::mutex> lock(g_rank_panic_mutex);
+        if (!g_rank_panicked) {
+            g_rank_panicked = true;
+            g_rank_panic_msg = p.what();
+            g_rank_panic_loc = p.location;
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "rank %d: %s\n", rank, e.what());
-        exit(2);   // the other ranks would wait for this one in the exchange for ever
+        exit(2);   // before the exchange: the other ranks would wait for this one for ever
     }
 }
 
@@ -268,6 +281,7 @@ int run_sharded(ShardedJob &job, const std::chrono::steady_clock::time_point sta
     std::vector<std::thread> threads;
     for (int r = 0; r < job.nranks; r++) threads.emplace_back(run_rank, std::cref(job), r, uid, ndev, &handlers[r]);
     for (auto &t : threads) t.join();
+    if (g_rank_panicked) rust_panic(g_rank_panic_msg, g_rank_panic_loc);           // once, from the main thread
     fprintf(stderr, "done\n");                                                     // kafka.rs:136 (spinner)
     kta::HipMetricHandler *h0 = handlers[0];            // after the exchange every rank holds the whole job's result
     uint64_t undelivered = 0;

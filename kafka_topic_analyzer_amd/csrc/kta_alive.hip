@@ -59,17 +59,54 @@ constexpr uint32_t kFnvMul = 0x811c9dc5u;    // fnv32.rs:97: the multiplier is t
 
 __device__ __forceinline__ uint32_t fnv_byte(uint32_t h, uint32_t b) { return (h ^ b) * kFnvMul; }
 
+// h ^ byte N of w in ONE instruction: gfx9's sub-dword addressing selects the byte inside the xor.  (Left to itself
+// the compiler does that for byte 3 only; bytes 1 and 2 cost a shift and an and-xor each — a quarter of the chain.)
+#define KTA_XOR_BYTE(N)                                                                                         \
+    __device__ __forceinline__ uint32_t xor_byte##N(uint32_t h, uint32_t w)                                      \
+    {                                                                                                           \
+        uint32_t r;                                                                                             \
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #N    \
+            : "=v"(r)                                                                                           \
+            : "v"(h), "v"(w));                                                                                  \
+        return r;                                                                                               \
+    }
+KTA_XOR_BYTE(0)
+KTA_XOR_BYTE(1)
+KTA_XOR_BYTE(2)
+KTA_XOR_BYTE(3)
+#undef KTA_XOR_BYTE
+
 __device__ __forceinline__ uint32_t fnv_word(uint32_t h, uint32_t w)
 {
-    h = fnv_byte(h, w & 0xFFu);
-    h = fnv_byte(h, (w >> 8) & 0xFFu);
-    h = fnv_byte(h, (w >> 16) & 0xFFu);
-    return fnv_byte(h, w >> 24);
+    h = xor_byte0(h, w) * kFnvMul;
+    h = xor_byte1(h, w) * kFnvMul;
+    h = xor_byte2(h, w) * kFnvMul;
+    return xor_byte3(h, w) * kFnvMul;
 }
 
 __device__ __forceinline__ uint32_t fnv_16(uint32_t h, const uint4 &v)
 {
     return fnv_word(fnv_word(fnv_word(fnv_word(h, v.x), v.y), v.z), v.w);
+}
+
+// Four 16-byte keys at once, their chains interleaved (one chain is 32 dependent instructions).
+__device__ __forceinline__ void fnv_16x4(uint32_t (&h)[4], const uint4 (&k)[4])
+{
+    const uint32_t w[4][4] = {{k[0].x, k[0].y, k[0].z, k[0].w}, {k[1].x, k[1].y, k[1].z, k[1].w},
+                              {k[2].x, k[2].y, k[2].z, k[2].w}, {k[3].x, k[3].y, k[3].z, k[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; j++) h[j] = kFnvInit;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) h[j] = xor_byte0(h[j], w[j][d]) * kFnvMul;
+#pragma unroll
+        for (int j = 0; j < 4; j++) h[j] = xor_byte1(h[j], w[j][d]) * kFnvMul;
+#pragma unroll
+        for (int j = 0; j < 4; j++) h[j] = xor_byte2(h[j], w[j][d]) * kFnvMul;
+#pragma unroll
+        for (int j = 0; j < 4; j++) h[j] = xor_byte3(h[j], w[j][d]) * kFnvMul;
+    }
 }
 
 // FNV of `len` more bytes at k (any alignment), continuing from h.  gfx950 runs in unaligned access mode,
@@ -175,13 +212,27 @@ __device__ __forceinline__ uint32_t lds_add(uint32_t *p, uint32_t v)
 
 
 // ------------------------------------------------------------------------------------------------------
-// pass 1: hash + partition with software write combining, no workgroup barrier in the loop
+// pass 1: hash + partition with software write combining: producer waves insert, consumer waves write out
 // ------------------------------------------------------------------------------------------------------
 constexpr int kPartThreads = 1024;                 // one workgroup per CU: the rings take most of the LDS
 constexpr int kPartWaves = kPartThreads / 64;
+#ifndef KTA_PART_CONSUMERS
+#define KTA_PART_CONSUMERS 4
+#endif
+#ifndef KTA_DBG_LEVEL
+#define KTA_DBG_LEVEL 0                            // ablation levels of tools/ubench_alive.hip; the library is built with 0
+#endif
+#ifndef KTA_PART_SLEEP
+#define KTA_PART_SLEEP 8
+#endif
+constexpr int kConsumers = KTA_PART_CONSUMERS;     // waves that move completed blocks from the rings to memory (one per SIMD)
+constexpr int kProducers = kPartWaves - kConsumers; // waves that stream, hash and insert
 constexpr uint32_t kTile = 256;                    // records of one wave step: four consecutive records per lane
 constexpr uint32_t kRing = 16;                     // pairs per bucket ring: two 64-byte blocks
-constexpr uint32_t kQueue = 128;                   // completed blocks a wave queues between two flushes
+static_assert(kConsumers >= 1 && kConsumers <= 8 && kProducers >= 1, "waves of the partition workgroup");
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
 
 struct TileCols {
     int4 kl, vl;
@@ -234,13 +285,24 @@ __device__ __forceinline__ uint32_t ring_at(uint32_t b, uint32_t p)
 // pool control words (device memory, zeroed before every launch pair)
 enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS = 3 };
 
-// pair = h << 32 | (batch-local index + 1) << 1 | alive       (index < 2^31 - 1: a pair is never zero)
+// pair = h << 32 | (batch-local index + 1) << 1 | alive       (index < 2^31 - 1: the low word of a pair is never zero)
 //
-// Per bucket in LDS: a ring of 16 pairs (two blocks of 8 = 64 bytes), a position counter, and one word per
-// ring half = (times this half was written out) << 4 | (pairs of the current block that have arrived).
-// Position p of a bucket belongs to block p >> 3, which uses half (p >> 3) & 1 once that half has been
-// written out (p >> 4) times.  (All three in ONE 64-bit word, so that the atomic that reserves a position also
-// returns the half's state — one LDS round trip less per record — measured the same: 3.07 vs 3.08 ms at 2^28.)
+// Per bucket in LDS: a ring of 16 pairs (two blocks of 8 = 64 bytes) and two counters — `pos`, the positions handed
+// out, and `out`, the pairs written out to memory (a multiple of 8).  Position p belongs to block p >> 3 and may be
+// written once p - out < 16: the ring entry's previous tenant has left.  An entry is zero from the moment it leaves
+// until its next tenant arrives.
+//
+// The workgroup's waves have two jobs (round 4; before, every wave did both and spent more instructions and LDS
+// round trips on the hand-over — arrival counts, a queue of completed blocks, stores staged around the prefetches
+// because loads and stores share one in-order counter — than on the records):
+//   producers  stream the columns and keys, hash, and per record: one returning LDS atomic (its position), one
+//              read (`out`, requested together with the atomic), one 8-byte write.  Nothing else: no store ever
+//              enters their vmcnt, and which block is complete is not their business.
+//   consumers  (one per SIMD) sweep the counters of their buckets: a block all of whose positions are handed out
+//              (pos >> 3 > out >> 3) and all of whose entries are non-zero leaves — four lanes per block, one aligned
+//              64-byte store — its entries are zeroed, `out` advances by 8.  They never load from memory.
+// Whoever holds a position in the oldest unwritten block of a bucket never waits (p - out < 8), so that block
+// completes and leaves: no deadlock, wherever its writers sit.
 template <int BLOG2>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint32_t skip, uint32_t tiles_per_wg,
                                                                     unsigned long long *__restrict__ pairs,
@@ -250,15 +312,17 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                                                                     uint32_t *__restrict__ pool_hist)
 {
     constexpr uint32_t B = 1u << BLOG2;
+    static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
     KTA_PHASE_BEGIN;
     extern __shared__ __attribute__((aligned(128))) unsigned long long s_ring[];   // B x kRing pairs
-    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_ring + (size_t)B * kRing);
-    uint32_t *s_half = s_pos + B;
-    uint32_t *s_queue = s_half + 2 * B;
-    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        s_pos[b] = 0;
-        s_half[2 * b] = 0;
-        s_half[2 * b + 1] = 0;
+    uint2 *s_ctl = reinterpret_cast<uint2 *>(s_ring + (size_t)B * kRing);          // per bucket: x = pos, y = out
+    uint32_t *s_list = reinterpret_cast<uint32_t *>(s_ctl + B);                    // kConsumers x 64: the chunk's ready blocks
+    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done, [1] next tile of the walk
+    {
+        ulonglong2 *z = reinterpret_cast<ulonglong2 *>(s_ring);
+        for (uint32_t e = threadIdx.x; e < B * kRing / 2u; e += kPartThreads) z[e] = make_ulonglong2(0ull, 0ull);
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) s_ctl[b] = make_uint2(0u, 0u);
+        if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
     }
     __syncthreads();
     const uint32_t W = gridDim.x, w = blockIdx.x;
@@ -266,206 +330,194 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const uint64_t first = (uint64_t)w * tiles_per_wg;
     const uint64_t end = first + tiles_per_wg < ntiles ? first + tiles_per_wg : ntiles;
-    uint32_t *queue = s_queue + wave * kQueue;
-    uint32_t qn = 0;                                                              // wave-uniform
+    const uint64_t span = end > first ? end - first : 0u;
 
-    // Completed blocks leave in two halves.  take_blocks (end of a step): up to 48 queued blocks are read from
-    // their rings into registers — four lanes per block, 16 bytes each — and their ring halves are free again at
-    // once.  put_blocks (next step, right before that step's prefetch loads are issued): the registers are
-    // stored, whole aligned 64-byte blocks.  Loads and stores share one in-order counter (vmcnt): a store issued
-    // AFTER a prefetch load would be waited for together with it at the top of the next step, and a varying
-    // number of stores would hide the load from the compiler's count altogether.
-#ifndef KTA_PART_STAGE
-#define KTA_PART_STAGE 2
-#endif
-    constexpr uint32_t kTake = KTA_PART_STAGE;        // 16-block groups staged in registers at the end of a step
-    // (named registers, not arrays: indexed through the lambdas below, arrays ended up in scratch memory; the
-    // destination is kept as one word: its offset in 16-byte units, bit 31 = in the pool, all ones = none)
-    ulonglong2 st_d0, st_d1;
-    uint32_t st_o0 = ~0u, st_o1 = ~0u;
-    auto put_one = [&](const ulonglong2 &sd, uint32_t &so) __attribute__((always_inline)) {
-        if (so != ~0u) {
-            unsigned long long *base = so >> 31 ? pool : pairs;
-            *reinterpret_cast<ulonglong2 *>(base + (size_t)(so & 0x7FFFFFFFu) * 2u) = sd;
-        }
-        so = ~0u;
-    };
-    // one group of up to 16 queued blocks, four lanes per block: ring -> registers, the ring half is free again
-    auto take_one = [&](uint32_t i, ulonglong2 &sd, uint32_t &so) __attribute__((always_inline)) {
-        const uint32_t e = i * 16u + (lane >> 2), piece = lane & 3u;
-        const bool on = e < qn;
-        const uint32_t ent = queue[on ? e : 0u];
-        const uint32_t b = ent & (B - 1), k = ent >> BLOG2;                   // bucket, block number
-        sd = *reinterpret_cast<const ulonglong2 *>(s_ring + ring_at(b, k * 8u + piece * 2u));
-        uint32_t off;
-        if ((k + 1u) * 8u <= cap) {
-            off = (uint32_t)((((uint64_t)b * W + w) * cap + (uint64_t)k * 8u) >> 1);
-        } else {                                                              // the segment is full: to the pool
-            unsigned long long at = 0;
-            if (on && piece == 0u) {
-                at = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
-                atomicAdd(&pool_hist[b], 8u);
-            }
-            at = __shfl(at, (int)(lane & ~3u));
-            off = (uint32_t)(at >> 1) | 0x80000000u;
-        }
-        so = on ? off + piece : ~0u;
-        KTA_LDS_ORDER();
-        if (on && piece == 0u) lds_add(&s_half[2 * b + (k & 1u)], 16u - 8u);
-    };
-    auto drop_taken = [&](uint32_t groups) __attribute__((always_inline)) {      // the queue's first groups are gone
-        const uint32_t took = qn < 16u * groups ? qn : 16u * groups;
-        for (uint32_t e0 = took; e0 < qn; e0 += 64) {                             // the rest moves up
-            const uint32_t v = e0 + lane < qn ? queue[e0 + lane] : 0u;
-            KTA_LDS_ORDER();
-            if (e0 + lane < qn) queue[e0 + lane - took] = v;
-            KTA_LDS_ORDER();
-        }
-        qn -= took;
-    };
-    auto put_blocks = [&]() __attribute__((always_inline)) {                       // start of a step, before its prefetch loads
-        put_one(st_d0, st_o0);
-        put_one(st_d1, st_o1);
-        while (qn) {                                                                // what was not staged: ring -> memory
-            ulonglong2 d;
-            uint32_t o;
-            take_one(0, d, o);
-            put_one(d, o);
-            drop_taken(1);
-        }
-    };
-    auto take_blocks = [&]() __attribute__((always_inline)) {                      // end of a step
-        if (kTake >= 1) take_one(0, st_d0, st_o0);
-        if (kTake >= 2) take_one(1, st_d1, st_o1);
-        if (kTake) drop_taken(kTake);
-    };
-    auto flush_queue = [&]() __attribute__((always_inline)) { put_blocks(); };     // everything, now
-
-#ifdef KTA_DBG_NOLDS
-    long long dummy = 0;
-#endif
-    if (first + wave < end) {
+    if (wave < (uint32_t)kProducers) {
+        // ---------------------------------------------- producer ----------------------------------------------
         // Two-stage prefetch: the columns run two steps ahead of the hash, the key bytes (whose addresses come
         // from the columns) one step ahead — no load waits for another inside a step.  Two register sets
         // alternate (the loop is unrolled by two): copying "next" into "current" at the end of a step would
         // make the wave wait for the prefetch at the very place it was issued.
-        TileCols cols_a, cols_b;
-        TileKeys keys_a, keys_b;
         // The workgroup's range is walked from a start that differs from workgroup to workgroup (and around): the
         // ranges lie a power of two apart, and in step all workgroups would ask the same few memory channels.
-        const uint64_t span = end - first, rot = span > 64u ? ((uint64_t)w * 37u * kPartWaves) % span : 0u;
+        // Tiles are handed out by a counter: the waves of a SIMD that also runs a consumer get fewer.
+        const uint64_t rot = span > 64u ? ((uint64_t)w * 37u * kPartWaves) % span : 0u;
         auto at = [&](uint64_t i) __attribute__((always_inline)) -> uint64_t {   // i-th tile of this workgroup's walk
             const uint64_t r = i + rot;
             return first + (r < span ? r : r - span);
         };
-        uint64_t tile = wave;                            // index into the walk
-        load_cols(c, n, skip, at(tile), true, cols_a);
-        load_cols(c, n, skip, at(tile + kPartWaves < span ? tile + kPartWaves : tile), tile + kPartWaves < span, cols_b);
-        load_keys(c, cols_a, keys_a);
-        auto step = [&](TileCols &r, TileKeys &keys, TileCols &r_next, TileKeys &keys_next, uint64_t t) __attribute__((always_inline)) {
-            const int32_t kl[4] = {r.kl.x, r.kl.y, r.kl.z, r.kl.w}, vl[4] = {r.vl.x, r.vl.y, r.vl.z, r.vl.w};
-            const uint32_t ko[4] = {r.ko.x, r.ko.y, r.ko.z, r.ko.w};
-            uint32_t h[4];
-            unsigned long long pr[4];
-            bool keyed[4];
-            const uint64_t i0 = at(t) * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                keyed[j] = kl[j] >= 0;
-                h[j] = kl[j] > 0 ? fnv32_prefetched(keys.k[j], c.key_bytes + ko[j], (uint32_t)kl[j]) : kFnvInit;
-                pr[j] = ((unsigned long long)h[j] << 32) | ((unsigned long long)(i0 + j + 1) << 1) | (vl[j] >= 0 ? 1ull : 0ull);
-            }
-            KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
-            load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
-            load_cols(c, n, skip, at(t + 2 * kPartWaves < span ? t + 2 * kPartWaves : t), t + 2 * kPartWaves < span, r);   // r is spent: hashed
-            // The blocks taken at the end of the last step are stored AFTER this step's loads were issued: loads
-            // and stores share one in-order counter (vmcnt), and the compiler cannot count a varying number of
-            // stores — issued before the loads, the wait for "the columns that came before them" becomes a wait
-            // for the stores themselves.  Issued last, they are what a later vmcnt(N) lets pend.
-            put_blocks();
-#ifdef KTA_DBG_NOLDS   /* ablation build of tools/ubench_alive.hip only: stream + hash, nothing else */
-            dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
-            return;
-#endif
-            // Straight-line, so that a lane's four LDS atomics (and then its four reads) are in flight together.
-            uint32_t bk[4], p[4], hw[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) bk[j] = h[j] >> (32 - BLOG2);
-#pragma unroll
-            for (int j = 0; j < 4; j++) p[j] = keyed[j] ? lds_add(&s_pos[bk[j]], 1u) : 0u;
-            KTA_LDS_ORDER();
-#pragma unroll
-            for (int j = 0; j < 4; j++) hw[j] = s_half[2 * bk[j] + ((p[j] >> 3) & 1u)];   // plain reads: four in flight
-            KTA_LDS_ORDER();
-            KTA_PHASE(0, 1);   // positions + half words
-            uint32_t pending = 0;
-            bool done[4];
-            // insert record j at its position once its ring half is free; true when that completed the block
-            auto insert = [&](int j) __attribute__((always_inline)) -> bool {
-                s_ring[ring_at(bk[j], p[j])] = pr[j];
-                KTA_LDS_ORDER();
-                return (lds_add(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)], 1u) & 15u) == 7u;
-            };
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool free_now = (hw[j] >> 4) == (p[j] >> 4);          // (both below 2^17)
-                done[j] = false;
-                if (keyed[j]) {
-                    if (free_now) done[j] = insert(j);
-                    else pending |= 1u << j;
-                }
-            }
-            auto enqueue = [&]() __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (qn > kQueue - 64u) flush_queue();           // room for 64 more (wave-uniform)
-                    const unsigned long long m = __ballot(done[j]);
-                    if (done[j]) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                        bk[j] | ((p[j] >> 3) << BLOG2);
-                    qn += (uint32_t)__popcll(m);
-                    done[j] = false;
-                }
-                KTA_LDS_ORDER();
-            };
-            KTA_PHASE(0, 2);   // inserts
-            enqueue();
-            KTA_PHASE(0, 3);   // queueing
-            take_blocks();   // every step: a completed block frees its ring half when it leaves the ring
-            KTA_PHASE(0, 5);   // ring -> registers
-            // Rare: a position whose ring half still holds the block before last (sixteen arrivals of one
-            // bucket in flight).  Whoever holds a position in an older block never waits for a younger one, so
-            // the oldest unwritten block always completes; its writers may sit in this very wave, which is why
-            // the loop body carries the whole protocol (insert, queue, write out).
-            while (__any(pending != 0u)) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!((pending >> j) & 1u)) continue;
-                    const uint32_t word = __hip_atomic_load(&s_half[2 * bk[j] + ((p[j] >> 3) & 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((word >> 4) != (p[j] >> 4)) continue;
-                    done[j] = insert(j);
-                    pending &= ~(1u << j);
-                }
-                enqueue();
-                flush_queue();
-                __builtin_amdgcn_s_sleep(1);
-            }
-            KTA_PHASE(0, 4);   // waiting for a ring half
+        auto grab = [&]() __attribute__((always_inline)) -> uint64_t {           // the next tile of the walk (wave-uniform)
+            uint32_t g = 0;
+            if (lane == 0) g = lds_add(&s_misc[1], 1u);
+            return (uint64_t)__builtin_amdgcn_readfirstlane(g);
         };
-        for (;; tile += 2 * kPartWaves) {
-            step(cols_a, keys_a, cols_b, keys_b, tile);
-            if (tile + kPartWaves >= span) break;
-            step(cols_b, keys_b, cols_a, keys_a, tile + kPartWaves);
-            if (tile + 2 * kPartWaves >= span) break;
-        }
-        flush_queue();
-    }
-#ifdef KTA_DBG_NOLDS
-    if (dummy == 0x1234567) counts[0] = 1;
+#if KTA_DBG_LEVEL
+        long long dummy = 0;
 #endif
+        uint64_t t_a = grab(), t_b = grab();              // walk indices of the tiles in the two register sets
+        if (t_a < span) {
+            TileCols cols_a, cols_b;
+            TileKeys keys_a, keys_b;
+            load_cols(c, n, skip, at(t_a), true, cols_a);
+            load_cols(c, n, skip, at(t_b < span ? t_b : t_a), t_b < span, cols_b);
+            load_keys(c, cols_a, keys_a);
+            // one step: hash the tile in (r, keys) — walk index t — and insert its pairs; request the key bytes of the
+            // next tile (its columns were requested a step ago) and the columns of the tile after that, into r
+            auto step = [&](TileCols &r, TileKeys &keys, uint64_t &t, TileCols &r_next, TileKeys &keys_next) __attribute__((always_inline)) {
+                const int32_t kl[4] = {r.kl.x, r.kl.y, r.kl.z, r.kl.w}, vl[4] = {r.vl.x, r.vl.y, r.vl.z, r.vl.w};
+                const uint32_t ko[4] = {r.ko.x, r.ko.y, r.ko.z, r.ko.w};
+                uint32_t h[4];
+                unsigned long long pr[4];
+                bool keyed[4];
+                const uint64_t i0 = at(t) * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
+                const uint64_t t_new = grab();                                    // (its latency hides behind the hashing)
+                // keys of one length are the common case (ids, UUIDs, fixed-width numbers): when every key of the tile
+                // has 16 bytes the wave takes the straight-line chain, without a branch per key
+                if (__all(kl[0] == 16 && kl[1] == 16 && kl[2] == 16 && kl[3] == 16)) {
+                    fnv_16x4(h, keys.k);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        h[j] = kl[j] > 0 ? fnv32_prefetched(keys.k[j], c.key_bytes + ko[j], (uint32_t)kl[j]) : kFnvInit;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    keyed[j] = kl[j] >= 0;
+                    pr[j] = ((unsigned long long)h[j] << 32) | ((unsigned long long)(i0 + j + 1) << 1) | (vl[j] >= 0 ? 1ull : 0ull);
+                }
+                KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
+                load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
+                t = t_new;
+                load_cols(c, n, skip, at(t < span ? t : 0u), t < span, r);   // r is spent: hashed
+#if KTA_DBG_LEVEL == 1   /* ablation builds of tools/ubench_alive.hip only.  1: stream + hash, nothing else */
+                dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
+                return;
+#endif
+                // Straight-line, so that a lane's four LDS atomics and its four reads are in flight together.
+                uint32_t bk[4], p[4], out[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bk[j] = h[j] >> (32 - BLOG2);
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = keyed[j] ? lds_add(&s_ctl[bk[j]].x, 1u) : 0u;
+#if KTA_DBG_LEVEL == 2   /* 2: + the position atomics */
+                dummy += (long long)(p[0] + p[1] + p[2] + p[3]) + (long long)pr[0] + (long long)pr[1] + (long long)pr[2] + (long long)pr[3];
+                return;
+#endif
+#pragma unroll
+                for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if KTA_DBG_LEVEL == 3   /* 3: + the reads of `out` and the ring writes, never waiting; no consumers */
+#pragma unroll
+                for (int j = 0; j < 4; j++) out[j] = p[j] - (out[j] & 7u);
+#endif
+                KTA_LDS_ORDER();
+                uint32_t pending = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (keyed[j]) {
+                        // (`out` may have been read before the position was handed out: it only grows, so an old
+                        // reading errs on the side of waiting)
+                        if (p[j] - out[j] < kRing) s_ring[ring_at(bk[j], p[j])] = pr[j];
+                        else pending |= 1u << j;
+                    }
+                }
+                KTA_PHASE(0, 1);   // positions + inserts
+                // Rare: sixteen arrivals of one bucket since its last block left.  The consumers write the oldest
+                // block out as soon as it is complete, and whoever holds a position in it never waits.
+                while (__any(pending != 0u)) {
+                    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!((pending >> j) & 1u)) continue;
+                        const uint32_t o = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (p[j] - o >= kRing) continue;
+                        KTA_LDS_ORDER();
+                        s_ring[ring_at(bk[j], p[j])] = pr[j];
+                        pending &= ~(1u << j);
+                    }
+                }
+                KTA_PHASE(0, 4);   // waiting for a ring half
+            };
+            for (;;) {
+                step(cols_a, keys_a, t_a, cols_b, keys_b);
+                if (t_b >= span) break;
+                step(cols_b, keys_b, t_b, cols_a, keys_a);
+                if (t_a >= span) break;
+            }
+        }
+#if KTA_DBG_LEVEL
+        if (dummy == 0x1234567) counts[0] = 1;
+#endif
+        KTA_LDS_ORDER();
+        if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
+    } else {
+        // ---------------------------------------------- consumer ----------------------------------------------
+        constexpr uint32_t kChunks = B / (64u * kConsumers);
+        const uint32_t cw = wave - (uint32_t)kProducers;
+        uint32_t *list = s_list + cw * 64u;
+        for (;;) {
+#if KTA_DBG_LEVEL >= 1 && KTA_DBG_LEVEL <= 3
+            break;
+#endif
+            const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
+            KTA_LDS_ORDER();
+            bool any_ready = false;                                               // wave-uniform
+            for (uint32_t ch = 0; ch < kChunks; ch++) {
+                const uint32_t b = (cw * kChunks + ch) * 64u + lane;
+                const unsigned long long ctl = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&s_ctl[b]), __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t pos = (uint32_t)ctl, out = (uint32_t)(ctl >> 32);
+                const bool ready = (pos >> 3) > (out >> 3);                        // every position of block out >> 3 is handed out
+                const unsigned long long m = __ballot(ready);
+                if (m == 0ull) continue;
+                any_ready = true;
+                const uint32_t nready = (uint32_t)__popcll(m);
+                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | ((out >> 3) << BLOG2);
+                KTA_LDS_ORDER();
+                for (uint32_t g0 = 0; g0 < nready; g0 += 16u) {                    // sixteen blocks at a time, four lanes per block
+                    const uint32_t e = g0 + (lane >> 2), piece = lane & 3u;
+                    const bool on = e < nready;
+                    const uint32_t ent = list[on ? e : 0u];
+                    const uint32_t bb = ent & (B - 1), k = ent >> BLOG2;           // bucket, block number
+                    ulonglong2 *src = reinterpret_cast<ulonglong2 *>(s_ring + ring_at(bb, k * 8u + piece * 2u));
+                    const ulonglong2 d = *src;
+                    KTA_LDS_ORDER();
+                    const unsigned long long vm = __ballot(on && (uint32_t)d.x != 0u && (uint32_t)d.y != 0u);
+                    const bool go = ((uint32_t)(vm >> (lane & ~3u)) & 15u) == 15u;  // all eight pairs have arrived
+                    if (go) {
+                        // ONE 16-byte store per lane, its address selected (stores in both arms of a branch were split into
+                        // two 8-byte stores each, one hoisted past the join)
+                        unsigned long long *dst;
+                        if ((k + 1u) * 8u <= cap) {
+                            dst = pairs + ((uint64_t)bb * W + w) * cap + (uint64_t)k * 8u;
+                        } else {                                                   // the segment is full: to the pool
+                            unsigned long long at_pool = 0;
+                            if (piece == 0u) {
+                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
+                                atomicAdd(&pool_hist[bb], 8u);
+                            }
+                            dst = pool + __shfl(at_pool, (int)(lane & ~3u));
+                        }
+#if KTA_DBG_LEVEL == 4   /* 4: the whole protocol, but the blocks are not stored */
+                        if (d.x == 0x1234567ull)
+#endif
+                        *reinterpret_cast<v2ull *>(dst + piece * 2u) = (v2ull){d.x, d.y};
+                        *src = make_ulonglong2(0ull, 0ull);
+                        KTA_LDS_ORDER();
+                        if (piece == 0u) lds_add(&s_ctl[bb].y, 8u);               // after the zeroes (program order)
+                    }
+                }
+                KTA_LDS_ORDER();
+            }
+            if (!any_ready) {
+                if (done == (uint32_t)kProducers) break;                          // nothing left that is complete
+                __builtin_amdgcn_s_sleep(KTA_PART_SLEEP);
+            }
+        }
+    }
     __syncthreads();
     // the last, partial block of every segment, and the segment fills for pass 2
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        const uint32_t f = s_pos[b], k = f >> 3, rem = f & 7u;
+        const uint32_t f = s_ctl[b].x, k = f >> 3, rem = f & 7u;
         if (rem) {
             unsigned long long *dst;
             if ((k + 1u) * 8u <= cap) {
@@ -484,11 +536,330 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 }
 
 // ------------------------------------------------------------------------------------------------------
+// pass 1, bit set state: the same partition with 4-byte pairs whose order is implicit
+// ------------------------------------------------------------------------------------------------------
+// What pass 1 costs is the scattered 64-byte stores of the pairs, not the LDS protocol and not the hash (measured:
+// stream + hash 1.26 ms, + protocol 1.42 ms, + stores 2.34 ms at 2^28 records with 8-byte pairs; 1.76 ms with half
+// the bytes).  An 8-byte pair is half index.  The bit set state needs no index — only, per slot, WHICH pair is the
+// newest — so its pairs carry none:
+//
+//   pair32 = slot-in-bucket (22 bits) << 10 | alive << 9 | window (1 ... 255: never zero)
+//
+// and the order of two pairs of one slot is the order of (workgroup w, producer v, position in the segment):
+//   * workgroup w takes a contiguous range of the batch (older than w + 1's), and inside it producer wave v takes a
+//     contiguous sub-range (older than v + 1's) and walks it in order;
+//   * the positions of ONE wave's pairs in a ring are handed out in program order (LDS operations of a wave are
+//     performed in order) — tile after tile, and inside a tile instruction j (records 64 j + lane) before j + 1;
+//   * inside one instruction the order of two lanes' atomics on one counter is the hardware's business, so no two
+//     records of one hash are ever inserted by the same instruction: every record first writes (signature, id) to
+//     a small per-wave guard table at an index taken from its hash and reads it back.  Exactly one record per
+//     index reads its own word and inserts; the others saw the winner's — a different signature means a different
+//     hash: they play again among themselves (16 of 256 on average; two or three rounds); the same signature
+//     (1/256, or a true repetition) fetches the winner's hash: equal, and the winner is the newer record ⇒ this one
+//     is superseded and DROPPED (exactly what the reference's insert / remove sequence leaves: metric.rs:289-304);
+//     equal and older ⇒ it goes in a later round, i.e. at a later position.
+// Hot keys — which used to fill their bucket's ring and stall the workgroup — mostly die in the guard.
+constexpr uint32_t kRing32 = 32;                   // pairs per bucket ring: two 64-byte blocks of 16
+constexpr uint32_t kGuard = 1024;                  // guard words (u16: signature << 8 | id) per producer wave
+constexpr uint32_t kPair32Shift = 10;
+
+__device__ __forceinline__ uint32_t ring32_at(uint32_t b, uint32_t p)   // (rows rotated by whole 16-byte pieces)
+{
+    return b * kRing32 + ((p + 4u * (b & 7u)) & (kRing32 - 1));
+}
+
+// order key of a pair of the bit set state (what pass 2 maximises per slot): segment w, producer v, position
+__device__ __forceinline__ uint32_t pair32_key(uint32_t w, uint32_t v, uint32_t cap, uint32_t pos)
+{
+    return (w * 256u + v) * cap + pos;             // (256 W cap = 0.28 n: below 2^27)
+}
+
+// a pool pair of the bit set state (segment overflow; they are ordered by their place in the pool, see the fallback)
+__device__ __forceinline__ unsigned long long pool_pair32(uint32_t bucket, uint32_t p32, uint32_t w, uint32_t RBITS)
+{
+    const uint32_t h = (bucket << RBITS) | (p32 >> kPair32Shift);
+    return ((unsigned long long)h << 32) | 0x80000000u | (w << 9) | ((p32 & 255u) << 1) | ((p32 >> 9) & 1u);   // w, window, alive
+}
+
+template <int BLOG2>
+__global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColumns c, uint64_t n, uint32_t tiles_per_wg,
+                                                                      uint32_t *__restrict__ pairs, uint32_t *__restrict__ counts,
+                                                                      uint32_t cap, unsigned long long *__restrict__ pool,
+                                                                      unsigned long long *__restrict__ pool_ctl,
+                                                                      uint32_t *__restrict__ pool_hist)
+{
+    constexpr uint32_t B = 1u << BLOG2;
+    constexpr uint32_t RBITS = 32 - BLOG2;
+    static_assert(RBITS == 32 - kPair32Shift, "a pair32 holds the hash bits below the bucket");
+    static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
+    extern __shared__ __attribute__((aligned(128))) uint32_t s_ring32[];           // B x kRing32 pairs
+    uint32_t *s_pos = s_ring32 + (size_t)B * kRing32;                              // positions handed out
+    unsigned short *s_out = reinterpret_cast<unsigned short *>(s_pos + B);         // pairs written out, modulo 2^16 (its consumer's)
+    unsigned short *s_guard = s_out + B;                                           // kProducers x kGuard
+    uint32_t *s_list = reinterpret_cast<uint32_t *>(s_guard + (size_t)kProducers * kGuard);   // kConsumers x 64
+    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_ring32);
+        for (uint32_t e = threadIdx.x; e < B * kRing32 / 4u; e += kPartThreads) z[e] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+            s_pos[b] = 0u;
+            s_out[b] = 0;
+        }
+        if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    const uint32_t W = gridDim.x, w = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t ntiles = (n + kTile - 1) / kTile;
+    const uint64_t first = (uint64_t)w * tiles_per_wg;
+    const uint64_t end = first + tiles_per_wg < ntiles ? first + tiles_per_wg : ntiles;
+
+    if (wave < (uint32_t)kProducers) {
+        // ---------------------------------------------- producer ----------------------------------------------
+        const uint32_t v = wave;
+        unsigned short *guard = s_guard + v * kGuard;
+        // instruction j of a step handles the records 64 j + lane of the tile: 4-byte loads, 256 bytes per
+        // instruction and column.  Unconditional (index clamped into the batch, result masked), two steps ahead; the
+        // key bytes — whose addresses come from the columns — one step ahead; two register sets alternate.
+        struct Cols {
+            int32_t kl[4], vl[4];
+            uint32_t ko[4];
+            uint32_t win;                                  // the tile's window (wave-uniform); 0: no tile
+        };
+        auto load_cols32 = [&](uint64_t tile, bool ok, Cols &r) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = tile * kTile + 64u * j + lane;
+                const bool in = ok && i < n;
+                const uint64_t ic = in ? i : n - 1;
+                r.kl[j] = c.key_len[ic];
+                r.vl[j] = c.val_len[ic];
+                r.ko[j] = c.key_off[ic];
+                r.kl[j] = in ? r.kl[j] : -1;               // key None: ignored (metric.rs:302)
+            }
+        };
+        auto load_keys32 = [&](const Cols &r, uint4 (&k)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) __builtin_memcpy(&k[j], c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u), 16);
+        };
+        // The workgroup's range is cut into (at most 255) windows of consecutive tiles, and the waves take them as they
+        // come (a counter in LDS; from a start that differs from workgroup to workgroup, and around: the ranges lie a
+        // power of two apart, and in step all workgroups would ask the same few memory channels).  A window is
+        // walked by ONE wave, in order, and its number — its place in the range, not the order of the taking — is
+        // what the pairs carry.
+        const uint64_t span = end > first ? end - first : 0u;
+        const uint32_t wtiles = (uint32_t)((span + 254u) / 255u);                 // tiles per window
+        const uint32_t nwin = wtiles ? (uint32_t)((span + wtiles - 1u) / wtiles) : 0u;
+        const uint32_t woff = nwin ? (w * 37u) % nwin : 0u;
+        uint64_t cur_tile = 0, cur_stop = 0;                                     // the walk's cursor (wave-uniform)
+        uint32_t cur_win = 0;
+        auto next_tile = [&](uint64_t &tile, uint32_t &win) __attribute__((always_inline)) {   // win = 0: the range is used up
+            if (cur_tile + 1 < cur_stop) {
+                cur_tile++;
+            } else {
+                uint32_t g = 0;
+                if (lane == 0) g = lds_add(&s_misc[1], 1u);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g < nwin) {
+                    const uint32_t cw = g + woff < nwin ? g + woff : g + woff - nwin;
+                    cur_tile = first + (uint64_t)cw * wtiles;
+                    cur_stop = cur_tile + wtiles < end ? cur_tile + wtiles : end;
+                    cur_win = cw + 1u;
+                } else {
+                    cur_win = 0u;
+                    cur_stop = 0u;
+                    cur_tile = 0u;
+                }
+            }
+            tile = cur_tile;
+            win = cur_win;
+        };
+        {
+            Cols cols_a, cols_b;
+            uint4 keys_a[4], keys_b[4];
+            uint64_t tl;
+            next_tile(tl, cols_a.win);
+            load_cols32(tl, cols_a.win != 0u, cols_a);
+            next_tile(tl, cols_b.win);
+            load_cols32(tl, cols_b.win != 0u, cols_b);
+            load_keys32(cols_a, keys_a);
+            auto step = [&](Cols &r, uint4 (&keys)[4], Cols &r_next, uint4 (&keys_next)[4]) __attribute__((always_inline)) {
+                uint32_t h[4];
+                if (__all(r.kl[0] == 16 && r.kl[1] == 16 && r.kl[2] == 16 && r.kl[3] == 16)) {
+                    fnv_16x4(h, keys);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        h[j] = r.kl[j] > 0 ? fnv32_prefetched(keys[j], c.key_bytes + r.ko[j], (uint32_t)r.kl[j]) : kFnvInit;
+                }
+                uint32_t act = 0;                                    // bit j: record j still has to be inserted
+                uint32_t pr[4];
+                const uint32_t vv = r.win;                           // the window: what the order sees of the tile's place
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    act |= r.kl[j] >= 0 ? 1u << j : 0u;
+                    pr[j] = (h[j] << kPair32Shift) | (r.vl[j] >= 0 ? 1u << 9 : 0u) | vv;
+                }
+                load_keys32(r_next, keys_next);                      // their columns were requested a step ago
+                {
+                    uint64_t tn;
+                    next_tile(tn, r.win);
+                    load_cols32(tn, r.win != 0u, r);                 // r is spent: hashed
+                }
+                uint32_t bk[4], gk[4], gv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    bk[j] = h[j] >> RBITS;
+                    gk[j] = h[j] & (kGuard - 1);                     // (bits 0..9: any function of the hash will do)
+                    gv[j] = (((h[j] >> 10) & 0xFFu) << 8) | ((uint32_t)j << 6) | lane;   // signature, id = the record's place in the tile
+                }
+                do {
+                    // ---- the guard: one winner per guard index among the records still in play ----
+                    uint32_t seen[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((act >> j) & 1u) guard[gk[j]] = (unsigned short)gv[j];
+                    KTA_LDS_ORDER();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) seen[j] = guard[gk[j]];
+                    KTA_LDS_ORDER();
+                    uint32_t win = 0, twin = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool on = (act >> j) & 1u;
+                        if (on && seen[j] == gv[j]) win |= 1u << j;
+                        else if (on && ((seen[j] ^ gv[j]) >> 8) == 0u) twin |= 1u << j;   // the winner has this record's signature
+                    }
+                    if (__any(twin != 0u)) {                          // rare: look at the winner's whole hash
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int wl = (int)(seen[j] & 63u);
+                            const uint32_t wj = (seen[j] >> 6) & 3u;
+                            const uint32_t h0 = __shfl(h[0], wl), h1 = __shfl(h[1], wl), h2 = __shfl(h[2], wl), h3 = __shfl(h[3], wl);
+                            const uint32_t hw = wj == 0u ? h0 : (wj == 1u ? h1 : (wj == 2u ? h2 : h3));
+                            // the same key later in the tile supersedes this record; earlier: this one goes in after it
+                            if (((twin >> j) & 1u) && hw == h[j] && (seen[j] & 0xFFu) > (gv[j] & 0xFFu)) act &= ~(1u << j);
+                        }
+                    }
+                    // ---- the winners insert: positions, then the pairs once their ring entries are free ----
+                    uint32_t p[4], out[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) p[j] = (win >> j) & 1u ? lds_add(&s_pos[bk[j]], 1u) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    KTA_LDS_ORDER();
+                    uint32_t pending = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((win >> j) & 1u) {
+                            // (`out` may have been read before the position was handed out: it only grows, so an old
+                            // reading errs on the side of waiting; differences are taken modulo 2^16)
+                            if (((p[j] - out[j]) & 0xFFFFu) < kRing32) s_ring32[ring32_at(bk[j], p[j])] = pr[j];
+                            else pending |= 1u << j;
+                        }
+                    }
+                    while (__any(pending != 0u)) {                    // rare: 32 arrivals of one bucket since its last block left
+                        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (!((pending >> j) & 1u)) continue;
+                            const uint32_t o = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (((p[j] - o) & 0xFFFFu) >= kRing32) continue;
+                            KTA_LDS_ORDER();
+                            s_ring32[ring32_at(bk[j], p[j])] = pr[j];
+                            pending &= ~(1u << j);
+                        }
+                    }
+                    act &= ~win;
+                } while (__any(act != 0u));
+            };
+            while (cols_a.win != 0u) {
+                step(cols_a, keys_a, cols_b, keys_b);
+                if (cols_b.win == 0u) break;
+                step(cols_b, keys_b, cols_a, keys_a);
+            }
+        }
+        KTA_LDS_ORDER();
+        if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
+    } else {
+        // ---------------------------------------------- consumer ----------------------------------------------
+        constexpr uint32_t kChunks = B / (64u * kConsumers);
+        const uint32_t cw = wave - (uint32_t)kProducers;
+        uint32_t *list = s_list + cw * 64u;
+        for (;;) {
+            const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
+            KTA_LDS_ORDER();
+            bool any_ready = false;                                               // wave-uniform
+            for (uint32_t ch = 0; ch < kChunks; ch++) {
+                const uint32_t b = (cw * kChunks + ch) * 64u + lane;
+                const uint32_t pos = __hip_atomic_load(&s_pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t have = (pos - s_out[b]) & 0xFFFFu;                  // handed out and not yet written out
+                const bool ready = have >= 16u;                                    // every position of the oldest block is handed out
+                const unsigned long long m = __ballot(ready);
+                if (m == 0ull) continue;
+                any_ready = true;
+                const uint32_t nready = (uint32_t)__popcll(m);
+                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | (((pos - have) >> 4) << BLOG2);
+                KTA_LDS_ORDER();
+                for (uint32_t g0 = 0; g0 < nready; g0 += 16u) {                    // sixteen blocks at a time, four lanes per block
+                    const uint32_t e = g0 + (lane >> 2), piece = lane & 3u;
+                    const bool on = e < nready;
+                    const uint32_t ent = list[on ? e : 0u];
+                    const uint32_t bb = ent & (B - 1), k = ent >> BLOG2;           // bucket, block number
+                    uint4 *src = reinterpret_cast<uint4 *>(s_ring32 + ring32_at(bb, k * 16u + piece * 4u));
+                    const uint4 d = *src;
+                    KTA_LDS_ORDER();
+                    const unsigned long long vm = __ballot(on && d.x != 0u && d.y != 0u && d.z != 0u && d.w != 0u);
+                    const bool go = ((uint32_t)(vm >> (lane & ~3u)) & 15u) == 15u;  // all sixteen pairs have arrived
+                    if (go) {
+                        if ((k + 1u) * 16u <= cap) {
+                            *reinterpret_cast<v4u *>(pairs + ((uint64_t)bb * W + w) * cap + (uint64_t)k * 16u + piece * 4u) = (v4u){d.x, d.y, d.z, d.w};
+                        } else {                                                   // the segment is full: to the pool, with what a pair32 leaves implicit
+                            unsigned long long at_pool = 0;
+                            if (piece == 0u) {
+                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], 16ull);
+                                atomicAdd(&pool_hist[bb], 16u);
+                            }
+                            unsigned long long *dst = pool + __shfl(at_pool, (int)(lane & ~3u)) + piece * 4u;
+                            *reinterpret_cast<v2ull *>(dst) = (v2ull){pool_pair32(bb, d.x, w, RBITS), pool_pair32(bb, d.y, w, RBITS)};
+                            *reinterpret_cast<v2ull *>(dst + 2) = (v2ull){pool_pair32(bb, d.z, w, RBITS), pool_pair32(bb, d.w, w, RBITS)};
+                        }
+                        *src = make_uint4(0u, 0u, 0u, 0u);
+                        KTA_LDS_ORDER();
+                        if (piece == 0u) s_out[bb] = (unsigned short)((k + 1u) * 16u);   // after the zeroes (program order); its only writer
+                    }
+                }
+                KTA_LDS_ORDER();
+            }
+            if (!any_ready) {
+                if (done == (uint32_t)kProducers) break;                          // nothing left that is complete
+                __builtin_amdgcn_s_sleep(KTA_PART_SLEEP);
+            }
+        }
+    }
+    __syncthreads();
+    // the last, partial block of every segment, and the segment fills for pass 2
+    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+        const uint32_t f = s_pos[b], k = f >> 4, rem = f & 15u;
+        if (rem) {
+            if ((k + 1u) * 16u <= cap) {
+                uint32_t *dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 16u;
+                for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring32[ring32_at(b, k * 16u + q)];
+            } else {
+                // an even number of pairs: the pool is read in 16-byte units (a zero pair is no pair)
+                unsigned long long *dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)((rem + 1u) & ~1u));
+                atomicAdd(&pool_hist[b], rem);
+                if (rem & 1u) dst[rem] = 0ull;
+                for (uint32_t q = 0; q < rem; q++) dst[q] = pool_pair32(b, s_ring32[ring32_at(b, k * 16u + q)], w, RBITS);
+            }
+        }
+        counts[(uint64_t)b * W + w] = f < cap ? f : cap;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // pass 2: per-bucket merge in LDS, then the survivors go to the bucket's region
 // ------------------------------------------------------------------------------------------------------
-#ifndef KTA_APPLY_SITES
-#define KTA_APPLY_SITES 2                          // merge sites in the driver loop (1: not yet measured)
-#endif
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr int kApplyUnroll = 2;                    // 16-byte loads of a unit: 256 pairs, 4 per lane
@@ -768,13 +1139,16 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // A wave reads its segments in units of kApplyUnroll 16-byte loads per lane = 256 pairs, masked by the segment's
     // fill (cap is a multiple of 128).
     // The loads of unit u + 1 are issued before unit u is merged, so a wave always has a unit in flight.
+    // (bit set state: 4-byte pairs, ONE 16-byte load of a lane is its four pairs of the unit; cap is a multiple of 256)
     const unsigned long long *region_pairs = pairs + (uint64_t)b * W * cap;
-    const uint32_t loads = cap >> 7;
-    const uint32_t chunks = (loads + kApplyUnroll - 1) / kApplyUnroll;
+    const uint32_t *region_pairs32 = reinterpret_cast<const uint32_t *>(pairs) + (uint64_t)b * W * cap;
+    const uint32_t loads = BITMAP ? cap >> 8 : cap >> 7;
+    const uint32_t chunks = BITMAP ? loads : (loads + kApplyUnroll - 1) / kApplyUnroll;
     const uint32_t groups = (W + kApplyWaves - 1) / kApplyWaves;
     const uint32_t units = groups * chunks;                                     // the same for every wave
     ulonglong2 p[kApplyUnroll], pn[kApplyUnroll];
-    uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2
+    uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2 (bit set state: [0] = 0..4, [1] = the
+                                                     // order key of the lane's first pair without its producer: see pair32_key)
     // Which segment a unit reads: in careful mode wave v takes the segments v, v + 16, ... (every group of 16 is
     // older than the next); in the fast attempt the order does not matter and the waves take whatever segment is
     // next (they finish together instead of waiting for whoever had the slow records).
@@ -788,18 +1162,26 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 if (lane == 0) g = lds_add(&sh.next_seg, 1u);
                 seg = __builtin_amdgcn_readfirstlane(g);
                 const uint32_t c = __builtin_amdgcn_readfirstlane(s_cnt[seg < W ? seg : 0u]);
-                seg_units = (c + 128u * kApplyUnroll - 1u) / (128u * kApplyUnroll);
+                seg_units = (c + 255u) / 256u;                                   // (128 x kApplyUnroll = 256 pairs either way)
                 if (seg_units == 0u) seg_units = 1u;
                 seg_unit = 0;
             }
-            r0 = seg_unit * kApplyUnroll;
+            r0 = seg_unit * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
             seg_unit++;
         } else {
-            r0 = (u % chunks) * kApplyUnroll;
+            r0 = (u % chunks) * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
             seg = (u / chunks) * kApplyWaves + wave;
         }
         const bool on = seg < W && (dynamic || u < units);
         const uint32_t cnt = on ? s_cnt[on ? seg : 0u] : 0u;
+        if (BITMAP) {
+            const uint32_t *sp = region_pairs32 + (uint64_t)(on ? seg : 0u) * cap;
+            const uint32_t k = (r0 << 8) + 4u * lane;
+            qv[0] = r0 < loads && k < cnt ? (cnt - k >= 4u ? 4u : cnt - k) : 0u;
+            qv[1] = pair32_key(on ? seg : 0u, 0u, cap, k);
+            q[0] = *reinterpret_cast<const ulonglong2 *>(sp + (qv[0] ? k : 4u * lane));   // unconditional, as below
+            return;
+        }
         const unsigned long long *sp = region_pairs + (uint64_t)(on ? seg : 0u) * cap;
 #pragma unroll
         for (int x = 0; x < kApplyUnroll; x++) {
@@ -893,8 +1275,21 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // `edge`: nothing may stay queued past this unit (the one-site driver's last unit of a trip).
     auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par, bool edge) __attribute__((always_inline)) {
         static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the empty queue");
-        const unsigned long long pr[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
-        const bool valid[4] = {qv[0] > 0u, qv[0] > 1u, qv[1] > 0u, qv[1] > 1u};
+        // the lane's four pairs as (slot in the bucket, value to maximise): value = order << 1 | alive
+        unsigned long long pr[4];
+        bool valid[4];
+        if (BITMAP) {
+            const uint32_t w32[4] = {(uint32_t)q[0].x, (uint32_t)(q[0].x >> 32), (uint32_t)q[0].y, (uint32_t)(q[0].y >> 32)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                valid[i] = (uint32_t)i < qv[0];
+                const uint32_t key = qv[1] + (uint32_t)i + (w32[i] & 255u) * cap;
+                pr[i] = ((unsigned long long)(w32[i] >> kPair32Shift) << 32) | (key << 1) | ((w32[i] >> 9) & 1u);
+            }
+        } else {
+            pr[0] = q[0].x, pr[1] = q[0].y, pr[2] = q[1].x, pr[3] = q[1].y;
+            valid[0] = qv[0] > 0u, valid[1] = qv[0] > 1u, valid[2] = qv[1] > 0u, valid[3] = qv[1] > 1u;
+        }
         uint32_t set[4], tag[4], hr[4];
         uint4 t[4];
 #pragma unroll
@@ -955,26 +1350,12 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         while (dynamic ? seg < W : u < units) {
             if (!careful && sh.fail[0]) break;            // (fast attempt) some wave ran out of room: stop early
             issue(u + 1, pn, nvn);
-#if KTA_APPLY_SITES == 1   /* experiment (tools/ab_alive.sh): one merge site, the prefetched unit copied over, and */
-            {              /* the long way of new slots (drain -> merge_new) inlined once instead of three times    */
-                // the queued misses are in before anybody looks at the table as a whole: the trip's last unit flushes
-                const bool edge = (dynamic ? seg >= W : u + 1u >= units) || (careful && (u + 1u) % chunks == 0u);
-                merge(p, nv, par, edge);
-#pragma unroll
-                for (int x = 0; x < kApplyUnroll; x++) {
-                    p[x] = pn[x];
-                    nv[x] = nvn[x];
-                }
-                u += 1;
-            }
-#else
             merge(p, nv, par, false);
             issue(u + 2, p, nv);
             merge(pn, nvn, par, false);
             u += 2;
             // the queued misses are in before anybody looks at the table as a whole
             if ((dynamic ? seg >= W : u >= units) || (careful && u % chunks == 0u)) drain(par);
-#endif
             KTA_PHASE(1, 3);
             if (careful && u % chunks == 0u && u < units) {
 #pragma unroll
@@ -1073,12 +1454,15 @@ __global__ __launch_bounds__(kWG) void kta_alive_pool_direct(const unsigned long
     add_running(delta, running, s_w);
 }
 
-// Bitmap state: the buckets pass 2 gave up (fail_from[b] != kNoFail), exactly, whatever they hold: the
-// bucket's region in sub-ranges of 2^15 slots, each resolved in a direct-indexed LDS array (largest index per
+// Bit set state: the buckets pass 2 gave up (fail_from[b] != kNoFail), exactly, whatever they hold: the
+// bucket's region in sub-ranges of 2^14 slots, each resolved in a direct-indexed LDS array (the newest pair per
 // slot) over ALL pairs of the bucket from segment fail_from[b] on plus the bucket's pool pairs.  Slow (every
 // pass re-reads the bucket's pairs) and only ever needed by batches that defeat the sizes of pass 1 / 2.
+// Order of two pairs of a slot: (segment w, producer v, in the pool?, position) — a segment's blocks go to the pool
+// once it is full, in order, by the one consumer wave that owns the bucket: a pool pair is newer than every pair
+// of its producer in the segment, and among a segment's pool pairs the pool index grows with the position.
 template <int BLOG2>
-__global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const unsigned long long *__restrict__ pairs,
+__global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32_t *__restrict__ pairs,
                                                                     const uint32_t *__restrict__ counts, uint32_t cap,
                                                                     uint32_t W, const unsigned long long *__restrict__ pool,
                                                                     const unsigned long long *__restrict__ pool_ctl,
@@ -1087,8 +1471,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const unsign
                                                                     long long *__restrict__ running)
 {
     constexpr uint32_t RBITS = 32 - BLOG2;
-    constexpr uint32_t kSub = 1u << 15;                  // slots per pass
-    extern __shared__ __attribute__((aligned(128))) uint32_t s_max[];   // kSub values
+    constexpr uint32_t kSub = 1u << 14;                  // slots per pass
+    extern __shared__ __attribute__((aligned(128))) unsigned long long s_max[];   // kSub values: order << 1 | alive
     __shared__ long long s_w[kApplyWaves];
     if (pool_ctl[POOL_FAILED] == 0ull) return;
     const uint32_t b = blockIdx.x, from = fail_from[b];
@@ -1097,30 +1481,36 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const unsign
     uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
     long long delta = 0;
     for (uint32_t r = 0; r < (1u << RBITS) / kSub; r++) {
-        for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0u;
+        for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0ull;
         __syncthreads();
         for (uint32_t w = from; w < W; w++) {
             const uint32_t cnt = counts[(uint64_t)b * W + w];
-            const unsigned long long *seg = pairs + ((uint64_t)b * W + w) * cap;
+            const uint32_t *seg = pairs + ((uint64_t)b * W + w) * cap;
             for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) {
-                const unsigned long long pr = seg[k];
-                const uint32_t h = (uint32_t)(pr >> 32) & ((1u << RBITS) - 1u);
-                if (h / kSub == r) atomicMax(&s_max[h % kSub], (uint32_t)pr);
+                const uint32_t p32 = seg[k];
+                const uint32_t h = p32 >> kPair32Shift;
+                if (h / kSub != r) continue;
+                const unsigned long long order = ((unsigned long long)(w * 256u + (p32 & 255u)) << 30) | k;
+                atomicMax(&s_max[h % kSub], (order << 1) | ((p32 >> 9) & 1u));
             }
         }
         for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
             const unsigned long long pr = pool[k];
-            const uint32_t hh = (uint32_t)(pr >> 32);
+            const uint32_t hh = (uint32_t)(pr >> 32), lo = (uint32_t)pr;
             if (pr == 0ull || (hh >> RBITS) != b) continue;
             const uint32_t h = hh & ((1u << RBITS) - 1u);
-            if (h / kSub == r) atomicMax(&s_max[h % kSub], (uint32_t)pr);
+            if (h / kSub != r) continue;
+            const uint32_t w = (lo >> 9) & 1023u;
+            if (w < from) continue;                      // (an instalment that pass 2 finished held no pool pairs: never true)
+            const unsigned long long order = ((unsigned long long)(w * 256u + ((lo >> 1) & 255u)) << 30) | (1ull << 29) | k;
+            atomicMax(&s_max[h % kSub], (order << 1) | (lo & 1u));
         }
         __syncthreads();
         for (uint32_t wd = threadIdx.x; wd < kSub / 32; wd += kApplyThreads) {
             uint32_t set_m = 0, clr_m = 0;
             for (uint32_t bit = 0; bit < 32; bit++) {
-                const uint32_t v = s_max[wd * 32 + bit];
-                if (v) (v & 1u ? set_m : clr_m) |= 1u << bit;
+                const unsigned long long v = s_max[wd * 32 + bit];
+                if (v) (v & 1ull ? set_m : clr_m) |= 1u << bit;
             }
             if (set_m | clr_m) {
                 uint32_t *word = region + (size_t)r * (kSub / 32) + wd;
@@ -1177,8 +1567,42 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     uint32_t *hist = reinterpret_cast<uint32_t *>(ctl + POOL_WORDS);
     uint32_t *flag = hist + B;
     const bool bitmap = st.bitmap != nullptr;
+    if (bitmap != pl.pair32) return hipErrorInvalidValue;      // the plan sized the workspace for the other pair format
+    const size_t lds2 = (size_t)kEntries * 6 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
+                        (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8;   // the slice area doubles as the waves' miss queues
+    if (bitmap) {
+        // 4-byte pairs; 4-byte column loads: any alignment of the columns will do
+        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard * 2 + (size_t)kConsumers * 64 * 4 + 16;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_partition32<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
+                           reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+#ifdef KTA_DBG_PART_ONLY
+        return e;
+#endif
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+                           pl.segment_wgs, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
+                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, (const uint32_t *)nullptr,
+                           WrittenList{nullptr, nullptr, 0});
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const size_t lds3 = (size_t)8 << 14;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_fallback<BLOG2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, reinterpret_cast<const uint32_t *>(pp),
+                           ws.counts, pl.cap, pl.segment_wgs, pool, ctl, ws.fail_from, st.bitmap, run);
+        return hipGetLastError();
+    }
+    // table state: 8-byte pairs (the survivors' sequence numbers come from their batch-local indices)
     const uint32_t *skip = nullptr;
-    if (c.seq && !bitmap) {
+    if (c.seq) {
         hipLaunchKernelGGL(kta_seq_ascending, dim3(1024), dim3(kWG), 0, s, c.seq, n, flag);
         skip = flag;
     }
@@ -1191,7 +1615,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     ca.key_len -= head;
     ca.val_len -= head;
     ca.key_off -= head;
-    const size_t lds1 = (size_t)B * kRing * 8 + (size_t)B * 12 + (size_t)kPartWaves * kQueue * 4;
+    const size_t lds1 = (size_t)B * kRing * 8 + (size_t)B * 8 + (size_t)kConsumers * 64 * 4 + 16;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return e;
@@ -1199,35 +1623,19 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                        ws.counts, pl.cap, pool, ctl, hist);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds2 = (size_t)kEntries * 6 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
-                        (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8;   // the slice area doubles as the waves' miss queues
-    if (bitmap) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
-                           pl.segment_wgs, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
-                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, skip, WrittenList{nullptr, nullptr, 0});
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const size_t lds3 = (size_t)4 << 15;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_fallback<BLOG2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, pp, ws.counts, pl.cap,
-                           pl.segment_wgs, pool, ctl, ws.fail_from, st.bitmap, run);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return e;
-        unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
-        hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
-                           pl.segment_wgs, base_seq, c.seq, t, (uint32_t *)nullptr, run,
-                           reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip, st.written);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip, st.written);
-    }
+#ifdef KTA_DBG_PART_ONLY
+    return e;
+#endif
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return e;
+    unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
+    hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+                       pl.segment_wgs, base_seq, c.seq, t, (uint32_t *)nullptr, run,
+                       reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip, st.written);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip, st.written);
     return hipGetLastError();
 }
 
@@ -1239,9 +1647,10 @@ const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2)
            (1u << bucket_log2);
 }
 
-AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count)
+AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32)
 {
     AlivePartitionPlan pl;
+    pl.pair32 = pair32;
     pl.bucket_log2 = 10u;
     pl.max_records = kAlivePartitionMax;
     if (n > pl.max_records) n = pl.max_records;
@@ -1251,15 +1660,16 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count)
     uint64_t wgs = req_wgs > 0 ? (uint64_t)req_wgs : (uint64_t)(cu_count > 0 ? cu_count : 256);
     if (wgs > kMaxSegWGs) wgs = kMaxSegWGs;
     const uint64_t ntiles = (n + 3 + kTile - 1) / kTile;              // + 3: columns aligned down by up to three records
-    const uint64_t want = (ntiles + kPartWaves - 1) / kPartWaves;     // at least one tile per wave
+    const uint64_t want = (ntiles + kProducers - 1) / kProducers;     // at least one tile per producer wave
     if (wgs > want) wgs = want;
     pl.tiles_per_wg = (uint32_t)((ntiles + wgs - 1) / wgs);
     pl.segment_wgs = (uint32_t)((ntiles + pl.tiles_per_wg - 1) / pl.tiles_per_wg);
     // a segment receives n / (W * B) pairs on average; 1/8 + 48 of slack (8 sigma at 2^26 records) before it
     // overflows into the pool, rounded up to what a wave reads with one load instruction (128 pairs)
     const uint64_t mean = n / ((uint64_t)pl.segment_wgs << pl.bucket_log2) + 1;
-    pl.cap = (uint32_t)((mean + mean / 8 + 48 + 127) & ~127ull);
-    pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap;
+    // (and to what a wave of pass 2 reads with one load instruction of four pairs per lane: 256)
+    pl.cap = (uint32_t)((mean + mean / 8 + 48 + 255) & ~255ull);
+    pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap / (pair32 ? 2 : 1);
     pl.count_words = (uint64_t)pl.segment_wgs << pl.bucket_log2;
     pl.pool_words = n + ((uint64_t)pl.segment_wgs << pl.bucket_log2);   // + one padding pair per segment tail
     pl.ctl_bytes = POOL_WORDS * 8 + ((size_t)4 << pl.bucket_log2) + 4;

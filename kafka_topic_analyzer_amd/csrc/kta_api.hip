@@ -205,6 +205,9 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
 {
     if (n == 0) return KTA_OK;
     hipEvent_t a = nullptr, b = nullptr;
+    // every refusal comes before the first launch: a batch is counted by both handlers or by neither
+    if ((which & 2) && ctx->alive && (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes))
+        return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
     if (which & 1) {
         if (!c->partition || !c->key_len || !c->val_len || !c->ts_ms)
             return fail(ctx, KTA_ERR_INVALID, "metric columns missing");
@@ -232,8 +235,6 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         if (ctx->timing) KTA_HIP(ctx, hipEventRecord(b, ctx->s_compute));
     }
     if ((which & 2) && ctx->alive) {
-        if (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes)
-            return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
         kta::AliveColumns ac{c->key_len, c->val_len, c->key_off, c->key_bytes, c->seq};
         if (ctx->timing) {
             int rc = timer_pair(ctx, 2, &a, &b);
@@ -271,19 +272,23 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 use_partitioned = false;
             }
         }
+        // (table state: its partition kernel reads the three i32 columns 16 bytes at a time, aligned down together;
+        // columns that do not share their alignment modulo 16 take the single-kernel update, which reads them 4 bytes
+        // at a time.  The bit set state's kernel has no such wish.)
+        if (use_partitioned && ctx->alive_table &&
+            (((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->val_len)) & 15u) ||
+             ((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->key_off)) & 15u)))
+            use_partitioned = false;
         if (use_partitioned) {
-            if ((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->val_len)) & 15u ||
-                (reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->key_off)) & 15u)
-                return fail(ctx, KTA_ERR_INVALID, "key_len, val_len and key_off must share their alignment modulo 16 bytes");
-            if (!ctx->d_alive_stats) {
-                KTA_HIP(ctx, hipMalloc((void **)&ctx->d_alive_stats, 2 * sizeof(uint64_t)));
-                KTA_HIP(ctx, hipHostMalloc((void **)&ctx->h_alive_stats, 2 * sizeof(uint64_t), hipHostMallocDefault));
+            if (!ctx->d_alive_stats) {   // (four words: builds with KTA_ALIVE_PHASES add instalments and side-table entries)
+                KTA_HIP(ctx, hipMalloc((void **)&ctx->d_alive_stats, 4 * sizeof(uint64_t)));
+                KTA_HIP(ctx, hipHostMalloc((void **)&ctx->h_alive_stats, 4 * sizeof(uint64_t), hipHostMallocDefault));
                 KTA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_alive_stats, hipEventDisableTiming));
             }
             const bool report = ctx->alive_table && !ctx->alive_stats_pending;       // one report in flight at a time
-            if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 2 * sizeof(uint64_t), ctx->s_compute));
+            if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 4 * sizeof(uint64_t), ctx->s_compute));
             for (uint64_t at = 0; at < n;) {
-                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, ctx->alive_wgs, ctx->cu_count);
+                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
                 const uint64_t take = n - at < pl.max_records ? n - at : pl.max_records;
                 if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words || ctx->pool_cap < pl.pool_words) {
                     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
@@ -301,10 +306,8 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                     ctx->pair_counts_cap = pl.count_words;
                     ctx->pool_cap = pl.pool_words;
                 }
-                if (!ctx->d_pool_ctl) {
-                    KTA_HIP(ctx, hipMalloc(&ctx->d_pool_ctl, pl.ctl_bytes));
-                    KTA_HIP(ctx, hipMalloc((void **)&ctx->d_fail_from, sizeof(uint32_t) << pl.bucket_log2));
-                }
+                if (!ctx->d_pool_ctl) KTA_HIP(ctx, hipMalloc(&ctx->d_pool_ctl, pl.ctl_bytes));
+                if (!ctx->d_fail_from) KTA_HIP(ctx, hipMalloc((void **)&ctx->d_fail_from, sizeof(uint32_t) << pl.bucket_log2));
                 kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes,
                                      ctx->alive_table && c->seq ? c->seq + at : nullptr};
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,

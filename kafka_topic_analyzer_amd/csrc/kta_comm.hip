@@ -207,6 +207,7 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
     if (!st->d_scalar) CH(ctx, hipMalloc((void **)&st->d_scalar, sizeof(uint64_t)));
     kta::WrittenList wl;
     bool listed = kta_internal_written(ctx, &wl);
+    if (n > 64) listed = false;                          // the list kernels keep one LDS counter per owner, 64 of them: sweep
     uint64_t *d_owner_at = st->d_counts + n + n * n, *d_cursors = d_owner_at + n;
     // 1. how many entries does this rank hold for every owner
     std::vector<uint64_t> send(n), matrix((size_t)n * n);

@@ -102,6 +102,7 @@ hipError_t launch_alive_update(const AliveColumns &c, uint64_t n, uint64_t base_
 constexpr uint64_t kAlivePartitionMin = 1ull << 21;   // table state: below this the single-kernel update is used
 constexpr uint64_t kAlivePartitionMax = 1ull << 28;   // records per launch pair: larger batches are sliced
 struct AlivePartitionPlan {
+    bool pair32;            // bit set state: 4-byte pairs with implicit order (kta_alive.hip); table state: 8-byte pairs
     uint32_t bucket_log2;   // buckets = state regions = apply workgroups
     uint32_t segment_wgs;   // partition workgroups = segments per bucket
     uint32_t tiles_per_wg;  // 256-record tiles each partition workgroup takes (a contiguous range)
@@ -125,7 +126,7 @@ struct AliveWorkspace {
     void *pool_ctl;         // ctl_bytes
     uint32_t *fail_from;    // u32[buckets] (bit set state)
 };
-AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count);
+AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32);
 hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
                                     const AlivePartitionPlan &plan, const AliveWorkspace &ws,
                                     uint64_t *stats /* [pairs, claims] += ; may be null */, hipStream_t s);
