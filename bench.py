@@ -137,17 +137,44 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
     out = {"workload": f"c3 shape: 64 partitions, {n_records} records, 16 B keys, 10M distinct, 10% tombstones",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
            "alive_keys": int(res.alive_keys),
-           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply",
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition32 + kta_alive_apply",
                         "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": algo_bytes, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": _traffic(["kta_alive_partition", "kta_alive_apply"], n_records),
+                        "traffic": _traffic(["kta_alive_partition32", "kta_alive_apply"], n_records),
                         "traffic_source": TRAFFIC_SOURCE,
                         "note": "kernel_ms is the HIP-event time of the kernels of one batch (hash + partition, then "
                                 "per-bucket merge + the bucket's region of the 512 MiB bit set streamed through LDS; "
-                                "the fallback kernel returns at once); the 8 bytes per record of partitioned pairs "
+                                "the fallback kernel returns at once); the 4 bytes per record of partitioned pairs "
                                 "written and read back and the bit set's 2 x 512 MiB per batch are traffic, not "
                                 "algorithmic bytes"}}
+    # ---- both handlers over the same resident batch: the product's actual -c step (/root/reference/src/kafka.rs:107-109
+    # calls every handler for every message) — reset-free, like a topic that keeps growing
+    for k in range(warmup):
+        h.submit_device(b, n_records, 0, which=3)
+    h.sync()
+    h.kernel_time_stats()
+    h.set_timing(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        h.submit_device(b, n_records, 0, which=3)
+    h.sync()
+    wall3 = time.perf_counter() - t0
+    avg3, cnt3 = h.kernel_time_stats()
+    h.set_timing(False)
+    both_ms = avg3[0] + avg3[1] + avg3[2]
+    # the scan reads partition, key_len, val_len, ts_ms (20 B), the alive pass key_len, val_len, key_off and the key
+    # (12 B + key): 8 B of the two are the same columns — 40 B per record with 16-byte keys, read once by a fused pass
+    algo3 = (20 + 12 - 8) * n_records + kb
+    both = {"workload": out["workload"] + "; MessageMetrics + LogCompactionInMemoryMetrics per record (which=3)",
+            "value": n_records * steps / wall3, "unit": "records/s", "ms_per_step": wall3 / steps * 1e3,
+            "roofline": {"bound": "hbm", "kernel": "kta_metrics_scan + kta_fold_partials + kta_alive_partition32 + kta_alive_apply",
+                         "achieved": algo3 / (both_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo3 / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo3,
+                         "kernel_ms": both_ms, "scan_ms": avg3[0], "fold_ms": avg3[1], "alive_ms": avg3[2],
+                         "launches": int(cnt3[2]), "traffic": None,
+                         "note": "algorithmic bytes = the union of the two handlers' columns (40 B per record with 16-byte "
+                                 "keys); the two passes read key_len and val_len once each (48 B per record touched)"}}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)
     passes, t_total = 0, 0.0
@@ -165,7 +192,78 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
                                      "LogCompactionInMemoryMetrics::handle_message loop of oracle/kta_oracle.c"}
     h.device_batch_free(b)
     h.close()
-    return out
+    return out, both
+
+
+def alive_table_report(kta, device, steps, n_records):
+    """The alive-key pass as a rank of a partition-sharded -c run executes it: the sequence-numbered table (32 GiB),
+    batches with a seq column (the global consumption index of every record), config 3's key law — 10 M distinct keys,
+    what one of eight ranks of config 5 sees (key-affine partitions: 12.5 M).  Every step is a NEW batch of the topic
+    (records and sequence numbers that follow the last one's): resubmitting a batch would find its own entries in the
+    table and write nothing."""
+    spec, _ = kta.synth_preset("c3")
+    h = kta.HipMetricHandler(64, count_alive_keys=True, device=device, alive_table=True)
+    batches = []
+    for k in range(steps + 1):
+        b = h.device_batch_alloc(n_records, n_records * 16, with_seq=True)
+        kb = h.synth_fill_device(spec, k * n_records, n_records, b)
+        batches.append(b)
+    h.submit_device(batches[0], n_records, 0, which=2)          # warm-up: the first batch also writes 10 M new slots
+    h.sync()
+    h.kernel_time_stats()
+    h.set_timing(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        h.submit_device(batches[k + 1], n_records, 0, which=2)
+    h.sync()
+    wall = time.perf_counter() - t0
+    avg_ms, cnt = h.kernel_time_stats()
+    h.set_timing(False)
+    res, _ = h.finish()
+    algo = (4 + 4 + 4) * n_records + kb
+    rep = {"workload": f"c3 law, table state, seq column: {steps} consecutive batches of {n_records} records, 16 B keys, 10M distinct, "
+                       "10% tombstones (the partitioned pass: kta_alive_partition + kta_alive_apply<table>)",
+           "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
+           "alive_keys": int(res.alive_keys),
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply (table state)",
+                        "achieved": algo / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo,
+                        "kernel_ms": avg_ms[2], "launches": int(cnt[2]), "traffic": None,
+                        "note": "algorithmic bytes as for alive_pass (12 B + key per record); the seq column is read for "
+                                "the survivors only"}}
+    for b in batches:
+        h.device_batch_free(b)
+    h.close()
+    return rep
+
+
+def alive_hot_key_report(kta, device, n_records):
+    """Adversarial shapes of the alive-key pass (bit set state): what a compacted topic with a dominant key costs.  One
+    key / 40 keys over the whole batch: most records die in the partition kernel's guard (one record per hash and wave
+    instruction survives), the rest overflow their segments into the pool and the bucket is resolved by
+    kta_alive_fallback (slow, exact)."""
+    rows = []
+    for distinct in (1, 40):
+        spec, _ = kta.synth_preset("c3")
+        spec.n_distinct_keys = distinct
+        h = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
+        b = h.device_batch_alloc(n_records, n_records * 16)
+        h.synth_fill_device(spec, 0, n_records, b)
+        h.submit_device(b, n_records, 0, which=2)
+        h.sync()
+        h.kernel_time_stats()
+        h.set_timing(True)
+        for k in range(3):
+            h.submit_device(b, n_records, 0, which=2)
+        h.sync()
+        avg_ms, cnt = h.kernel_time_stats()
+        h.set_timing(False)
+        res, _ = h.finish()
+        rows.append({"distinct_keys": distinct, "records": n_records, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
+                     "records_per_s": n_records / (avg_ms[2] * 1e-3), "alive_keys": int(res.alive_keys)})
+        h.device_batch_free(b)
+        h.close()
+    return {"workload": f"c3 shape with 1 / 40 distinct keys over {n_records} records (bit set state)", "rows": rows}
 
 
 def _recompress_batches(lib, raw, codec):
@@ -642,8 +740,10 @@ def main():
     h.close()
     if rank == 0:
         if world == 1 and not args.no_alive and not c5:
-            line["alive_pass"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
-                                                   args.alive_records, args.cpu_seconds)
+            line["alive_pass"], line["both_handlers"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
+                                                                          args.alive_records, args.cpu_seconds)
+            line["alive_pass_table"] = alive_table_report(kta, local_rank, 5, args.alive_records)
+            line["alive_pass_hot_key"] = alive_hot_key_report(kta, local_rank, 1 << 26)
         if world == 1 and not args.no_decode and not c5:
             line["kafka_decode"] = kafka_decode_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                        args.decode_records, args.cpu_seconds)

@@ -543,24 +543,55 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 // the bytes).  An 8-byte pair is half index.  The bit set state needs no index — only, per slot, WHICH pair is the
 // newest — so its pairs carry none:
 //
-//   pair32 = slot-in-bucket (22 bits) << 10 | alive << 9 | window (1 ... 255: never zero)
+//   pair32 = slot-in-bucket (22 bits) << 10 | window (1 ... 255: never zero) << 1 | alive          (bit 9 is zero)
 //
-// and the order of two pairs of one slot is the order of (workgroup w, producer v, position in the segment):
-//   * workgroup w takes a contiguous range of the batch (older than w + 1's), and inside it producer wave v takes a
-//     contiguous sub-range (older than v + 1's) and walks it in order;
+// and the order of two pairs of one slot is the order of (workgroup w, window, position in the segment):
+//   * workgroup w takes a contiguous range of the batch (older than w + 1's), cut into windows of consecutive tiles
+//     (window c is older than c + 1); a window is walked by ONE producer wave, in order;
 //   * the positions of ONE wave's pairs in a ring are handed out in program order (LDS operations of a wave are
 //     performed in order) — tile after tile, and inside a tile instruction j (records 64 j + lane) before j + 1;
 //   * inside one instruction the order of two lanes' atomics on one counter is the hardware's business, so no two
-//     records of one hash are ever inserted by the same instruction: every record first writes (signature, id) to
-//     a small per-wave guard table at an index taken from its hash and reads it back.  Exactly one record per
-//     index reads its own word and inserts; the others saw the winner's — a different signature means a different
-//     hash: they play again among themselves (16 of 256 on average; two or three rounds); the same signature
-//     (1/256, or a true repetition) fetches the winner's hash: equal, and the winner is the newer record ⇒ this one
-//     is superseded and DROPPED (exactly what the reference's insert / remove sequence leaves: metric.rs:289-304);
-//     equal and older ⇒ it goes in a later round, i.e. at a later position.
+//     records of one hash are ever inserted by the same instruction: every record first writes its lane number to a
+//     small per-wave guard table (bytes) at an index taken from its hash and reads it back (LDS operations of a wave
+//     are performed in order: the read sees the instruction's last writer, and instruction j + 1 writes after j has
+//     read).  A record that reads its own lane is alone at its index, or it is the last writer there; a record that
+//     reads another lane shares the index with that lane — by chance (different hashes: 64 records over 2048 indices,
+//     about one such pair per instruction) or because the hashes are equal.  For every record that lost its index
+//     the wave looks at the lanes with that record's very hash (one readlane + one compare per group, scalar
+//     bookkeeping): the NEWEST of them (the highest lane: lane order is record order) stays, the others are
+//     superseded and DROPPED — exactly what the reference's insert / remove sequence leaves (metric.rs:289-304).
+//     Records with equal hashes always share their index, so every group with two or more members has a loser and is
+//     looked at: after the guard no two records of one instruction have the same hash.  One round, exact.
 // Hot keys — which used to fill their bucket's ring and stall the workgroup — mostly die in the guard.
-constexpr uint32_t kRing32 = 32;                   // pairs per bucket ring: two 64-byte blocks of 16
-constexpr uint32_t kGuard = 1024;                  // guard words (u16: signature << 8 | id) per producer wave
+// The stream is read once: non-temporal loads keep it out of the caches the pair blocks are written through.
+#ifndef KTA_P32_NT
+#define KTA_P32_NT 1
+#endif
+#if KTA_P32_NT
+#define KTA_P32_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define KTA_P32_LOAD(p) (*(p))
+#endif
+typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));   // 16 key bytes at any address (unaligned access mode)
+#ifndef KTA_P32_BLOCK
+#define KTA_P32_BLOCK 16
+#endif
+constexpr uint32_t kBlk32 = KTA_P32_BLOCK;         // pairs of a block: what leaves the ring in one piece (64 bytes)
+constexpr uint32_t kRing32 = 2 * kBlk32;           // pairs per bucket ring: two blocks
+constexpr uint32_t kBlkLanes = kBlk32 / 4;         // lanes that move a block (16 bytes each)
+constexpr uint32_t kBlkPerTrip = 64 / kBlkLanes;   // blocks a consumer wave moves at a time
+// experiments of tools/ubench_alive.hip on the block stores (the library is built with none of them)
+#if defined(KTA_P32_STORE_NT)
+#define KTA_P32_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
+#elif defined(KTA_P32_STORE_SC1)
+#define KTA_P32_STORE(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(val) : "memory")
+#else
+#define KTA_P32_STORE(ptr, val) (*(ptr) = (val))
+#endif
+#ifndef KTA_P32_GUARD
+#define KTA_P32_GUARD 2048
+#endif
+constexpr uint32_t kGuard = KTA_P32_GUARD;           // guard bytes (the lane that wrote last) per producer wave
 constexpr uint32_t kPair32Shift = 10;
 
 __device__ __forceinline__ uint32_t ring32_at(uint32_t b, uint32_t p)   // (rows rotated by whole 16-byte pieces)
@@ -568,17 +599,11 @@ __device__ __forceinline__ uint32_t ring32_at(uint32_t b, uint32_t p)   // (rows
     return b * kRing32 + ((p + 4u * (b & 7u)) & (kRing32 - 1));
 }
 
-// order key of a pair of the bit set state (what pass 2 maximises per slot): segment w, producer v, position
-__device__ __forceinline__ uint32_t pair32_key(uint32_t w, uint32_t v, uint32_t cap, uint32_t pos)
-{
-    return (w * 256u + v) * cap + pos;             // (256 W cap = 0.28 n: below 2^27)
-}
-
 // a pool pair of the bit set state (segment overflow; they are ordered by their place in the pool, see the fallback)
 __device__ __forceinline__ unsigned long long pool_pair32(uint32_t bucket, uint32_t p32, uint32_t w, uint32_t RBITS)
 {
     const uint32_t h = (bucket << RBITS) | (p32 >> kPair32Shift);
-    return ((unsigned long long)h << 32) | 0x80000000u | (w << 9) | ((p32 & 255u) << 1) | ((p32 >> 9) & 1u);   // w, window, alive
+    return ((unsigned long long)h << 32) | 0x80000000u | (w << 9) | (p32 & 0x1FFu);   // w, window, alive
 }
 
 template <int BLOG2>
@@ -590,12 +615,14 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 {
     constexpr uint32_t B = 1u << BLOG2;
     constexpr uint32_t RBITS = 32 - BLOG2;
+#ifndef KTA_P32_EXP_BLOG2
     static_assert(RBITS == 32 - kPair32Shift, "a pair32 holds the hash bits below the bucket");
+#endif
     static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
     extern __shared__ __attribute__((aligned(128))) uint32_t s_ring32[];           // B x kRing32 pairs
     uint32_t *s_pos = s_ring32 + (size_t)B * kRing32;                              // positions handed out
     unsigned short *s_out = reinterpret_cast<unsigned short *>(s_pos + B);         // pairs written out, modulo 2^16 (its consumer's)
-    unsigned short *s_guard = s_out + B;                                           // kProducers x kGuard
+    uint8_t *s_guard = reinterpret_cast<uint8_t *>(s_out + B);                     // kProducers x kGuard
     uint32_t *s_list = reinterpret_cast<uint32_t *>(s_guard + (size_t)kProducers * kGuard);   // kConsumers x 64
     uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done
     {
@@ -617,7 +644,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
     if (wave < (uint32_t)kProducers) {
         // ---------------------------------------------- producer ----------------------------------------------
         const uint32_t v = wave;
-        unsigned short *guard = s_guard + v * kGuard;
+        uint8_t *guard = s_guard + v * kGuard;
         // instruction j of a step handles the records 64 j + lane of the tile: 4-byte loads, 256 bytes per
         // instruction and column.  Unconditional (index clamped into the batch, result masked), two steps ahead; the
         // key bytes — whose addresses come from the columns — one step ahead; two register sets alternate.
@@ -632,15 +659,28 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 const uint64_t i = tile * kTile + 64u * j + lane;
                 const bool in = ok && i < n;
                 const uint64_t ic = in ? i : n - 1;
-                r.kl[j] = c.key_len[ic];
-                r.vl[j] = c.val_len[ic];
-                r.ko[j] = c.key_off[ic];
+#if KTA_DBG_LEVEL == 5   /* 5: nothing is read — made-up records, everything else as it is */
+                r.kl[j] = 16;
+                r.vl[j] = (int32_t)(ic & 7u) - 1;
+                r.ko[j] = (uint32_t)ic;
+#else
+                r.kl[j] = KTA_P32_LOAD(c.key_len + ic);
+                r.vl[j] = KTA_P32_LOAD(c.val_len + ic);
+                r.ko[j] = KTA_P32_LOAD(c.key_off + ic);
+#endif
                 r.kl[j] = in ? r.kl[j] : -1;               // key None: ignored (metric.rs:302)
             }
         };
         auto load_keys32 = [&](const Cols &r, uint4 (&k)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) __builtin_memcpy(&k[j], c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u), 16);
+            for (int j = 0; j < 4; j++) {
+#if KTA_DBG_LEVEL == 5
+                k[j] = make_uint4(r.ko[j] * 0x9E3779B9u, r.ko[j] * 0x85EBCA6Bu + 1u, r.ko[j] ^ 0x5bd1e995u, r.ko[j] * 0xC2B2AE35u);
+#else
+                const v4u_any kk = KTA_P32_LOAD(reinterpret_cast<const v4u_any *>(c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u)));
+                k[j] = make_uint4(kk.x, kk.y, kk.z, kk.w);
+#endif
+            }
         };
         // The workgroup's range is cut into (at most 255) windows of consecutive tiles, and the waves take them as they
         // come (a counter in LDS; from a start that differs from workgroup to workgroup, and around: the ranges lie a
@@ -674,6 +714,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             tile = cur_tile;
             win = cur_win;
         };
+#if KTA_DBG_LEVEL
+        long long dummy = 0;
+#endif
         {
             Cols cols_a, cols_b;
             uint4 keys_a[4], keys_b[4];
@@ -692,13 +735,13 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     for (int j = 0; j < 4; j++)
                         h[j] = r.kl[j] > 0 ? fnv32_prefetched(keys[j], c.key_bytes + r.ko[j], (uint32_t)r.kl[j]) : kFnvInit;
                 }
-                uint32_t act = 0;                                    // bit j: record j still has to be inserted
                 uint32_t pr[4];
+                bool keyed[4];
                 const uint32_t vv = r.win;                           // the window: what the order sees of the tile's place
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    act |= r.kl[j] >= 0 ? 1u << j : 0u;
-                    pr[j] = (h[j] << kPair32Shift) | (r.vl[j] >= 0 ? 1u << 9 : 0u) | vv;
+                    keyed[j] = r.kl[j] >= 0;
+                    pr[j] = (h[j] << kPair32Shift) | (vv << 1) | (r.vl[j] >= 0 ? 1u : 0u);
                 }
                 load_keys32(r_next, keys_next);                      // their columns were requested a step ago
                 {
@@ -706,72 +749,69 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     next_tile(tn, r.win);
                     load_cols32(tn, r.win != 0u, r);                 // r is spent: hashed
                 }
-                uint32_t bk[4], gk[4], gv[4];
+#if KTA_DBG_LEVEL == 1   /* ablation builds of tools/ubench_alive.hip only.  1: stream + hash, nothing else */
+                dummy += (long long)(pr[0] ^ pr[1] ^ pr[2] ^ pr[3]);
+                return;
+#endif
+                // ---- the guard: among the records of one instruction, one record per hash (the newest) ----
+                uint32_t seen[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    bk[j] = h[j] >> RBITS;
-                    gk[j] = h[j] & (kGuard - 1);                     // (bits 0..9: any function of the hash will do)
-                    gv[j] = (((h[j] >> 10) & 0xFFu) << 8) | ((uint32_t)j << 6) | lane;   // signature, id = the record's place in the tile
+                    uint8_t *g = guard + (h[j] & (kGuard - 1));      // (the low bits: any function of the hash will do)
+                    if (keyed[j]) *g = (uint8_t)lane;
+                    KTA_LDS_ORDER();
+                    seen[j] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    KTA_LDS_ORDER();
                 }
-                do {
-                    // ---- the guard: one winner per guard index among the records still in play ----
-                    uint32_t seen[4];
+                bool ins[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if ((act >> j) & 1u) guard[gk[j]] = (unsigned short)gv[j];
-                    KTA_LDS_ORDER();
+                for (int j = 0; j < 4; j++) {
+                    unsigned long long todo = __builtin_amdgcn_ballot_w64(keyed[j] && seen[j] != lane);   // lost their index to another lane
+                    unsigned long long drop = 0;
+                    while (todo) {                                   // (wave-uniform) one trip per group of equal hashes
+                        const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h[j], (int)__builtin_ctzll(todo));
+                        const unsigned long long grp = __builtin_amdgcn_ballot_w64(keyed[j] && h[j] == hl);
+                        drop |= grp & ~(0x8000000000000000ull >> __builtin_clzll(grp));   // all but the highest lane
+                        todo &= ~grp;
+                    }
+                    ins[j] = keyed[j] && !((drop >> lane) & 1ull);
+                }
+#if KTA_DBG_LEVEL == 2   /* 2: + the guard */
+                dummy += (long long)(pr[0] ^ pr[1] ^ pr[2] ^ pr[3]) + (ins[0] ? 1 : 0) + (ins[1] ? 2 : 0) + (ins[2] ? 4 : 0) + (ins[3] ? 8 : 0);
+                return;
+#endif
+                // ---- positions, then the pairs once their ring entries are free: straight-line, so that a lane's four
+                // LDS atomics and its four reads are in flight together ----
+                uint32_t bk[4], p[4], out[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) seen[j] = guard[gk[j]];
-                    KTA_LDS_ORDER();
-                    uint32_t win = 0, twin = 0;
+                for (int j = 0; j < 4; j++) bk[j] = h[j] >> RBITS;
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = ins[j] ? lds_add(&s_pos[bk[j]], 1u) : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                KTA_LDS_ORDER();
+                uint32_t pending = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (ins[j]) {
+                        // (`out` may have been read before the position was handed out: it only grows, so an old
+                        // reading errs on the side of waiting; differences are taken modulo 2^16)
+                        if (((p[j] - out[j]) & 0xFFFFu) < kRing32) s_ring32[ring32_at(bk[j], p[j])] = pr[j];
+                        else pending |= 1u << j;
+                    }
+                }
+                while (__any(pending != 0u)) {                        // rare: 32 arrivals of one bucket since its last block left
+                    __builtin_amdgcn_s_sleep(2);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const bool on = (act >> j) & 1u;
-                        if (on && seen[j] == gv[j]) win |= 1u << j;
-                        else if (on && ((seen[j] ^ gv[j]) >> 8) == 0u) twin |= 1u << j;   // the winner has this record's signature
+                        if (!((pending >> j) & 1u)) continue;
+                        const uint32_t o = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (((p[j] - o) & 0xFFFFu) >= kRing32) continue;
+                        KTA_LDS_ORDER();
+                        s_ring32[ring32_at(bk[j], p[j])] = pr[j];
+                        pending &= ~(1u << j);
                     }
-                    if (__any(twin != 0u)) {                          // rare: look at the winner's whole hash
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int wl = (int)(seen[j] & 63u);
-                            const uint32_t wj = (seen[j] >> 6) & 3u;
-                            const uint32_t h0 = __shfl(h[0], wl), h1 = __shfl(h[1], wl), h2 = __shfl(h[2], wl), h3 = __shfl(h[3], wl);
-                            const uint32_t hw = wj == 0u ? h0 : (wj == 1u ? h1 : (wj == 2u ? h2 : h3));
-                            // the same key later in the tile supersedes this record; earlier: this one goes in after it
-                            if (((twin >> j) & 1u) && hw == h[j] && (seen[j] & 0xFFu) > (gv[j] & 0xFFu)) act &= ~(1u << j);
-                        }
-                    }
-                    // ---- the winners insert: positions, then the pairs once their ring entries are free ----
-                    uint32_t p[4], out[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) p[j] = (win >> j) & 1u ? lds_add(&s_pos[bk[j]], 1u) : 0u;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    KTA_LDS_ORDER();
-                    uint32_t pending = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if ((win >> j) & 1u) {
-                            // (`out` may have been read before the position was handed out: it only grows, so an old
-                            // reading errs on the side of waiting; differences are taken modulo 2^16)
-                            if (((p[j] - out[j]) & 0xFFFFu) < kRing32) s_ring32[ring32_at(bk[j], p[j])] = pr[j];
-                            else pending |= 1u << j;
-                        }
-                    }
-                    while (__any(pending != 0u)) {                    // rare: 32 arrivals of one bucket since its last block left
-                        __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (!((pending >> j) & 1u)) continue;
-                            const uint32_t o = __hip_atomic_load(&s_out[bk[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (((p[j] - o) & 0xFFFFu) >= kRing32) continue;
-                            KTA_LDS_ORDER();
-                            s_ring32[ring32_at(bk[j], p[j])] = pr[j];
-                            pending &= ~(1u << j);
-                        }
-                    }
-                    act &= ~win;
-                } while (__any(act != 0u));
+                }
             };
             while (cols_a.win != 0u) {
                 step(cols_a, keys_a, cols_b, keys_b);
@@ -779,6 +819,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 step(cols_b, keys_b, cols_a, keys_a);
             }
         }
+#if KTA_DBG_LEVEL
+        if (dummy == 0x1234567) counts[0] = 1;
+#endif
         KTA_LDS_ORDER();
         if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
     } else {
@@ -787,6 +830,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         const uint32_t cw = wave - (uint32_t)kProducers;
         uint32_t *list = s_list + cw * 64u;
         for (;;) {
+#if KTA_DBG_LEVEL >= 1 && KTA_DBG_LEVEL <= 2
+            break;
+#endif
             const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
             KTA_LDS_ORDER();
             bool any_ready = false;                                               // wave-uniform
@@ -794,39 +840,55 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 const uint32_t b = (cw * kChunks + ch) * 64u + lane;
                 const uint32_t pos = __hip_atomic_load(&s_pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t have = (pos - s_out[b]) & 0xFFFFu;                  // handed out and not yet written out
-                const bool ready = have >= 16u;                                    // every position of the oldest block is handed out
+                const bool ready = have >= kBlk32;                                    // every position of the oldest block is handed out
                 const unsigned long long m = __ballot(ready);
                 if (m == 0ull) continue;
                 any_ready = true;
                 const uint32_t nready = (uint32_t)__popcll(m);
-                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | (((pos - have) >> 4) << BLOG2);
+                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | (((pos - have) / kBlk32) << BLOG2);
                 KTA_LDS_ORDER();
-                for (uint32_t g0 = 0; g0 < nready; g0 += 16u) {                    // sixteen blocks at a time, four lanes per block
-                    const uint32_t e = g0 + (lane >> 2), piece = lane & 3u;
+                for (uint32_t g0 = 0; g0 < nready; g0 += kBlkPerTrip) {             // sixteen blocks at a time, four lanes per block
+                    const uint32_t e = g0 + lane / kBlkLanes, piece = lane % kBlkLanes;
                     const bool on = e < nready;
                     const uint32_t ent = list[on ? e : 0u];
                     const uint32_t bb = ent & (B - 1), k = ent >> BLOG2;           // bucket, block number
-                    uint4 *src = reinterpret_cast<uint4 *>(s_ring32 + ring32_at(bb, k * 16u + piece * 4u));
+                    uint4 *src = reinterpret_cast<uint4 *>(s_ring32 + ring32_at(bb, k * kBlk32 + piece * 4u));
                     const uint4 d = *src;
                     KTA_LDS_ORDER();
                     const unsigned long long vm = __ballot(on && d.x != 0u && d.y != 0u && d.z != 0u && d.w != 0u);
-                    const bool go = ((uint32_t)(vm >> (lane & ~3u)) & 15u) == 15u;  // all sixteen pairs have arrived
+                    const bool go = ((uint32_t)(vm >> (lane & ~(kBlkLanes - 1u))) & ((1u << kBlkLanes) - 1u)) == (1u << kBlkLanes) - 1u;   // all its pairs have arrived
                     if (go) {
-                        if ((k + 1u) * 16u <= cap) {
-                            *reinterpret_cast<v4u *>(pairs + ((uint64_t)bb * W + w) * cap + (uint64_t)k * 16u + piece * 4u) = (v4u){d.x, d.y, d.z, d.w};
+                        if ((k + 1u) * kBlk32 <= cap) {
+#if KTA_DBG_LEVEL == 4   /* 4: the whole protocol, but the blocks are not stored */
+                            if (d.x == 0x1234567u)
+#endif
+#ifdef KTA_P32_TIMEMAJOR   /* experiment: block k of every segment side by side (what is written at one time lies together) */
+                            KTA_P32_STORE(reinterpret_cast<v4u *>(pairs + (((uint64_t)k * B + bb) * W + w) * kBlk32 + piece * 4u), ((v4u){d.x, d.y, d.z, d.w}));
+#else
+                            {
+                                uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
+#ifdef KTA_P32_STORE_WRAP      /* experiment: every block into the same 32 MB */
+                                at &= (8u << 20) - 1u;
+#endif
+#ifdef KTA_P32_STORE_HALF      /* experiment: every other block is not stored */
+                                if (!(k & 1u))
+#endif
+                                KTA_P32_STORE(reinterpret_cast<v4u *>(pairs + at), ((v4u){d.x, d.y, d.z, d.w}));
+                            }
+#endif
                         } else {                                                   // the segment is full: to the pool, with what a pair32 leaves implicit
                             unsigned long long at_pool = 0;
                             if (piece == 0u) {
-                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], 16ull);
-                                atomicAdd(&pool_hist[bb], 16u);
+                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kBlk32);
+                                atomicAdd(&pool_hist[bb], kBlk32);
                             }
-                            unsigned long long *dst = pool + __shfl(at_pool, (int)(lane & ~3u)) + piece * 4u;
+                            unsigned long long *dst = pool + __shfl(at_pool, (int)(lane & ~(kBlkLanes - 1u))) + piece * 4u;
                             *reinterpret_cast<v2ull *>(dst) = (v2ull){pool_pair32(bb, d.x, w, RBITS), pool_pair32(bb, d.y, w, RBITS)};
                             *reinterpret_cast<v2ull *>(dst + 2) = (v2ull){pool_pair32(bb, d.z, w, RBITS), pool_pair32(bb, d.w, w, RBITS)};
                         }
                         *src = make_uint4(0u, 0u, 0u, 0u);
                         KTA_LDS_ORDER();
-                        if (piece == 0u) s_out[bb] = (unsigned short)((k + 1u) * 16u);   // after the zeroes (program order); its only writer
+                        if (piece == 0u) s_out[bb] = (unsigned short)((k + 1u) * kBlk32);   // after the zeroes (program order); its only writer
                     }
                 }
                 KTA_LDS_ORDER();
@@ -840,17 +902,17 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
     __syncthreads();
     // the last, partial block of every segment, and the segment fills for pass 2
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        const uint32_t f = s_pos[b], k = f >> 4, rem = f & 15u;
+        const uint32_t f = s_pos[b], k = f / kBlk32, rem = f % kBlk32;
         if (rem) {
-            if ((k + 1u) * 16u <= cap) {
-                uint32_t *dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 16u;
-                for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring32[ring32_at(b, k * 16u + q)];
+            if ((k + 1u) * kBlk32 <= cap) {
+                uint32_t *dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * kBlk32;
+                for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring32[ring32_at(b, k * kBlk32 + q)];
             } else {
                 // an even number of pairs: the pool is read in 16-byte units (a zero pair is no pair)
                 unsigned long long *dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)((rem + 1u) & ~1u));
                 atomicAdd(&pool_hist[b], rem);
                 if (rem & 1u) dst[rem] = 0ull;
-                for (uint32_t q = 0; q < rem; q++) dst[q] = pool_pair32(b, s_ring32[ring32_at(b, k * 16u + q)], w, RBITS);
+                for (uint32_t q = 0; q < rem; q++) dst[q] = pool_pair32(b, s_ring32[ring32_at(b, k * kBlk32 + q)], w, RBITS);
             }
         }
         counts[(uint64_t)b * W + w] = f < cap ? f : cap;
@@ -874,31 +936,102 @@ constexpr uint32_t kOvfSub = 1u << kOvfSubLog2;
 constexpr uint32_t kOvfProbes = 32;                // linear probes before the side table counts as full
 constexpr uint32_t kSliceSets = 128;               // sets of one bitmap slice
 constexpr uint32_t kNoFail = 0xFFFFFFFFu;
-constexpr uint32_t kMissQueue = 256;               // pairs a wave queues for the long way of the merge
+constexpr uint32_t kMissQueue = 320;               // pairs a wave queues for the long way of the merge
+#ifndef KTA_APPLY_DEPTH
+#define KTA_APPLY_DEPTH 4
+#endif
+constexpr int kApplyDepth = KTA_APPLY_DEPTH;       // units of a wave's walk: one being merged, the others in flight
 
-// One lookup: which of the set's eight 16-bit tags equals `tag` (8 = none).  t = the set's 16 bytes.  The
-// entries are numbered as the halves lie in memory: entry 2 d + s is half s of dword d; of two matching entries the
-// low halves come first (tags are unique in a set; the order matters for tag 0 = "first free entry").
-// Zero halves of x = t ^ tag:tag are found arithmetically — (x - 0x00010001) & ~x & 0x80008000 sets bit 15 / 31 for a
-// zero low / high half; a zero low half can also flag a high half that is exactly 1 (the borrow), which is harmless
-// because the low half is preferred.  Three operations per dword (xor, add, bitop3); a packed min / compare
-// formulation compiled to eight 16-bit compares + selects + permutes.
+// One lookup: which of the set's eight 16-bit tags equals `tag` (8 = none).  t = the set's 16 bytes.  Entry i < 4 is
+// the low half of dword i, entry i >= 4 the high half of dword i - 4 (the order a search finds them in: of two
+// matching entries the lower number wins — tags are unique in a set, the order matters for tag 0 = "first free
+// entry", which all racers for one slot must agree on); the entry's value is s_val[8 set + i].
+// x = t ^ tag:tag has a zero half where a tag matches; v_pk_min_u16(x, 1:1) turns every half into "differs" (1 / 0) —
+// two operations per dword; the compiler, asked for a packed minimum, produces eight 16-bit compares + selects +
+// permutes, hence the asm.  Then the eight flags are gathered into one byte and the lowest clear bit is the entry.
+__device__ __forceinline__ uint32_t pk_differs(uint32_t x)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(0x00010001u));
+    return r;
+}
 __device__ __forceinline__ uint32_t find_tag(const uint4 &t, uint32_t tag)
 {
     const uint32_t rep = tag * 0x10001u;
-    const uint32_t x0 = t.x ^ rep, x1 = t.y ^ rep, x2 = t.z ^ rep, x3 = t.w ^ rep;
-    // a & ~b & c in one v_bitop3_b32 (truth table 0x20); the compiler spends three operations on it
-    const uint32_t z0 = __builtin_amdgcn_bitop3_b32(x0 - 0x00010001u, x0, 0x80008000u, 0x20);
-    const uint32_t z1 = __builtin_amdgcn_bitop3_b32(x1 - 0x00010001u, x1, 0x80008000u, 0x20);
-    const uint32_t z2 = __builtin_amdgcn_bitop3_b32(x2 - 0x00010001u, x2, 0x80008000u, 0x20);
-    const uint32_t z3 = __builtin_amdgcn_bitop3_b32(x3 - 0x00010001u, x3, 0x80008000u, 0x20);
-    const uint32_t m = (z0 >> 15) | (z1 >> 14) | (z2 >> 13) | (z3 >> 12);   // bits 0..3: low halves of dwords 0..3; 16..19: high halves
-    // no branch (the kernel is bound by instruction issue, and every divergent region costs scalar instructions
-    // too): low halves first, then high halves, then bit 8 = "none"
-    const uint32_t c = (m & 0xFu) | ((m >> 12) & 0xF0u) | 0x100u;
-    const uint32_t i = (uint32_t)__builtin_ctz(c);
-    return i == 8u ? 8u : (((i & 3u) << 1) | (i >> 2));
+    const uint32_t m0 = pk_differs(t.x ^ rep), m1 = pk_differs(t.y ^ rep), m2 = pk_differs(t.z ^ rep), m3 = pk_differs(t.w ^ rep);
+    const uint32_t comb = m0 | (m1 << 1) | (m2 << 2) | (m3 << 3);   // bits 0..3: low halves of dwords 0..3 differ; 16..19: high halves
+    return (uint32_t)__builtin_ctz(~(comb | (comb >> 12)));         // (bit 8 of the argument is always set: 8 = none)
 }
+// where entry i of a set lies: the dword of the set's 16 tag bytes, and the shift of its half
+__device__ __forceinline__ uint32_t entry_dword(uint32_t i) { return i & 3u; }
+__device__ __forceinline__ uint32_t entry_shift(uint32_t i) { return (i >> 2) * 16u; }
+// the entry number of the tag at half-word position ph (0..7) of a set
+__device__ __forceinline__ uint32_t entry_of_half(uint32_t ph) { return ((ph & 1u) << 2) | (ph >> 1); }
+
+// The long way of the merge — a pair that found no entry for its slot — out of line: it is taken by whole waves of
+// queued pairs, from several places, and inlined everywhere it made the kernel three times its size (and what the
+// scalar registers could not hold went through v_writelane in the hot loop).  A function has no idea of the kernel's
+// LDS layout, so the arrays come as LDS byte offsets and are addressed through address-space pointers (a generic
+// pointer would make every access a flat_ instruction, which counts on both memory counters).
+//
+// A new slot takes the set's first free entry with a compare-and-swap on the dword that holds it.  All racers for
+// one slot pick the same entry (first free), so exactly one wins and the others find its tag when they look again:
+// a slot never holds two entries.  A slot whose set is full goes to the side table — open addressing over 64-bit
+// entries (slot + 1) << 32 | value, claimed with a compare-and-swap, the value kept with a 64-bit max (same slot,
+// same upper half); one sub-table of kOvf / 16 entries per slice of 128 sets (the wave that sweeps a slice of the
+// bit set reads its sub-table into registers).
+// Returns 0: merged into an entry that was there; 1: merged into an entry it claimed; 2: merged into the side table;
+// 3: the side table had no room either (the caller gives the attempt up, or takes the direct path).
+#define KTA_LDS(T, off) (reinterpret_cast<__attribute__((address_space(3))) T *>(static_cast<uintptr_t>(off)))
+__device__ __noinline__ uint32_t merge_new_slot(uint32_t lds_tag, uint32_t lds_val, uint32_t lds_ovf, uint32_t lds_ovf_n, uint32_t lds_any_ovf,
+                                               uint32_t tagbits, uint32_t h, uint32_t lo)
+{
+    const uint32_t set = h >> tagbits, tag = (h & ((1u << tagbits) - 1u)) + 1u;
+    uint32_t e, ret = 0;
+    for (;;) {
+        KTA_LDS_ORDER();
+        const v4u raw = *KTA_LDS(const v4u, lds_tag + set * 16u);
+        const uint4 tt = make_uint4(raw.x, raw.y, raw.z, raw.w);
+        KTA_LDS_ORDER();
+        e = find_tag(tt, tag);
+        if (e < 8u) break;
+        const uint32_t f = find_tag(tt, 0u);
+        if (f == 8u) break;                           // the set is full
+        const uint32_t d = entry_dword(f);
+        uint32_t old = d == 0u ? tt.x : (d == 1u ? tt.y : (d == 2u ? tt.z : tt.w));
+        if (__hip_atomic_compare_exchange_strong(KTA_LDS(uint32_t, lds_tag + set * 16u + d * 4u), &old, old | (tag << entry_shift(f)),
+                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            e = f;
+            ret = 1;
+            break;
+        }
+    }
+    if (e < 8u) {
+        __hip_atomic_fetch_max(KTA_LDS(uint32_t, lds_val + (set * 8u + e) * 4u), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return ret;
+    }
+    const unsigned long long pr = ((unsigned long long)(h + 1u) << 32) | lo;
+    const uint32_t sub = (set / kSliceSets) * kOvfSub;
+    uint32_t pos = sub + ((h * 0x9E3779B1u) >> (32 - kOvfSubLog2));
+    for (uint32_t probe = 0; probe < kOvfProbes; probe++) {
+        auto *slot = KTA_LDS(unsigned long long, lds_ovf + pos * 8u);
+        unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0ull) {
+            if (__hip_atomic_compare_exchange_strong(slot, &cur, pr, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                __hip_atomic_fetch_add(KTA_LDS(uint32_t, lds_ovf_n), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                *KTA_LDS(uint32_t, lds_any_ovf) = 1u;
+                return 2;
+            }                                             // (cur now holds what got there first)
+        }
+        if ((uint32_t)(cur >> 32) == h + 1u) {
+            __hip_atomic_fetch_max(slot, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return 2;
+        }
+        pos = sub + ((pos + 1u) & (kOvfSub - 1u));
+    }
+    return 3;
+}
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }   // (the low half of an LDS address is its offset)
 
 struct ApplyShared {
     uint32_t pairs, claims, instalments, ovf_total;
@@ -933,7 +1066,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
     static_assert(TAGBITS <= 15, "tags are 16 bit");
     constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
+#ifndef KTA_P32_EXP_BLOG2
     static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
+#endif
     // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
     // records that found their set full stay short up to about 0.75 load
     constexpr uint32_t kFlushAt = kEntries / 2 + kEntries / 4;
@@ -1048,15 +1183,16 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 sl[lane] = q0;
                 sl[lane + 64u] = q1;
                 KTA_LDS_ORDER();
-                const uint32_t e = (wave * kSliceSets + m * 8u) * 8u + lane;
-                const uint32_t tag = s_tag[e], lo = s_val[e];
+                const uint32_t e = (wave * kSliceSets + m * 8u) * 8u + lane;            // the lane's tag: half-word lane & 7 of set lane >> 3
+                const uint32_t ev = (e & ~7u) | entry_of_half(lane & 7u);                 // ... and its value
+                const uint32_t tag = s_tag[e], lo = s_val[ev];
                 if (tag) {
                     const uint32_t bit = ((lane >> 3) << TAGBITS) | (tag - 1u);
                     const uint32_t mk = 1u << (bit & 31u);
                     const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
                     delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
                     s_tag[e] = 0;
-                    s_val[e] = 0u;
+                    s_val[ev] = 0u;
                 }
                 apply_side(side0, m);
                 apply_side(side1, m);
@@ -1066,27 +1202,34 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 dst[lane + 64u] = sl[lane + 64u];
                 KTA_LDS_ORDER();
             };
-            // The first piece is peeled off the loop so that every path into the loop's top has the same operations
-            // outstanding — [this piece's two loads, the previous piece's two stores] — and the compiler's wait for
-            // the loads is exactly "all but the two stores" (merging a path without stores, it would wait for one).
-            uint32_t m = occupied ? (uint32_t)__builtin_ctz(occupied) : kPieces;
-            if (m < kPieces) {
-                uint4 a0, a1;
-                request(m, a0, a1);
-                {
-                    const uint32_t mn = next_piece(m);
-                    const uint4 t0 = a0, t1 = a1;
-                    request(mn, a0, a1);
-                    piece(m, t0, t1);
-                    m = mn;
-                }
+            // Two pieces are in flight while one is worked on (one wave holds 4 KiB of requests: 16 waves x 256 CUs =
+            // 16 MiB on the way, what the memory's latency asks for at its full rate; with one piece the sweep ran at less
+            // than half of it).  Two register sets take turns — copying "next" into "current" would wait for the request
+            // at the very place it was issued — and every request is unconditional: countable.
+            uint32_t m0 = occupied ? (uint32_t)__builtin_ctz(occupied) : kPieces;
+            if (m0 < kPieces) {
+                uint32_t m1 = next_piece(m0);
+                uint4 x0, x1, y0, y1;
+                request(m0, x0, x1);
+                request(m1, y0, y1);
 #pragma unroll 1
-                while (m < kPieces) {
-                    const uint32_t mn = next_piece(m);
-                    const uint4 t0 = a0, t1 = a1;
-                    request(mn, a0, a1);
-                    piece(m, t0, t1);
-                    m = mn;
+                for (;;) {
+                    {
+                        const uint32_t m2 = next_piece(m1 < kPieces ? m1 : kPieces - 1u);
+                        const uint4 t0 = x0, t1 = x1;
+                        request(m2, x0, x1);
+                        piece(m0, t0, t1);
+                        m0 = m2;
+                    }
+                    if (m1 >= kPieces) break;
+                    {
+                        const uint32_t m3 = next_piece(m0 < kPieces ? m0 : kPieces - 1u);
+                        const uint4 t0 = y0, t1 = y1;
+                        request(m3, y0, y1);
+                        piece(m1, t0, t1);
+                        m1 = m3;
+                    }
+                    if (m0 >= kPieces) break;
                 }
             }
             lds_barrier();                              // all waves have read the side table
@@ -1099,11 +1242,12 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 unsigned long long v[4], old[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const uint32_t e = e0 + (uint32_t)u * kApplyThreads + threadIdx.x;
+                    const uint32_t e = e0 + (uint32_t)u * kApplyThreads + threadIdx.x;      // a tag by its half-word position ...
+                    const uint32_t ev = (e & ~7u) | entry_of_half(e & 7u);                    // ... and its value
                     tg[u] = s_tag[e];
-                    lo[u] = s_val[e];
+                    lo[u] = s_val[ev];
                     s_tag[e] = 0;
-                    s_val[e] = 0u;
+                    s_val[ev] = 0u;
                     slot[u] = (b << RBITS) | ((e >> 3) << TAGBITS) | (tg[u] - 1u);
                 }
 #pragma unroll
@@ -1136,33 +1280,42 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         lds_barrier();
     };
 
-    // A wave reads its segments in units of kApplyUnroll 16-byte loads per lane = 256 pairs, masked by the segment's
-    // fill (cap is a multiple of 128).
-    // The loads of unit u + 1 are issued before unit u is merged, so a wave always has a unit in flight.
-    // (bit set state: 4-byte pairs, ONE 16-byte load of a lane is its four pairs of the unit; cap is a multiple of 256)
+    // A wave reads its segments in units of 256 pairs, masked by the segment's fill: table state — two 16-byte loads
+    // per lane of 8-byte pairs (cap is a multiple of 128); bit set state — ONE 16-byte load per lane, its four 4-byte
+    // pairs (cap is a multiple of 256).  kApplyDepth - 1 units are in flight while one is merged.
     const unsigned long long *region_pairs = pairs + (uint64_t)b * W * cap;
     const uint32_t *region_pairs32 = reinterpret_cast<const uint32_t *>(pairs) + (uint64_t)b * W * cap;
     const uint32_t loads = BITMAP ? cap >> 8 : cap >> 7;
     const uint32_t chunks = BITMAP ? loads : (loads + kApplyUnroll - 1) / kApplyUnroll;
     const uint32_t groups = (W + kApplyWaves - 1) / kApplyWaves;
     const uint32_t units = groups * chunks;                                     // the same for every wave
-    ulonglong2 p[kApplyUnroll], pn[kApplyUnroll];
-    uint32_t nv[kApplyUnroll], nvn[kApplyUnroll];    // valid pairs of each load: 0, 1 or 2 (bit set state: [0] = 0..4, [1] = the
-                                                     // order key of the lane's first pair without its producer: see pair32_key)
+    // bit set state: what pass 2 maximises per slot is (segment w, window, position in the segment) << 1 | alive; the
+    // position takes ksh = ceil(log2(cap)) bits (cap >= 256, so the window's field starts above bit 8)
+    const uint32_t ksh = 32u - (uint32_t)__builtin_clz(cap - 1u);
+    struct Unit {
+        ulonglong2 q[kApplyUnroll];
+        uint32_t nv[kApplyUnroll];   // valid pairs of each load: 0, 1 or 2 (bit set state: [0] = 0..4, [1] = the value of the
+                                     // lane's first pair without its window and alive bit)
+    };
     // Which segment a unit reads: in careful mode wave v takes the segments v, v + 16, ... (every group of 16 is
     // older than the next); in the fast attempt the order does not matter and the waves take whatever segment is
     // next (they finish together instead of waiting for whoever had the slow records).
     uint32_t seg = 0, seg_unit = 0, seg_units = 0;       // wave-uniform
     bool dynamic = false;
-    auto issue = [&](uint32_t u, ulonglong2 (&q)[kApplyUnroll], uint32_t (&qv)[kApplyUnroll]) __attribute__((always_inline)) {
+    auto issue = [&](uint32_t u, Unit &un) __attribute__((always_inline)) {
         uint32_t r0;
+        // (wave-uniform by construction; said again, because loop-carried values of this kernel's loops end up in
+        // vector registers and every use of them in vector instructions)
+        seg_unit = __builtin_amdgcn_readfirstlane(seg_unit);
+        seg_units = __builtin_amdgcn_readfirstlane(seg_units);
+        u = __builtin_amdgcn_readfirstlane(u);
         if (dynamic) {                                   // a handed-out segment is read in as many units as it has pairs for
             if (seg_unit >= seg_units) {
                 uint32_t g = 0;
                 if (lane == 0) g = lds_add(&sh.next_seg, 1u);
                 seg = __builtin_amdgcn_readfirstlane(g);
                 const uint32_t c = __builtin_amdgcn_readfirstlane(s_cnt[seg < W ? seg : 0u]);
-                seg_units = (c + 255u) / 256u;                                   // (128 x kApplyUnroll = 256 pairs either way)
+                seg_units = (c + 255u) / 256u;                                   // (256 pairs a unit either way)
                 if (seg_units == 0u) seg_units = 1u;
                 seg_unit = 0;
             }
@@ -1170,85 +1323,40 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             seg_unit++;
         } else {
             r0 = (u % chunks) * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
-            seg = (u / chunks) * kApplyWaves + wave;
+            seg = (u / chunks) * kApplyWaves + __builtin_amdgcn_readfirstlane(wave);
         }
+        seg = __builtin_amdgcn_readfirstlane(seg);
         const bool on = seg < W && (dynamic || u < units);
-        const uint32_t cnt = on ? s_cnt[on ? seg : 0u] : 0u;
+        const uint32_t cnt = on ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[on ? seg : 0u]) : 0u;
         if (BITMAP) {
             const uint32_t *sp = region_pairs32 + (uint64_t)(on ? seg : 0u) * cap;
             const uint32_t k = (r0 << 8) + 4u * lane;
-            qv[0] = r0 < loads && k < cnt ? (cnt - k >= 4u ? 4u : cnt - k) : 0u;
-            qv[1] = pair32_key(on ? seg : 0u, 0u, cap, k);
-            q[0] = *reinterpret_cast<const ulonglong2 *>(sp + (qv[0] ? k : 4u * lane));   // unconditional, as below
+            un.nv[0] = r0 < loads && k < cnt ? (cnt - k >= 4u ? 4u : cnt - k) : 0u;
+            un.nv[1] = ((on ? seg : 0u) << (ksh + 9u)) | (k << 1);
+            // unconditional (clamped address, masked by nv): a predicated load is a branch, and the wait for this
+            // unit's data would then be vmcnt(0) — it would wait for the units behind it as well
+            const v2ull four = __builtin_nontemporal_load(reinterpret_cast<const v2ull *>(sp + (un.nv[0] ? k : 4u * lane)));   // (read once)
+            un.q[0] = make_ulonglong2(four.x, four.y);
             return;
         }
         const unsigned long long *sp = region_pairs + (uint64_t)(on ? seg : 0u) * cap;
 #pragma unroll
         for (int x = 0; x < kApplyUnroll; x++) {
             const uint32_t k = ((r0 + (uint32_t)x) << 7) + 2u * lane;
-            qv[x] = (r0 + (uint32_t)x) < loads && k < cnt ? (cnt - k >= 2u ? 2u : 1u) : 0u;
-            // unconditional (clamped address, masked by qv): a predicated load is a branch, and the wait for this
-            // unit's data would then be vmcnt(0) — it would wait for the NEXT unit's loads as well
-            q[x] = *reinterpret_cast<const ulonglong2 *>(sp + (qv[x] ? k : 2u * lane));
+            un.nv[x] = (r0 + (uint32_t)x) < loads && k < cnt ? (cnt - k >= 2u ? 2u : 1u) : 0u;
+            un.q[x] = *reinterpret_cast<const ulonglong2 *>(sp + (un.nv[x] ? k : 2u * lane));   // unconditional, as above
         }
     };
     uint32_t claimed = 0;
-    bool careful = sh.dense != 0u;                     // an earlier bucket of this batch overflowed its table: check as we go
-    // The merge of one pair that found no entry for its slot.  A new slot takes the set's first free entry with a
-    // compare-and-swap on the dword that holds it.  All racers for one slot pick the same entry (first free), so
-    // exactly one wins and the others find its tag when they look again: a slot never holds two entries.
+    bool careful = __builtin_amdgcn_readfirstlane(sh.dense) != 0u;   // an earlier bucket of this batch overflowed its table: check as we go
+    // The merge of one pair that found no entry for its slot: merge_new_slot, out of line.
+    const uint32_t o_tag = lds_offset(s_tag), o_val = lds_offset(s_val), o_ovf = lds_offset(s_ovf), o_any = lds_offset(&sh.any_ovf);
     auto merge_new = [&](uint32_t h, uint32_t lo, uint32_t par) __attribute__((always_inline)) {
-        const uint32_t set = h >> TAGBITS, tag = (h & ((1u << TAGBITS) - 1u)) + 1u;
-        uint32_t e;
-        for (;;) {
-            KTA_LDS_ORDER();
-            const uint4 tt = *reinterpret_cast<const uint4 *>(s_tag + set * 8u);
-            KTA_LDS_ORDER();
-            e = find_tag(tt, tag);
-            if (e < 8u) break;
-            const uint32_t f = find_tag(tt, 0u);
-            if (f == 8u) break;                           // the set is full
-            const uint32_t d = f >> 1;
-            const uint32_t old = d == 0u ? tt.x : (d == 1u ? tt.y : (d == 2u ? tt.z : tt.w));
-            uint32_t *word = reinterpret_cast<uint32_t *>(s_tag + set * 8u) + d;
-            if (atomicCAS(word, old, old | (tag << (16u * (f & 1u)))) == old) {
-                e = f;
-                claimed++;
-                break;
-            }
-        }
-        if (e < 8u) {
-            atomicMax(&s_val[set * 8u + e], lo);
-            return;
-        }
-        // The set is full: the slot goes to the side table — open addressing over 64-bit entries (slot + 1) << 32 |
-        // value, claimed with a compare-and-swap, the value kept with a 64-bit max (same slot, same upper half);
-        // one sub-table of kOvf / 16 entries per slice of 128 sets (the wave that sweeps a slice of the bit set
-        // reads its sub-table into registers).  Full as well: the attempt is given up (fast attempt; bit set state)
-        // or the record takes the direct path (table state, careful mode).
-        const unsigned long long pr = ((unsigned long long)(h + 1u) << 32) | lo;
-        const uint32_t sub = (set / kSliceSets) * kOvfSub;
-        uint32_t pos = sub + ((h * 0x9E3779B1u) >> (32 - kOvfSubLog2));
-        bool placed = false;
-        for (uint32_t probe = 0; probe < kOvfProbes; probe++) {
-            unsigned long long cur = s_ovf[pos];
-            if (cur == 0ull) {
-                cur = atomicCAS(&s_ovf[pos], 0ull, pr);
-                if (cur == 0ull) {
-                    lds_add(&sh.ovf_n[par], 1u);
-                    sh.any_ovf = 1u;
-                    placed = true;
-                    break;
-                }
-            }
-            if ((uint32_t)(cur >> 32) == h + 1u) {
-                atomicMax(&s_ovf[pos], pr);
-                placed = true;
-                break;
-            }
-            pos = sub + ((pos + 1u) & (kOvfSub - 1u));
-        }
-        if (!placed) {
+        const uint32_t how = merge_new_slot(o_tag, o_val, o_ovf, lds_offset(&sh.ovf_n[par]), o_any, TAGBITS, h, lo);
+        claimed += how == 1u ? 1u : 0u;
+        if (how == 3u) {
+            // Full as well: the attempt is given up (fast attempt; bit set state) or the record takes the direct path
+            // (table state, careful mode).
             if (BITMAP || !careful) sh.fail[par] = 1u;
             else delta += direct_update(table, (b << RBITS) | h, global_val(lo), wl);
         }
@@ -1256,10 +1364,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // Pairs whose slot has an entry (most of a compacted topic's) are merged where they stand: one lookup, one
     // max.  The others are queued, per wave, and handled 64 at a time: a lane that needs the long way would
     // otherwise make its whole wave walk it — and with 64 lanes there is always one.  The queues live in the LDS
-    // the sweep uses later (2 KiB = 256 pairs per wave).
+    // the sweep uses later (kMissQueue pairs per wave).
     unsigned long long *missq = reinterpret_cast<unsigned long long *>(s_slice) + wave * kMissQueue;
     uint32_t mq = 0;                                     // wave-uniform
-    auto drain = [&](uint32_t par) __attribute__((always_inline)) {
+    auto drain = [&](uint32_t par) __attribute__((always_inline)) {   // everything that is queued
         KTA_LDS_ORDER();
         for (uint32_t q0 = 0; q0 < mq; q0 += 64u) {
             const bool on = q0 + lane < mq;
@@ -1269,27 +1377,52 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         KTA_LDS_ORDER();
         mq = 0;
     };
-    // merge the unit held in (q, qv): four pairs per lane, their four lookups in flight together.  Misses collect in
-    // the wave's queue over several units and are handled when it is half full (64 lanes at work, not the few of
-    // one unit); a miss that finds the queue full waits in its register until the queue has been handled.
-    // `edge`: nothing may stay queued past this unit (the one-site driver's last unit of a trip).
-    auto merge = [&](const ulonglong2 (&q)[kApplyUnroll], const uint32_t (&qv)[kApplyUnroll], uint32_t par, bool edge) __attribute__((always_inline)) {
-        static_assert(kApplyUnroll == 2 && kMissQueue >= 4 * 64, "a unit's misses fit the empty queue");
-        // the lane's four pairs as (slot in the bucket, value to maximise): value = order << 1 | alive
-        unsigned long long pr[4];
-        bool valid[4];
+    auto drain_full = [&](uint32_t par) __attribute__((always_inline)) {   // whole waves of 64 only, from the queue's end (the order does not matter)
+        KTA_LDS_ORDER();
+        while (mq >= 64u) {
+            mq -= 64u;
+            const unsigned long long pr = missq[mq + lane];
+            merge_new((uint32_t)(pr >> 32), (uint32_t)pr, par);
+        }
+        KTA_LDS_ORDER();
+    };
+    // Merge the unit `un`: four pairs per lane, their four lookups in flight together.
+    //   bit set state: a lookup is the set's 16 tag bytes — read unconditionally, any word addresses a set —, a hit one
+    //     LDS max; the misses of the unit go to the wave's queue, which always has room for a unit's 256 (it is emptied
+    //     down to less than 64 after every unit: whole waves of 64 lanes walk the long way, never the few of one unit).
+    //   table state: misses collect over several units and are handled when the queue is half full; a miss that
+    //     finds the queue full waits in its register until the queue has been handled.
+    auto merge = [&](const Unit &un, uint32_t par) __attribute__((always_inline)) {
+        static_assert(kApplyUnroll == 2 && kMissQueue >= 5 * 64, "a unit's misses fit the queue behind what drain_full leaves");
+        mq = __builtin_amdgcn_readfirstlane(mq);         // (wave-uniform by construction: see issue)
         if (BITMAP) {
-            const uint32_t w32[4] = {(uint32_t)q[0].x, (uint32_t)(q[0].x >> 32), (uint32_t)q[0].y, (uint32_t)(q[0].y >> 32)};
+            const uint32_t w32[4] = {(uint32_t)un.q[0].x, (uint32_t)(un.q[0].x >> 32), (uint32_t)un.q[0].y, (uint32_t)(un.q[0].y >> 32)};
+            uint4 t[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = *reinterpret_cast<const uint4 *>(s_tag + (w32[i] >> (kPair32Shift + TAGBITS)) * 8u);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                valid[i] = (uint32_t)i < qv[0];
-                const uint32_t key = qv[1] + (uint32_t)i + (w32[i] & 255u) * cap;
-                pr[i] = ((unsigned long long)(w32[i] >> kPair32Shift) << 32) | (key << 1) | ((w32[i] >> 9) & 1u);
+                const uint32_t w = w32[i];
+                // value = (segment, window, position) << 1 | alive: the window and the alive bit are the pair's low bits
+                uint32_t val = ((w & 0x1FEu) << ksh) | (un.nv[1] + 2u * (uint32_t)i);
+                val = (val & ~1u) | (w & 1u);
+                const uint32_t tag = ((w >> kPair32Shift) & ((1u << TAGBITS) - 1u)) + 1u;
+                const uint32_t e = find_tag(t[i], tag);
+                const bool valid = (uint32_t)i < un.nv[0];
+                if (valid && e < 8u) atomicMax(&s_val[(w >> (kPair32Shift + TAGBITS)) * 8u + e], val);
+                const bool miss = valid && e >= 8u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);   // (__ballot goes through an int: a select and a compare)
+                if (miss)
+                    missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        ((unsigned long long)(w >> kPair32Shift) << 32) | val;
+                mq += (uint32_t)__popcll(m);
             }
-        } else {
-            pr[0] = q[0].x, pr[1] = q[0].y, pr[2] = q[1].x, pr[3] = q[1].y;
-            valid[0] = qv[0] > 0u, valid[1] = qv[0] > 1u, valid[2] = qv[1] > 0u, valid[3] = qv[1] > 1u;
+            drain_full(par);
+            return;
         }
+        // the lane's four pairs as (slot in the bucket, value to maximise): value = order << 1 | alive
+        unsigned long long pr[4] = {un.q[0].x, un.q[0].y, un.q[1].x, un.q[1].y};
+        const bool valid[4] = {un.nv[0] > 0u, un.nv[0] > 1u, un.nv[1] > 0u, un.nv[1] > 1u};
         uint32_t set[4], tag[4], hr[4];
         uint4 t[4];
 #pragma unroll
@@ -1314,7 +1447,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             }
             mq += cnt < room ? cnt : room;
         }
-        if (mq > kMissQueue / 2 || __any(waiting != 0u) || (edge && mq != 0u)) {
+        if (mq > kMissQueue / 2 || __any(waiting != 0u)) {
             for (;;) {                                    // (leaves the queue empty)
                 drain(par);
                 if (!__any(waiting != 0u)) break;
@@ -1332,50 +1465,66 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     };
     // The driver.  First without checkpoints (no barrier until the end: a compacted topic's bucket fits the table);
     // a bucket that overflows table AND side table that way starts over in careful mode, and tells the buckets
-    // still to come (POOL_DENSE).  Careful mode: after every trip that ends on a group boundary (every wave has
+    // still to come (POOL_DENSE).  Careful mode: after every unit that ends a group of segments (every wave has
     // finished whole segments: everything merged so far is older than everything that follows — what the bit set
     // state needs) the workgroup decides whether the table is emptied before it goes on.  Every thread keeps the
     // instalment's totals in registers, fed from the counter slot of the interval just ended (ApplyShared).
+    // (Whatever the workgroup decides on comes out of LDS through readfirstlane: a value loaded per lane is divergent
+    // to the compiler, and so is every loop counter of a loop that such a value leaves.)
     uint32_t inst_start = 0;                            // first segment of the current instalment
     uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
-    uint32_t u = 0;
+    uint32_t u = 0;                                     // the unit that is merged next
+    constexpr int D = BITMAP ? kApplyDepth : 2;        // (table state: 8-byte pairs, two loads a unit — the registers for two)
+    Unit ring[D];
     for (;;) {                                          // one pass per instalment (one more per restart)
-        // Two units per trip, the buffers alternating: copying the prefetched registers into the current ones at the
-        // end of an iteration would make the compiler wait for the prefetch right where it was issued.
-        // The prefetch is issued unconditionally (a unit past the end loads a clamped address and merges nothing):
-        // under a branch the compiler could not count it and would wait with vmcnt(0).
+        // D units per trip, the buffers taking turns: copying prefetched registers into "current" ones
+        // would make the compiler wait for the prefetch right where it was issued.  The prefetch is issued
+        // unconditionally (a unit past the end loads a clamped address and merges nothing): under a branch the
+        // compiler could not count it and would wait with vmcnt(0).
         dynamic = !careful;
-        issue(u, p, nv);
-        bool flush = false, failed = false;
-        while (dynamic ? seg < W : u < units) {
-            if (!careful && sh.fail[0]) break;            // (fast attempt) some wave ran out of room: stop early
-            issue(u + 1, pn, nvn);
-            merge(p, nv, par, false);
-            issue(u + 2, p, nv);
-            merge(pn, nvn, par, false);
-            u += 2;
-            // the queued misses are in before anybody looks at the table as a whole
-            if ((dynamic ? seg >= W : u >= units) || (careful && u % chunks == 0u)) drain(par);
-            KTA_PHASE(1, 3);
-            if (careful && u % chunks == 0u && u < units) {
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
-                if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
-                claimed = 0;
-                lds_barrier();
-                tot_occ += sh.occ[par];
-                tot_ovf += sh.ovf_n[par];
-                failed = sh.fail[par] != 0u;
-                if (threadIdx.x == 0) sh.occ[(par + 2u) % 3u] = sh.ovf_n[(par + 2u) % 3u] = 0;
-                par = (par + 1u) % 3u;
-                // empty the table when the next interval, growing like the last one, would take it past kFlushAt
-                const uint32_t grew = tot_occ - last_occ;
-                last_occ = tot_occ;
-                flush = tot_occ + grew + grew / 4 > kFlushAt || tot_ovf > kOvf / 2;
-                KTA_PHASE(1, 4);
-                if (failed || flush) break;
+        for (int s = 0; s + 1 < D; s++) issue(u + (uint32_t)s, ring[s]);
+        bool flush = false, failed = false, stop = false;
+        // (fast attempt: `seg` is the segment of the unit issued LAST; segments are handed out in ascending order, so
+        // once it is past the end every unit still in flight is empty or about to be merged by the trip)
+        while (!stop && (dynamic ? seg < W : u < units)) {
+            if (!careful && __builtin_amdgcn_readfirstlane(sh.fail[0])) break;   // (fast attempt) some wave ran out of room: stop early
+#pragma unroll
+            for (int s = 0; s < D; s++) {
+                if (stop) break;
+                issue(u + (uint32_t)D - 1u, ring[(s + D - 1) % D]);
+                merge(ring[s], par);
+                u++;
+                KTA_PHASE(1, 3);
+                if (careful && u % chunks == 0u) {
+                    drain(par);                           // the queued misses are in before anybody looks at the table as a whole
+                    if (u < units) {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
+                        if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
+                        claimed = 0;
+                        lds_barrier();
+                        tot_occ += __builtin_amdgcn_readfirstlane(sh.occ[par]);
+                        tot_ovf += __builtin_amdgcn_readfirstlane(sh.ovf_n[par]);
+                        failed = __builtin_amdgcn_readfirstlane(sh.fail[par]) != 0u;
+                        if (threadIdx.x == 0) sh.occ[(par + 2u) % 3u] = sh.ovf_n[(par + 2u) % 3u] = 0;
+                        par = (par + 1u) % 3u;
+                        // empty the table when the next interval, growing like the last one, would take it past kFlushAt
+                        const uint32_t grew = tot_occ - last_occ;
+                        last_occ = tot_occ;
+                        flush = tot_occ + grew + grew / 4 > kFlushAt || tot_ovf > kOvf / 2;
+                        KTA_PHASE(1, 4);
+                        if (failed || flush) stop = true;   // (the units in flight are issued again by the next pass, from u)
+                    }
+                }
             }
         }
+        // the trip's remaining units (fast attempt: in flight and not empty) are merged before the verdict
+        if (dynamic && !stop) {
+#pragma unroll
+            for (int s = 0; s + 1 < D; s++) merge(ring[s], par);
+        }
+        drain(par);
         if (dynamic && !flush) u = units;                // (segments were handed out: every wave counted its own units)
         if (!failed && !flush) {                         // the last units are in: did everything fit?
 #pragma unroll
@@ -1383,7 +1532,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
             claimed = 0;
             lds_barrier();
-            failed = (sh.fail[0] | sh.fail[1] | sh.fail[2]) != 0u;
+            failed = __builtin_amdgcn_readfirstlane(sh.fail[0] | sh.fail[1] | sh.fail[2]) != 0u;
         }
         if (failed) {
             if (careful) {
@@ -1403,9 +1552,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                     sh.any_ovf = 0;
                     pool_ctl[POOL_DENSE] = 1ull;
                 }
-                {
-                    mq = 0;
-                }
+                mq = 0;
+                claimed = 0;
                 careful = true;
                 u = 0;
                 lds_barrier();
@@ -1490,8 +1638,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
                 const uint32_t p32 = seg[k];
                 const uint32_t h = p32 >> kPair32Shift;
                 if (h / kSub != r) continue;
-                const unsigned long long order = ((unsigned long long)(w * 256u + (p32 & 255u)) << 30) | k;
-                atomicMax(&s_max[h % kSub], (order << 1) | ((p32 >> 9) & 1u));
+                const unsigned long long order = ((unsigned long long)(w * 256u + ((p32 >> 1) & 255u)) << 30) | k;
+                atomicMax(&s_max[h % kSub], (order << 1) | (p32 & 1u));
             }
         }
         for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
@@ -1552,6 +1700,14 @@ __global__ __launch_bounds__(kWG) void kta_bitmap_count(const uint4 *__restrict_
     }
 }
 
+// tools/ubench_alive.hip times the kernels of a pair one by one: events between the launches (compiled out of the library)
+#ifdef KTA_UBENCH_EVENTS
+hipEvent_t g_ub_ev[4];
+#define KTA_UB_MARK(i) (void)hipEventRecord(g_ub_ev[i], s)
+#else
+#define KTA_UB_MARK(i)
+#endif
+
 template <int BLOG2>
 hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
                        const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
@@ -1568,19 +1724,25 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     uint32_t *flag = hist + B;
     const bool bitmap = st.bitmap != nullptr;
     if (bitmap != pl.pair32) return hipErrorInvalidValue;      // the plan sized the workspace for the other pair format
+    // (the area a wave's slice of the bit set goes through doubles as the waves' miss queues: the larger of the two)
+    constexpr size_t kSliceBytes = (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8, kQueueBytes = (size_t)kApplyWaves * kMissQueue * 8;
     const size_t lds2 = (size_t)kEntries * 6 + (size_t)kOvf * 8 + (size_t)((pl.segment_wgs + 31u) & ~31u) * 4 +
-                        (size_t)(kSliceSets << (32 - BLOG2 - kSetLog2)) / 8;   // the slice area doubles as the waves' miss queues
+                        (kSliceBytes > kQueueBytes ? kSliceBytes : kQueueBytes);
     if (bitmap) {
         // 4-byte pairs; 4-byte column loads: any alignment of the columns will do
-        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard * 2 + (size_t)kConsumers * 64 * 4 + 16;
+        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard + (size_t)kConsumers * 64 * 4 + 16;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
+        KTA_UB_MARK(0);
         hipLaunchKernelGGL((kta_alive_partition32<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
                            reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        KTA_UB_MARK(1);
 #ifdef KTA_DBG_PART_ONLY
+        KTA_UB_MARK(2);
+        KTA_UB_MARK(3);
         return e;
 #endif
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
@@ -1592,12 +1754,14 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                            WrittenList{nullptr, nullptr, 0});
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        KTA_UB_MARK(2);
         const size_t lds3 = (size_t)8 << 14;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_fallback<BLOG2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, reinterpret_cast<const uint32_t *>(pp),
                            ws.counts, pl.cap, pl.segment_wgs, pool, ctl, ws.fail_from, st.bitmap, run);
+        KTA_UB_MARK(3);
         return hipGetLastError();
     }
     // table state: 8-byte pairs (the survivors' sequence numbers come from their batch-local indices)
@@ -1651,7 +1815,11 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
 {
     AlivePartitionPlan pl;
     pl.pair32 = pair32;
+#ifdef KTA_P32_EXP_BLOG2   /* experiment (partition kernel only): another number of buckets */
+    pl.bucket_log2 = pair32 ? KTA_P32_EXP_BLOG2 : 10u;
+#else
     pl.bucket_log2 = 10u;
+#endif
     pl.max_records = kAlivePartitionMax;
     if (n > pl.max_records) n = pl.max_records;
     if (n == 0) n = 1;
@@ -1679,6 +1847,9 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
 hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
                                     const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
 {
+#ifdef KTA_P32_EXP_BLOG2
+    if (pl.pair32) return launch_pair<KTA_P32_EXP_BLOG2>(c, n, base_seq, st, pl, ws, stats, s);
+#endif
     return launch_pair<10>(c, n, base_seq, st, pl, ws, stats, s);
 }
 

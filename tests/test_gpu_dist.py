@@ -166,16 +166,15 @@ def test_native_exchange_over_rccl(tmp_path, nranks):
 
 _THREADED_WORKER = r'''
 import os, sys, threading
-root, nranks = sys.argv[1], int(sys.argv[2])
+root, nranks, P, alive = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "1"
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import kafka_topic_analyzer_amd as kta
 from helpers import random_cols, NOW
 from oracle_c import Oracle
-P = 10
 rng = np.random.default_rng(5 + nranks)
 cols = random_cols(rng, 400000, P, key_space=30000, tomb=0.35)
-o = Oracle(NOW, True); o.run_soa(cols)
+o = Oracle(NOW, alive); o.run_soa(cols)
 n = len(cols["partition"])
 seq = np.arange(n, dtype=np.uint64)
 def shard_of(rank):
@@ -192,20 +191,22 @@ uid = kta.HipMetricHandler.comm_unique_id()
 errors, stats = [], [None] * nranks
 def run(rank):
     try:
-        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=True)
+        h = kta.HipMetricHandler(P, count_alive_keys=alive, now=NOW, alive_table=alive)
         h.comm_create(nranks, rank, uid)
-        b, nb = h.upload_batch(shard_of(rank), with_keys=True)
+        b, nb = h.upload_batch(shard_of(rank), with_keys=alive)
         h.submit_device(b, nb, 0)
         for _ in range(2):                     # the second exchange finds every owner's range already merged
             h.exchange()
             res, c = h.exchange_result()
-            assert res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
+            assert not alive or res.alive_keys == o.alive_keys(), (rank, res.alive_keys, o.alive_keys())
             assert np.array_equal(c, o.counters(P)) and res.overall_count == n
-        lo, hi = -((-rank * (1 << 32)) // nranks), -((-(rank + 1) * (1 << 32)) // nranks)
-        words = h.export_alive_bitmap()        # this rank's table is the merged one on its own hash range
-        want = o.alive_words()
-        wl, wh = (lo + 31) // 32, hi // 32
-        assert np.array_equal(words[wl:wh], want[wl:wh]), rank
+            assert res.smallest_message == o.get("smallest_message") and res.largest_message == o.get("largest_message")
+        if alive:
+            lo, hi = -((-rank * (1 << 32)) // nranks), -((-(rank + 1) * (1 << 32)) // nranks)
+            words = h.export_alive_bitmap()    # this rank's table is the merged one on its own hash range
+            want = o.alive_words()
+            wl, wh = (lo + 31) // 32, hi // 32
+            assert np.array_equal(words[wl:wh], want[wl:wh]), rank
         ends = np.zeros(P, np.int64); ends[rank::nranks] = 7
         assert np.array_equal(h.comm_allreduce_i64(ends), np.full(P, 7))
         stats[rank] = h.comm_info()
@@ -216,17 +217,21 @@ def run(rank):
 ts = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
 [t.start() for t in ts]; [t.join() for t in ts]
 assert not errors, errors
-assert sum(s[2] for s in stats) == sum(s[3] for s in stats) > 0      # every entry sent was received
+assert sum(s[2] for s in stats) == sum(s[3] for s in stats)          # every entry sent was received
+assert not alive or sum(s[2] for s in stats) > 0
 print("OK", stats)
 '''
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks):
+@pytest.mark.parametrize("nranks,P,alive", [(2, 10, True), (3, 10, True), (4, 256, True), (8, 256, False)])
+def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks, P, alive):
     """The multi-rank paths of csrc/kta_comm.hip (per-owner export, count all-gather, grouped send / recv,
-    owner merge + range count, SUM / MAX all-reduce) with 2 and 3 ranks as threads of one process on the one
+    owner merge + range count, SUM / MAX all-reduce) with 2, 3, 4 and 8 ranks as threads of one process on the one
     reachable GPU, RCCL replaced by tests/mock_rccl.cpp: every rank ends with the unsharded oracle's counters
-    and alive count, and with the oracle's BitSet on the hash range it owns."""
+    and alive count, and with the oracle's BitSet on the hash range it owns.  The target machine has eight GPUs:
+    config 4's sharding (256 partitions, 32 per rank, p % 8) runs with all eight communicator ranks; with -c every
+    rank keeps a 32 GiB table, of which four fit the one GPU here and eight do not (8 x 32 GiB + workspaces > 288 GB),
+    so the hash-range exchange runs with four owners (hash_range(r, 4))."""
     lib = tmp_path / "libmock_rccl.so"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
                         "-o", str(lib)], capture_output=True, text=True, timeout=600)
@@ -234,5 +239,6 @@ def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks):
     script = tmp_path / "w.py"
     script.write_text(_THREADED_WORKER)
     env = dict(os.environ, KTA_RCCL_LIBRARY=str(lib))
-    r = subprocess.run([sys.executable, str(script), ROOT, str(nranks)], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(nranks), str(P), "1" if alive else "0"], capture_output=True,
+                       text=True, timeout=900, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

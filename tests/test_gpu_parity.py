@@ -417,6 +417,57 @@ def test_partitioned_alive_pass_at_scale_vs_oracle(hc, ht, state, preset, log2n)
     hc.device_batch_free(b)
 
 
+def _fnv32_np(keys16):
+    """The reference's FNV variant (src/fnv32.rs:92-101: multiplier = offset basis) over the rows of a [n, 16] byte array."""
+    h = np.full(len(keys16), 0x811c9dc5, np.uint64)
+    for j in range(keys16.shape[1]):
+        h = ((h ^ keys16[:, j]) * np.uint64(0x811c9dc5)) & np.uint64(0xFFFFFFFF)
+    return h.astype(np.uint32)
+
+
+@pytest.mark.parametrize("state", ["bitset", "table"])
+@pytest.mark.parametrize("shape,log2n", [("one_key", 26), ("forty_keys", 26), ("one_bucket", 24)])
+def test_adversarial_alive_shapes_at_scale(hc, ht, state, shape, log2n):
+    """What defeats the sizes of the partitioned pass, at scale, against the single BitSet oracle (count + every bit):
+    ONE key over 2^26 records and 40 keys over 2^26 records (a compacted topic with dominant keys: the guard of the
+    partition kernel drops what the same wave instruction supersedes, the rest overflows the hot buckets' segments into
+    the pool — bit set state: kta_alive_fallback; table state: the direct path), and 4096 keys that all hash into ONE
+    bucket (same top 10 hash bits) over 2^24 records: every pair of the batch in one region, nothing for the other 1023
+    workgroups of pass 2.  Half of the records are tombstones, so the order of the records decides every bit
+    (/root/reference/src/metric.rs:289-304)."""
+    h = ht if state == "table" else hc
+    n = 1 << log2n
+    if shape == "one_bucket":
+        rng = np.random.default_rng(77)
+        cand = rng.integers(0, 256, size=(6_000_000, 16), dtype=np.uint8)
+        hh = _fnv32_np(cand)
+        pick = cand[(hh >> 22) == 0x2A5][:4096]
+        assert len(pick) == 4096 and fnv32(pick[0].tobytes()) >> 22 == 0x2A5
+        kid = rng.integers(0, 4096, size=n)
+        cols = {"partition": (kid % 64).astype(np.int32), "key_len": np.full(n, 16, np.int32),
+                "val_len": np.where(rng.random(n) < 0.5, -1, 100).astype(np.int32),
+                "ts_ms": np.full(n, 1_600_000_000_000, np.int64), "key_off": (np.arange(n, dtype=np.uint64) * 16).astype(np.uint32),
+                "key_bytes": pick[kid].reshape(-1), "n_key_bytes": 16 * n}
+    else:
+        sp, _ = kta.synth_preset("c3")
+        sp.n_distinct_keys = 1 if shape == "one_key" else 40
+        sp.tombstone_permille = 500
+        cols = kta.synth_fill_host(sp, 0, n, with_keys=True)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    h.reset()
+    h.set_tuning(alive_variant=13)       # the partitioned pass in either state
+    b, nb = h.upload_batch(cols, with_keys=True)
+    h.submit_device(b, nb, 0, which=2)
+    h.submit_device(b, nb, nb, which=2)  # and once more: the same records on top of what they left
+    o.run_soa(cols)
+    res, _ = h.finish()
+    h.set_tuning()
+    h.device_batch_free(b)
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
+
+
 def test_max_partitions_uses_large_dynamic_lds():
     P = 4096  # 96 KiB of LDS partials per workgroup
     rng = np.random.default_rng(41)

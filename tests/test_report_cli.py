@@ -270,6 +270,24 @@ def mock_rccl(tmp_path_factory):
 
 
 @pytest.mark.gpu
+def test_cli_sharded_over_eight_ranks_prints_the_single_gpu_report(mock_rccl):
+    """kta.gpus=8 on config 4's sharding (256 partitions, 32 per rank): the eight communicator ranks of the target
+    machine, here as eight threads on the one reachable GPU with tests/mock_rccl.cpp.  Without -c (eight 32 GiB
+    tables do not fit one GPU); with -c on four ranks."""
+    env = dict(os.environ, KTA_RCCL_LIBRARY=mock_rccl)
+    one = run_cli("-t", "c4", "-b", "synthetic://c4?records=400000")
+    many = subprocess.run([CLI, "-t", "c4", "-b", "synthetic://c4?records=400000", "--librdkafka",
+                           "kta.gpus=8,kta.batch=16384,kta.oversubscribe=1"], capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    assert _normalise(many.stdout) == _normalise(one.stdout)
+    one = run_cli("-t", "c3", "-b", "synthetic://c3?records=300000", "-c")
+    many = subprocess.run([CLI, "-t", "c3", "-b", "synthetic://c3?records=300000", "-c", "--librdkafka",
+                           "kta.gpus=4,kta.batch=16384,kta.oversubscribe=1"], capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    assert "Alive keys: " in one.stdout and _normalise(many.stdout) == _normalise(one.stdout)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_cli_sharded_over_several_ranks_prints_the_single_gpu_report(tmp_path, mock_rccl, gpus):
     """kta.gpus=N: partition p on rank p % N (one thread + context + communicator rank each; here all on the one

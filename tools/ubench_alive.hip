@@ -5,6 +5,7 @@
 #ifndef KTA_NO_PHASES
 #define KTA_ALIVE_PHASES 1
 #endif
+#define KTA_UBENCH_EVENTS 1   // bit set state: events between the kernels of a pair (partition / apply / fallback)
 #include "../kafka_topic_analyzer_amd/csrc/kta_alive.hip"
 
 #include <stdio.h>
@@ -63,6 +64,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d_stats, 32));
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 4; i++) hipEventCreate(&kta::g_ub_ev[i]);
     for (int rep = 0; rep < 4; rep++) {
         unsigned long long zero[16] = {0};
 #ifdef KTA_ALIVE_PHASES
@@ -89,6 +91,13 @@ int main(int argc, char **argv)
         const double w1 = pl.segment_wgs, w2 = (double)(1u << pl.bucket_log2);
         printf("rep %d: %.3f ms = %.1f G records/s  alive=%lld  pool pairs=%llu  buckets given to the fallback=%llu\n", rep, ms,
                n / ms / 1e6, alive, pc[0], pc[1]);
+        if (!table_state) {
+            float t1 = 0, t2 = 0, t3 = 0;
+            hipEventElapsedTime(&t1, kta::g_ub_ev[0], kta::g_ub_ev[1]);
+            hipEventElapsedTime(&t2, kta::g_ub_ev[1], kta::g_ub_ev[2]);
+            hipEventElapsedTime(&t3, kta::g_ub_ev[2], kta::g_ub_ev[3]);
+            printf("kernels %d: partition %.3f  apply %.3f  fallback %.3f ms\n", rep, t1, t2, t3);
+        }
         printf("   partition per workgroup (us, thread 0's wave): wait+hash %.1f  positions %.1f  inserts %.1f  queueing %.1f  write-out %.1f  ring wait %.1f  tail %.1f\n",
                ph[0] / w1 / 100, ph[1] / w1 / 100, ph[2] / w1 / 100, ph[3] / w1 / 100, ph[5] / w1 / 100, ph[4] / w1 / 100, ph[7] / w1 / 100);
         printf("   apply per workgroup (us):     init %.1f  loads+merge %.1f  checkpoints %.1f  rest %.1f  end %.1f   (x %.0f workgroups / 256 CUs)\n",
