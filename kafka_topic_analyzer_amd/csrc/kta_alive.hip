@@ -829,6 +829,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         constexpr uint32_t kChunks = B / (64u * kConsumers);
         const uint32_t cw = wave - (uint32_t)kProducers;
         uint32_t *list = s_list + cw * 64u;
+#ifdef KTA_P32_STORE_LOG
+        if (lane == 0) s_list[kConsumers * 64 + 4 + cw] = 0u;
+#endif
         for (;;) {
 #if KTA_DBG_LEVEL >= 1 && KTA_DBG_LEVEL <= 2
             break;
@@ -867,6 +870,16 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 #else
                             {
                                 uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
+#ifdef KTA_P32_STORE_LOG       /* experiment: the blocks of a consumer wave one behind the other, in the order they leave */
+                                {
+                                    const unsigned long long gm = __builtin_amdgcn_ballot_w64(go && piece == 0u);
+                                    const uint32_t rank = (uint32_t)__popcll(gm & ((1ull << (lane & ~(kBlkLanes - 1u))) - 1ull));
+                                    const uint32_t cur = s_list[kConsumers * 64 + 4 + cw];      // (a word behind s_misc's two)
+                                    KTA_LDS_ORDER();
+                                    if (piece == 0u && rank == 0u) s_list[kConsumers * 64 + 4 + cw] = cur + (uint32_t)__popcll(gm);
+                                    at = ((uint64_t)(w * kConsumers + cw) * (B / kConsumers) * cap) + (uint64_t)(cur + rank) * kBlk32 + piece * 4u;
+                                }
+#endif
 #ifdef KTA_P32_STORE_WRAP      /* experiment: every block into the same 32 MB */
                                 at &= (8u << 20) - 1u;
 #endif
@@ -1620,15 +1633,34 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
 {
     constexpr uint32_t RBITS = 32 - BLOG2;
     constexpr uint32_t kSub = 1u << 14;                  // slots per pass
+    constexpr uint32_t kRanges = (1u << RBITS) / kSub;   // 256 sub-ranges of a bucket
     extern __shared__ __attribute__((aligned(128))) unsigned long long s_max[];   // kSub values: order << 1 | alive
     __shared__ long long s_w[kApplyWaves];
+    __shared__ uint8_t s_has[kRanges];                   // the sub-ranges that hold a pair at all
     if (pool_ctl[POOL_FAILED] == 0ull) return;
     const uint32_t b = blockIdx.x, from = fail_from[b];
     if (from == kNoFail) return;
     const unsigned long long npool = pool_ctl[POOL_CURSOR];
     uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
     long long delta = 0;
-    for (uint32_t r = 0; r < (1u << RBITS) / kSub; r++) {
+    // What sends a bucket here is mostly a handful of hot keys (their pairs overflow the segments into the pool): its
+    // pairs then sit in very few of the 256 sub-ranges, and a pass reads ALL pairs of the bucket and the whole pool.
+    // One more walk first, to find the sub-ranges that hold anything (every writer writes the same 1: no atomic).
+    for (uint32_t r = threadIdx.x; r < kRanges; r += kApplyThreads) s_has[r] = 0;
+    __syncthreads();
+    for (uint32_t w = from; w < W; w++) {
+        const uint32_t cnt = counts[(uint64_t)b * W + w];
+        const uint32_t *seg = pairs + ((uint64_t)b * W + w) * cap;
+        for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) s_has[(seg[k] >> kPair32Shift) / kSub] = 1;
+    }
+    for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
+        const unsigned long long pr = pool[k];
+        const uint32_t hh = (uint32_t)(pr >> 32);
+        if (pr != 0ull && (hh >> RBITS) == b && (((uint32_t)pr >> 9) & 1023u) >= from) s_has[(hh & ((1u << RBITS) - 1u)) / kSub] = 1;
+    }
+    __syncthreads();
+    for (uint32_t r = 0; r < kRanges; r++) {
+        if (!s_has[r]) continue;                         // (the same for every thread: read after the barrier)
         for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0ull;
         __syncthreads();
         for (uint32_t w = from; w < W; w++) {
@@ -1730,7 +1762,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                         (kSliceBytes > kQueueBytes ? kSliceBytes : kQueueBytes);
     if (bitmap) {
         // 4-byte pairs; 4-byte column loads: any alignment of the columns will do
-        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard + (size_t)kConsumers * 64 * 4 + 16;
+        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard + (size_t)kConsumers * 64 * 4 + 16 + 64;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
@@ -1809,6 +1841,11 @@ const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2)
 {
     return reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned long long *>(ws.pool_ctl) + POOL_WORDS) +
            (1u << bucket_log2);
+}
+
+const void *alive_failed_word(const AliveWorkspace &ws)
+{
+    return reinterpret_cast<const unsigned long long *>(ws.pool_ctl) + POOL_FAILED;
 }
 
 AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32)

@@ -83,6 +83,9 @@ struct kta_ctx {
     uint64_t *d_alive_stats = nullptr, *h_alive_stats = nullptr;
     hipEvent_t ev_alive_stats = nullptr;
     bool alive_stats_pending = false;
+    // bit set state: batches of mostly unique keys are applied in smaller slices (see run_device_batch)
+    uint64_t alive_slice = kta::kAlivePartitionMax;
+    bool alive_failed_pending = false;
     int alive_backoff = 0;
     std::vector<Stage> stages;
     uint64_t batch_capacity = 0, key_bytes_capacity = 0;
@@ -286,10 +289,22 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 KTA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_alive_stats, hipEventDisableTiming));
             }
             const bool report = ctx->alive_table && !ctx->alive_stats_pending;       // one report in flight at a time
+            // Bit set state: a bucket with more distinct slots than pass 2's LDS table takes is applied in instalments,
+            // as long as an instalment's segments fit the table; at 2^28 records of mostly unique keys (config 5's law
+            // on ONE GPU) they do not, and the bucket goes to kta_alive_fallback — exact, 70 times slower.  The number of
+            // buckets a batch handed over comes back with the stream (never waited for); once it was not zero, the
+            // batches that follow are applied in slices of 2^26 records: 16 segments of a bucket then hold 4 k pairs.
+            if (!ctx->alive_table && ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
+                ctx->alive_failed_pending = false;
+                if (ctx->h_alive_stats[2] != 0 && ctx->alive_slice > (1ull << 26)) ctx->alive_slice = 1ull << 26;
+            }
+            uint64_t first_take = 0;
             if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 4 * sizeof(uint64_t), ctx->s_compute));
             for (uint64_t at = 0; at < n;) {
-                kta::AlivePartitionPlan pl = kta::plan_alive_partition(n - at, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
-                const uint64_t take = n - at < pl.max_records ? n - at : pl.max_records;
+                const uint64_t left = !ctx->alive_table && n - at > ctx->alive_slice ? ctx->alive_slice : n - at;
+                kta::AlivePartitionPlan pl = kta::plan_alive_partition(left, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
+                const uint64_t take = left < pl.max_records ? left : pl.max_records;
+                if (at == 0) first_take = take;
                 if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words || ctx->pool_cap < pl.pool_words) {
                     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
                     if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
@@ -320,6 +335,15 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                                                           ctx->d_alive_running, ctx->s_compute,
                                                           kta::alive_order_flag(ws, (int)pl.bucket_log2), written_list(ctx)));
                 at += take;
+            }
+            if (!ctx->alive_table && !ctx->alive_failed_pending && first_take >= (1ull << 27) && ctx->alive_slice > (1ull << 26)) {
+                // (the last slice's word; hot keys that overflow their segments send buckets to the fallback kernel as
+                // well, whatever the size of the slice — batches that small are left as they are)
+                KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats + 2, kta::alive_failed_word(
+                                                kta::AliveWorkspace{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from}),
+                                            sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->s_compute));
+                KTA_HIP(ctx, hipEventRecord(ctx->ev_alive_stats, ctx->s_compute));
+                ctx->alive_failed_pending = true;
             }
             if (report) {
                 KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats, ctx->d_alive_stats, 2 * sizeof(uint64_t),

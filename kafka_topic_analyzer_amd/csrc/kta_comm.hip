@@ -126,7 +126,8 @@ Rccl *rccl()
 struct CommState {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
-    uint64_t *d_counts = nullptr;      // [nranks] entries this rank sends to every owner, then [nranks x nranks] gathered
+    uint64_t *d_counts = nullptr;      // [nranks] entries this rank sends to every owner, then [nranks x nranks] gathered, ..., the overflow flag
+    uint64_t *h_pinned = nullptr;      // pinned: [nranks + nranks x nranks + 1] read back, then [nranks] offsets of the owners' lists
     uint64_t *d_scalar = nullptr;
     uint32_t *d_send_slots = nullptr, *d_recv_slots = nullptr;
     uint64_t *d_send_vals = nullptr, *d_recv_vals = nullptr;
@@ -141,6 +142,7 @@ void free_comm(void *p)
     if (!st) return;
     if (st->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(st->comm);
     if (st->d_counts) (void)hipFree(st->d_counts);
+    if (st->h_pinned) (void)hipHostFree(st->h_pinned);
     if (st->d_scalar) (void)hipFree(st->d_scalar);
     if (st->d_send_slots) (void)hipFree(st->d_send_slots);
     if (st->d_recv_slots) (void)hipFree(st->d_recv_slots);
@@ -195,46 +197,54 @@ int grow(kta_ctx *ctx, uint32_t **slots, uint64_t **vals, uint64_t *cap, uint64_
 // time (WrittenList), so counting per owner, exporting per owner and counting the own range are passes over that
 // list (4 bytes per distinct key hash) with gathers from the table — not sweeps of the 32 GiB table, whose cost
 // would not depend on how few keys the rank saw.  The sweeps remain as the fallback for a list that overflowed or
-// a table somebody else wrote into (kta_alive_table_modified).  One host synchronisation remains in either form:
-// the sizes of the sends and receives have to be known to the host that issues them.
+// a table somebody else wrote into (kta_alive_table_modified).  ONE host synchronisation remains in either form:
+// the sizes of the sends and receives have to be known to the host that issues them.  The list's length never comes
+// to the host (the kernels read it on the device; a list that overflowed raises a flag that travels with the counts),
+// and what the host hands to the device afterwards (the offsets of the owners' lists) leaves from pinned memory.
 int exchange_alive(kta_ctx *ctx, CommState *st)
 {
     Rccl *R = rccl();
     hipStream_t s = kta_internal_stream(ctx);
     uint64_t *table = kta_internal_table(ctx);
     const int n = st->nranks;
-    if (!st->d_counts) CH(ctx, hipMalloc((void **)&st->d_counts, (size_t)(3 * n + n * n) * sizeof(uint64_t)));
+    // what a rank contributes to the all-gather: its n counts and its overflow flag; what comes back: n such rows
+    const size_t row = (size_t)n + 1, n_read = row + row * n;
+    if (!st->d_counts) CH(ctx, hipMalloc((void **)&st->d_counts, (n_read + 2 * (size_t)n) * sizeof(uint64_t)));
+    if (!st->h_pinned) CH(ctx, hipHostMalloc((void **)&st->h_pinned, (n_read + (size_t)n) * sizeof(uint64_t), hipHostMallocDefault));
     if (!st->d_scalar) CH(ctx, hipMalloc((void **)&st->d_scalar, sizeof(uint64_t)));
     kta::WrittenList wl;
     bool listed = kta_internal_written(ctx, &wl);
     if (n > 64) listed = false;                          // the list kernels keep one LDS counter per owner, 64 of them: sweep
-    uint64_t *d_owner_at = st->d_counts + n + n * n, *d_cursors = d_owner_at + n;
+    uint64_t *d_flag = st->d_counts + n, *d_owner_at = st->d_counts + n_read, *d_cursors = d_owner_at + n;
+    const uint64_t *send = st->h_pinned, *matrix = st->h_pinned + row;          // matrix[r * row + o]: rank r's entries for owner o
+    uint64_t *h_owner_at = st->h_pinned + n_read;
     // 1. how many entries does this rank hold for every owner
-    std::vector<uint64_t> send(n), matrix((size_t)n * n);
-    uint64_t n_written = 0;
-    if (listed) {
-        CH(ctx, hipMemcpyAsync(&n_written, wl.n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        CH(ctx, hipStreamSynchronize(s));
-        listed = n_written <= wl.cap;                    // the list overflowed: sweep
+    for (int attempt = 0;; attempt++) {
+        CH(ctx, hipMemsetAsync(st->d_counts, 0, row * sizeof(uint64_t), s));
+        if (listed) {
+            CH(ctx, kta::launch_written_count(wl, n, st->d_counts, d_flag, s));
+        } else {
+            for (int r = 0; r < n; r++)
+                CH(ctx, kta::launch_alive_count_written_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_counts + r, s));
+        }
+        CN(ctx, R->AllGather(st->d_counts, st->d_counts + row, row, ncclUint64, st->comm, s));
+        CH(ctx, hipMemcpyAsync(st->h_pinned, st->d_counts, n_read * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CH(ctx, hipStreamSynchronize(s));                // THE synchronisation of the exchange
+        // A list that overflowed (only its device knew) counted its first entries only: that rank counts again, with
+        // sweeps — and every rank gathers again, because all of them have to issue the same collectives: the flags
+        // travel with the counts, so all ranks see the same ones and decide alike.
+        bool any = false;
+        for (int r = 0; r < n; r++) any |= matrix[(size_t)r * row + n] != 0;
+        if (!any || attempt) break;
+        if (send[n] != 0) listed = false;
     }
-    if (listed) {
-        CH(ctx, hipMemsetAsync(st->d_counts, 0, (size_t)n * sizeof(uint64_t), s));
-        CH(ctx, kta::launch_written_count(wl, n_written, n, st->d_counts, s));
-    } else {
-        for (int r = 0; r < n; r++)
-            CH(ctx, kta::launch_alive_count_written_span(table, range_lo(r, n), range_lo(r + 1, n), st->d_counts + r, s));
-    }
-    CN(ctx, R->AllGather(st->d_counts, st->d_counts + n, (size_t)n, ncclUint64, st->comm, s));
-    CH(ctx, hipMemcpyAsync(send.data(), st->d_counts, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    CH(ctx, hipMemcpyAsync(matrix.data(), st->d_counts + n, (size_t)n * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    CH(ctx, hipStreamSynchronize(s));
     uint64_t send_total = 0, recv_total = 0;
     std::vector<uint64_t> send_at(n), recv_at(n);
     for (int r = 0; r < n; r++) {
         send_at[r] = send_total;
         if (r != st->rank) send_total += send[r];
         recv_at[r] = recv_total;
-        if (r != st->rank) recv_total += matrix[(size_t)r * n + st->rank];
+        if (r != st->rank) recv_total += matrix[(size_t)r * row + st->rank];
     }
     int rc = grow(ctx, &st->d_send_slots, &st->d_send_vals, &st->send_cap, send_total);
     if (rc != KTA_OK) return rc;
@@ -243,11 +253,10 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
     // 2. one contiguous list per owner (the rank's own range stays where it is)
     if (listed) {
         if (send_total) {
-            CH(ctx, hipMemcpyAsync(d_owner_at, send_at.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            for (int r = 0; r < n; r++) h_owner_at[r] = send_at[r];
+            CH(ctx, hipMemcpyAsync(d_owner_at, h_owner_at, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s));   // (pinned: no wait)
             CH(ctx, hipMemsetAsync(d_cursors, 0, (size_t)n * sizeof(uint64_t), s));
-            CH(ctx, kta::launch_written_export(wl, n_written, table, n, st->rank, d_owner_at, d_cursors, st->d_send_slots,
-                                               st->d_send_vals, s));
-            CH(ctx, hipStreamSynchronize(s));             // send_at (host memory) was the source of an async copy
+            CH(ctx, kta::launch_written_export(wl, table, n, st->rank, d_owner_at, d_cursors, st->d_send_slots, st->d_send_vals, s));
         }
     } else {
         for (int r = 0; r < n; r++) {
@@ -260,7 +269,7 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
     CN(ctx, R->GroupStart());
     for (int r = 0; r < n; r++) {
         if (r == st->rank) continue;
-        const uint64_t ns = send[r], nr = matrix[(size_t)r * n + st->rank];
+        const uint64_t ns = send[r], nr = matrix[(size_t)r * row + st->rank];
         if (ns) {
             CN(ctx, R->Send(st->d_send_slots + send_at[r], ns, ncclUint32, r, st->comm, s));
             CN(ctx, R->Send(st->d_send_vals + send_at[r], ns, ncclUint64, r, st->comm, s));
@@ -275,9 +284,10 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
     if (recv_total)
         CH(ctx, kta::launch_alive_import(st->d_recv_slots, st->d_recv_vals, recv_total, table, kta_internal_running(ctx), wl, s));
     uint64_t *dst = kta_internal_vec_out(ctx) + (size_t)kta_internal_partitions(ctx) * KTA_NCOUNTERS + KTA_G_ALIVE_KEYS;
-    if (listed && n_written + recv_total <= wl.cap) {
-        // (the list may have grown by the import: the kernel reads its length on the device, bounded by this sum)
-        CH(ctx, kta::launch_written_alive_count(wl, n_written + recv_total, table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
+    if (listed) {
+        // (the list may have grown by the import, past its capacity even: the kernels read its length on the device, and
+        // the range itself is counted when the list is no longer complete)
+        CH(ctx, kta::launch_written_alive_count(wl, table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
     } else {
         CH(ctx, kta::launch_alive_count_span(table, range_lo(st->rank, n), range_lo(st->rank + 1, n), dst, s));
     }

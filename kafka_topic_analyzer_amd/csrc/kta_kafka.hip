@@ -56,7 +56,9 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
     if (forced) return forced;
     if (n_batches < 2048) return 2;
     const uint64_t mean = blob_len / n_batches;
-    return mean < 4096 ? 5 : (mean < 65536 ? 4 : 3);
+    // (batches of 64 KiB and more: 4000 batches of 134 KiB are 2000 waves of the <2, 8 KiB> geometry — two per SIMD —
+    // and 17 windows each: 0.223 ms where <4, 4 KiB> took 0.316 and <1, 8 KiB> 0.333, round 4)
+    return mean < 4096 ? 5 : (mean < 65536 ? 4 : 7);
 }
 
 // ---- device-side byte reader over the blob: aligned 16-byte loads, one block cached -------------
@@ -1223,7 +1225,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..5 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..7 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1619,6 +1621,8 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     case 2: KTA_DECODE_COOP(1, 8192u, 256u); break;   // one wave per batch
     case 3: KTA_DECODE_COOP(4, 4096u, 64u); break;    // 16 lanes per batch, 4 KiB windows
     case 4: KTA_DECODE_COOP(4, 2048u, 32u); break;    // 16 lanes per batch, 2 KiB windows
+    case 6: KTA_DECODE_COOP(4, 8192u, 128u); break;   // 16 lanes per batch, 8 KiB windows
+    case 7: KTA_DECODE_COOP(2, 8192u, 128u); break;   // 32 lanes per batch, 8 KiB windows: batches of 64 KiB and more
     default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
     }
 #undef KTA_DECODE_COOP
@@ -1879,7 +1883,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 5) return KTA_ERR_INVALID;
+    if (!ctx || variant < 0 || variant > 7) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }

@@ -132,6 +132,8 @@ hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t 
                                     uint64_t *stats /* [pairs, claims] += ; may be null */, hipStream_t s);
 // device word that the launch pair sets when the batch's seq column does not ascend (the pair then did nothing)
 const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2);
+// bit set state: the word that counts the buckets the last launch pair handed to kta_alive_fallback
+const void *alive_failed_word(const AliveWorkspace &ws);
 // popcount of the bit set -> *out += (u64)
 hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)
@@ -148,11 +150,12 @@ hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint
                                int64_t *running, const WrittenList &written, hipStream_t s);
 // the exchange over the written list: entries per owner rank (owner(slot) = (slot * R) >> 32), their export as
 // one contiguous (slot, value) list per owner, and the alive count of one owner's range
-hipError_t launch_written_count(const WrittenList &wl, uint64_t n, int nranks, uint64_t *counts /* [nranks] += */, hipStream_t s);
-hipError_t launch_written_export(const WrittenList &wl, uint64_t n, const uint64_t *table, int nranks, int skip_rank,
+// (the list's length is read on the device; *overflow = 1 when it exceeds the list's capacity)
+hipError_t launch_written_count(const WrittenList &wl, int nranks, uint64_t *counts /* [nranks] += */, uint64_t *overflow, hipStream_t s);
+hipError_t launch_written_export(const WrittenList &wl, const uint64_t *table, int nranks, int skip_rank,
                                  const uint64_t *owner_at /* device [nranks] */, uint64_t *cursors /* device [nranks], zero */,
                                  uint32_t *out_slots, uint64_t *out_vals, hipStream_t s);
-hipError_t launch_written_alive_count(const WrittenList &wl, uint64_t n, const uint64_t *table, uint64_t lo, uint64_t hi,
+hipError_t launch_written_alive_count(const WrittenList &wl, const uint64_t *table, uint64_t lo, uint64_t hi,
                                       uint64_t *out /* = */, hipStream_t s);
 // table -> 2^32-bit bitmap (u32 words)
 hipError_t launch_alive_bitmap(const uint64_t *table, uint64_t n_slots, uint32_t *bitmap, hipStream_t s);

@@ -711,6 +711,26 @@ __global__ __launch_bounds__(kWG) void kta_alive_count_span(const uint64_t *__re
     }
 }
 
+// The same, but only when the written list is no longer complete (see launch_written_alive_count).
+__global__ __launch_bounds__(kWG) void kta_alive_count_span_if_overflowed(WrittenList wl, const uint64_t *__restrict__ table, uint64_t lo,
+                                                                          uint64_t hi, unsigned long long *out)
+{
+    __shared__ unsigned long long s_w[kWG / 64];
+    if (*wl.n <= wl.cap) return;
+    const uint64_t stride = (uint64_t)gridDim.x * kWG;
+    unsigned long long cnt = 0;
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * kWG + threadIdx.x; i < hi; i += stride) cnt += table[i] & 1ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWG / 64; w++) t += s_w[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
 // Compact export of the entries ever written (value != 0): (slot u32, value u64) pairs.  A shard's
 // table holds at most one entry per distinct key hash it has seen, so this is what partition-sharded
 // GPUs exchange instead of the 32 GiB table.  Each workgroup sweeps a contiguous slab, stages hits in
@@ -1015,11 +1035,16 @@ hipError_t launch_alive_import(const uint32_t *slots, const uint64_t *vals, uint
 // ---- the exchange over the written list -----------------------------------------------------------------
 constexpr int kMaxOwners = 64;
 
-__global__ __launch_bounds__(kWG) void kta_written_count(WrittenList wl, uint64_t n, uint32_t nranks, unsigned long long *counts)
+// The list's length is read on the device (the host does not wait for it): a list that overflowed its capacity says so
+// in *overflow, and the counts then cover its first `cap` entries only — the host, which reads the flag together with the
+// counts, falls back to the sweeps.
+__global__ __launch_bounds__(kWG) void kta_written_count(WrittenList wl, uint32_t nranks, unsigned long long *counts, unsigned long long *overflow)
 {
     __shared__ uint32_t s_c[kMaxOwners];
     if (threadIdx.x < kMaxOwners) s_c[threadIdx.x] = 0;
     __syncthreads();
+    const uint64_t have = *wl.n, n = have < wl.cap ? have : wl.cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && have > wl.cap) *overflow = 1ull;
     for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kWG)
         atomicAdd(&s_c[(uint32_t)(((uint64_t)wl.slots[i] * nranks) >> 32)], 1u);
     __syncthreads();
@@ -1028,7 +1053,7 @@ __global__ __launch_bounds__(kWG) void kta_written_count(WrittenList wl, uint64_
 
 // Every workgroup takes a contiguous piece of the list, counts its entries per owner in LDS, reserves their places
 // in the owners' lists with ONE device atomic per owner, and writes (slot, table[slot]).
-__global__ __launch_bounds__(kWG) void kta_written_export(WrittenList wl, uint64_t n, const unsigned long long *__restrict__ table,
+__global__ __launch_bounds__(kWG) void kta_written_export(WrittenList wl, const unsigned long long *__restrict__ table,
                                                           uint32_t nranks, uint32_t skip_rank,
                                                           const unsigned long long *__restrict__ owner_at,
                                                           unsigned long long *__restrict__ cursors, uint32_t *__restrict__ out_slots,
@@ -1036,6 +1061,7 @@ __global__ __launch_bounds__(kWG) void kta_written_export(WrittenList wl, uint64
 {
     __shared__ uint32_t s_c[kMaxOwners];
     __shared__ unsigned long long s_base[kMaxOwners];
+    const uint64_t have = *wl.n, n = have < wl.cap ? have : wl.cap;     // (the length is read on the device, as in kta_written_count)
     const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     constexpr uint64_t kChunk = (uint64_t)kWG * 8;
@@ -1064,12 +1090,13 @@ __global__ __launch_bounds__(kWG) void kta_written_export(WrittenList wl, uint64
     }
 }
 
-__global__ __launch_bounds__(kWG) void kta_written_alive_count(WrittenList wl, uint64_t n, const unsigned long long *__restrict__ table,
+__global__ __launch_bounds__(kWG) void kta_written_alive_count(WrittenList wl, const unsigned long long *__restrict__ table,
                                                                uint64_t lo, uint64_t hi, unsigned long long *out)
 {
     __shared__ unsigned long long s_w[kWG / 64];
     unsigned long long cnt = 0;
-    const uint64_t len = *wl.n < n ? *wl.n : n;           // n: an upper bound known to the host
+    const uint64_t len = *wl.n;                           // (may have grown by the import that ran just before)
+    if (len > wl.cap) return;                             // the list is not complete: kta_alive_count_span_if_overflowed counts
     for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i < len; i += (uint64_t)gridDim.x * kWG) {
         const uint64_t slot = wl.slots[i];
         if (slot >= lo && slot < hi) cnt += table[slot] & 1ull;
@@ -1085,39 +1112,36 @@ __global__ __launch_bounds__(kWG) void kta_written_alive_count(WrittenList wl, u
     }
 }
 
-hipError_t launch_written_count(const WrittenList &wl, uint64_t n, int nranks, uint64_t *counts, hipStream_t s)
+hipError_t launch_written_count(const WrittenList &wl, int nranks, uint64_t *counts, uint64_t *overflow, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
     if (nranks > kMaxOwners) return hipErrorInvalidValue;
-    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
-    if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(kta_written_count, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n, (uint32_t)nranks,
-                       reinterpret_cast<unsigned long long *>(counts));
+    // (the grid does not depend on the list's length, which only the device knows: 4 workgroups per CU walk it)
+    hipLaunchKernelGGL(kta_written_count, dim3(1024), dim3(kWG), 0, s, wl, (uint32_t)nranks,
+                       reinterpret_cast<unsigned long long *>(counts), reinterpret_cast<unsigned long long *>(overflow));
     return hipGetLastError();
 }
 
-hipError_t launch_written_export(const WrittenList &wl, uint64_t n, const uint64_t *table, int nranks, int skip_rank,
+hipError_t launch_written_export(const WrittenList &wl, const uint64_t *table, int nranks, int skip_rank,
                                  const uint64_t *owner_at, uint64_t *cursors, uint32_t *out_slots, uint64_t *out_vals, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
     if (nranks > kMaxOwners) return hipErrorInvalidValue;
-    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
-    if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(kta_written_export, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n, reinterpret_cast<const unsigned long long *>(table),
+    hipLaunchKernelGGL(kta_written_export, dim3(1024), dim3(kWG), 0, s, wl, reinterpret_cast<const unsigned long long *>(table),
                        (uint32_t)nranks, (uint32_t)skip_rank, reinterpret_cast<const unsigned long long *>(owner_at),
                        reinterpret_cast<unsigned long long *>(cursors), out_slots, reinterpret_cast<unsigned long long *>(out_vals));
     return hipGetLastError();
 }
 
-hipError_t launch_written_alive_count(const WrittenList &wl, uint64_t n, const uint64_t *table, uint64_t lo, uint64_t hi,
+// The owner's count of its hash range over the written list — or, when the list has overflowed by now (the import may
+// have added to it; only the device knows), over the range itself: both kernels are launched, one of them returns at once.
+hipError_t launch_written_alive_count(const WrittenList &wl, const uint64_t *table, uint64_t lo, uint64_t hi,
                                       uint64_t *out, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), s);
-    if (e != hipSuccess || n == 0 || lo >= hi) return e;
-    uint64_t wgs = (n + kWG * 8 - 1) / (kWG * 8);
-    if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(kta_written_alive_count, dim3((uint32_t)wgs), dim3(kWG), 0, s, wl, n,
+    if (e != hipSuccess || lo >= hi) return e;
+    hipLaunchKernelGGL(kta_written_alive_count, dim3(1024), dim3(kWG), 0, s, wl,
                        reinterpret_cast<const unsigned long long *>(table), lo, hi, reinterpret_cast<unsigned long long *>(out));
+    hipLaunchKernelGGL(kta_alive_count_span_if_overflowed, dim3(256 * 8), dim3(kWG), 0, s, wl, table, lo, hi,
+                       reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }
 

@@ -1,15 +1,18 @@
-"""profiles/traffic.json from the PMC summary of tools/profile_r03.sh (profiles/rNN_pmc_hbm.txt): HBM bytes per
+"""profiles/traffic.json from the PMC summary of tools/profile_r04.sh (profiles/rNN_pmc_hbm.txt): HBM bytes per
 launch of the kernels bench.py reports a roofline for.  bench.py replays this file (roofline.traffic); it
 does not measure traffic itself.  Every entry records the kernel's source file and its sha256 (first 16 hex
 digits) AS THE FILE LIES IN THE TREE WHEN THIS SCRIPT RUNS — run it on the tree the passes were taken with;
 bench.py returns "traffic": null for a kernel whose file has changed since.
 
-    python tools/make_traffic.py profiles/r03_pmc_hbm.txt > profiles/traffic.json
+    python tools/make_traffic.py profiles/r04_pmc_hbm.txt > profiles/traffic.json
 
 Counters are KiB per launch.  FETCH_SIZE under-reports wide coalesced streaming reads by a factor of two on
 gfx950 (MI355X_MICROARCH.md, HBM section), so the streaming part of a kernel's reads is doubled:
-  kta_metrics_scan, kta_alive_partition, kafka_decode_coop   everything they read is such a stream
-  kta_alive_apply (bit set state)                             the pair stream (8 B x records) and the bucket regions of
+  kta_metrics_scan, kafka_decode_coop                        everything they read is such a stream
+  kta_alive_partition32                                       reads its columns 4 bytes per lane (256-byte requests of a wave)
+                                                              and the keys 16 bytes per lane: whether the factor of two
+                                                              applies is decided by the cross-check below (28 B per record)
+  kta_alive_apply (bit set state)                             the pair stream (4 B x records) and the bucket regions of
                                                               the bit set (16 B per lane, 2 KiB per wave) both are
 Cross-checks the corrections must pass (printed to stderr): the scan reads 20 B/record, the partition kernel
 28 B/record.
@@ -44,9 +47,9 @@ def find(sub, counter, largest_grid=False):
 
 
 KIB = 1024.0
-out = {"round": 3, "source": path,
+out = {"round": 4, "source": path,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 5 --warmup 1 "
-                 "--preroll 5 --no-cpu-baseline` (tools/profile_r03.sh), turned into this file by tools/make_traffic.py; counters "
+                 "--preroll 5 --no-cpu-baseline` (tools/profile_r04.sh), turned into this file by tools/make_traffic.py; counters "
                  "are KiB per launch (average over the launches of the kernel unless stated).  FETCH_SIZE is doubled for wide "
                  "coalesced streaming reads per the gfx950 correction (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  "
                  "bench.py replays these numbers (roofline.traffic, traffic_source), it does not measure them."}
@@ -61,26 +64,32 @@ out["kta_metrics_scan"] = {"kernel": "kta_metrics_scan<0,true,false>", "records_
 print("scan: read %.3f GB vs 20 B x 2^30 = %.3f GB" % (rd / 1e9, 20 * n_scan / 1e9), file=sys.stderr)
 
 n_alive = 15 << 24                            # bench.py --alive-records
-f, w = find("kta_alive_partition<10>", "FETCH_SIZE"), find("kta_alive_partition<10>", "WRITE_SIZE")
-rd, wr = 2 * f[1] * KIB, w[1] * KIB
-out["kta_alive_partition"] = {"kernel": "kta_alive_partition<10>", "records_per_launch": n_alive,
-                              "algorithmic_bytes_per_launch": 28 * n_alive, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
-                              "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                              "note": "reads = the batch (key_len, val_len, key_off, 16 B keys: 28 B/record); writes = the partitioned "
-                                      "(hash, index, alive) pairs, 8 B per keyed record in aligned 64-byte blocks",
-                              **src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")}
-print("partition: read %.3f GB vs 28 B x %d = %.3f GB" % (rd / 1e9, n_alive, 28 * n_alive / 1e9), file=sys.stderr)
+f, w = find("kta_alive_partition32<10>", "FETCH_SIZE"), find("kta_alive_partition32<10>", "WRITE_SIZE")
+# the factor of FETCH_SIZE for this kernel's mix of request widths: the one (1 or 2) that brings the reads closest to the
+# 28 B per record the kernel is known to read (it reads nothing else)
+factor = min((1.0, 2.0), key=lambda x: abs(x * f[1] * KIB - 28 * n_alive))
+rd, wr = factor * f[1] * KIB, w[1] * KIB
+out["kta_alive_partition32"] = {"kernel": "kta_alive_partition32<10>", "records_per_launch": n_alive,
+                                "algorithmic_bytes_per_launch": 28 * n_alive, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
+                                "FETCH_SIZE_factor": factor,
+                                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                                "note": "reads = the batch (key_len, val_len, key_off, 16 B keys: 28 B/record); writes = the partitioned "
+                                        "4-byte pairs (slot in bucket, window, alive), one per record that survives the guard, in "
+                                        "aligned 64-byte blocks",
+                                **src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")}
+print("partition32: read %.3f GB (FETCH_SIZE x %g) vs 28 B x %d = %.3f GB; wrote %.3f GB vs 4 B x records = %.3f GB"
+      % (rd / 1e9, factor, n_alive, 28 * n_alive / 1e9, wr / 1e9, 4 * n_alive / 1e9), file=sys.stderr)
 
 f, w = find("kta_alive_apply<10, true>", "FETCH_SIZE"), find("kta_alive_apply<10, true>", "WRITE_SIZE")
 rd, wr = 2 * f[1] * KIB, w[1] * KIB
 out["kta_alive_apply"] = {"kernel": "kta_alive_apply<10,true>", "records_per_launch": n_alive, "algorithmic_bytes_per_launch": 0,
                           "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1], "hbm_read_bytes_per_launch": rd,
                           "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                          "note": "reads = the pair stream (8 B x records) + the 512 MiB bit set, both wide coalesced streams "
+                          "note": "reads = the pair stream (4 B x records) + the 512 MiB bit set, both wide coalesced streams "
                                   "(FETCH_SIZE doubled); writes = the 512 MiB bit set in whole lines.  None of this is algorithmic "
-                                  "input: the batch's algorithmic bytes are booked on kta_alive_partition",
+                                  "input: the batch's algorithmic bytes are booked on kta_alive_partition32",
                           **src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")}
-print("apply: read %.3f GB vs pairs %.3f + bit set 0.537 GB; wrote %.3f GB vs 0.537" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
+print("apply: read %.3f GB vs pairs %.3f + bit set 0.537 GB; wrote %.3f GB vs 0.537" % (rd / 1e9, 4 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
 f, w = find("kafka_decode_coop<4, 2048u, 32u>", "FETCH_SIZE", True), find("kafka_decode_coop<4, 2048u, 32u>", "WRITE_SIZE", True)
 raw_log = 1075251127                          # bytes of the 4 M-record raw log bench.py's kafka_decode.roofline describes

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 profile recipe (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
+# Round-4 profile recipe (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
 # command, and the HBM traffic counters in their own passes.  tools/make_traffic.py turns pmc.txt into
 # profiles/traffic.json; the text summaries are copied to profiles/ by hand.
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r03
-RAW=/tmp/prof_r03
+OUT=$ROOT/gpurun_out/prof_r04
+RAW=/tmp/prof_r04
 mkdir -p $OUT $RAW
 cd $ROOT
 timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
