@@ -32,6 +32,8 @@
 // than the LDS table takes is applied in instalments, in segment order (older ranges first).
 #include "kta_kernels.h"
 
+#include <limits.h>
+
 // Phase timers for tools/ubench_alive.hip (which includes this file with KTA_ALIVE_PHASES defined): thread 0
 // of every workgroup adds the ticks (100 MHz) it spent between marks.  Compiled out of the library.
 #ifdef KTA_ALIVE_PHASES
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 //     small per-wave guard table (bytes) at an index taken from its hash and reads it back (LDS operations of a wave
 //     are performed in order: the read sees the instruction's last writer, and instruction j + 1 writes after j has
 //     read).  A record that reads its own lane is alone at its index, or it is the last writer there; a record that
-//     reads another lane shares the index with that lane — by chance (different hashes: 64 records over 2048 indices,
-//     about one such pair per instruction) or because the hashes are equal.  For every record that lost its index
+//     reads another lane shares the index with that lane — by chance (different hashes: 64 records over 1024 indices,
+//     about two such pairs per instruction) or because the hashes are equal.  For every record that lost its index
 //     the wave looks at the lanes with that record's very hash (one readlane + one compare per group, scalar
 //     bookkeeping): the NEWEST of them (the highest lane: lane order is record order) stays, the others are
 //     superseded and DROPPED — exactly what the reference's insert / remove sequence leaves (metric.rs:289-304).
@@ -589,7 +591,7 @@ constexpr uint32_t kBlkPerTrip = 64 / kBlkLanes;   // blocks a consumer wave mov
 #define KTA_P32_STORE(ptr, val) (*(ptr) = (val))
 #endif
 #ifndef KTA_P32_GUARD
-#define KTA_P32_GUARD 2048
+#define KTA_P32_GUARD 1024
 #endif
 constexpr uint32_t kGuard = KTA_P32_GUARD;           // guard bytes (the lane that wrote last) per producer wave
 constexpr uint32_t kPair32Shift = 10;
@@ -606,12 +608,29 @@ __device__ __forceinline__ unsigned long long pool_pair32(uint32_t bucket, uint3
     return ((unsigned long long)h << 32) | 0x80000000u | (w << 9) | (p32 & 0x1FFu);   // w, window, alive
 }
 
-template <int BLOG2>
+// ---- both handlers in one pass over the batch (kafka.rs:107-109 calls every handler for every message) ----
+// With FUSE the producers also read partition and ts_ms (12 B more per record: 40 instead of 28 + 20 for two kernels) and do
+// what kta_metrics_scan does (MessageMetrics::handle_message, metric.rs:207-252), in the scan's own terms: per partition
+// three LDS words — A += 1 | tombstone << 21 | key None << 42, K += key length, V += value length (no replicas: the
+// rings leave 6 KiB) — and the global extrema in registers.  The workgroup writes one row of the scan's partial
+// workspace, which kta_fold_partials folds as it folds the scan's.  A workgroup takes less than 2^21 records (the
+// host checks), so the 21-bit counts cannot overflow.
+struct FuseArgs {
+    const int32_t *partition;
+    const int64_t *ts_ms;
+    uint32_t P;                  // <= kFuseMaxP
+    uint64_t *partials;          // rows of row_len words, one per workgroup
+    uint32_t row_len;
+};
+constexpr uint32_t kFuseMaxP = 256;
+constexpr uint32_t kFuseCntBits = 21;   // (the scan's packing: kta_kernels.hip)
+
+template <int BLOG2, bool FUSE>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColumns c, uint64_t n, uint32_t tiles_per_wg,
                                                                       uint32_t *__restrict__ pairs, uint32_t *__restrict__ counts,
                                                                       uint32_t cap, unsigned long long *__restrict__ pool,
                                                                       unsigned long long *__restrict__ pool_ctl,
-                                                                      uint32_t *__restrict__ pool_hist)
+                                                                      uint32_t *__restrict__ pool_hist, FuseArgs fz)
 {
     constexpr uint32_t B = 1u << BLOG2;
     constexpr uint32_t RBITS = 32 - BLOG2;
@@ -624,7 +643,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
     unsigned short *s_out = reinterpret_cast<unsigned short *>(s_pos + B);         // pairs written out, modulo 2^16 (its consumer's)
     uint8_t *s_guard = reinterpret_cast<uint8_t *>(s_out + B);                     // kProducers x kGuard
     uint32_t *s_list = reinterpret_cast<uint32_t *>(s_guard + (size_t)kProducers * kGuard);   // kConsumers x 64
-    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done
+    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done (20 words)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_misc + 20);      // FUSE: A, K, V per partition
+    long long *s_red = reinterpret_cast<long long *>(s_acc + 3 * kFuseMaxP);              // FUSE: [kPartWaves][5] extrema of the waves
     {
         uint4 *z = reinterpret_cast<uint4 *>(s_ring32);
         for (uint32_t e = threadIdx.x; e < B * kRing32 / 4u; e += kPartThreads) z[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -633,7 +654,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             s_out[b] = 0;
         }
         if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
+        if (FUSE)
+            for (uint32_t e = threadIdx.x; e < 3 * kFuseMaxP; e += kPartThreads) s_acc[e] = 0ull;
     }
+    // FUSE: the lane's share of the global extrema (metric.rs:56-72) and of the records outside [0, P)
+    long long f_tmin = LLONG_MAX, f_tmax = LLONG_MIN;
+    uint32_t f_smin = 0xFFFFFFFFu, f_smax = 0u, f_bad = 0u;   // (0xFFFFFFFF is no size: both lengths are below 2^31)
     __syncthreads();
     const uint32_t W = gridDim.x, w = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -652,6 +678,8 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             int32_t kl[4], vl[4];
             uint32_t ko[4];
             uint32_t win;                                  // the tile's window (wave-uniform); 0: no tile
+            int32_t pt[FUSE ? 4 : 1];                      // FUSE: partition (-1: no record), timestamp
+            long long ts[FUSE ? 4 : 1];
         };
         auto load_cols32 = [&](uint64_t tile, bool ok, Cols &r) __attribute__((always_inline)) {
 #pragma unroll
@@ -669,6 +697,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 r.ko[j] = KTA_P32_LOAD(c.key_off + ic);
 #endif
                 r.kl[j] = in ? r.kl[j] : -1;               // key None: ignored (metric.rs:302)
+                if (FUSE) {
+                    r.pt[j] = KTA_P32_LOAD(fz.partition + ic);
+                    r.ts[j] = KTA_P32_LOAD(fz.ts_ms + ic);
+                    r.vl[j] = in ? r.vl[j] : 0;
+                    r.pt[j] = in ? r.pt[j] : -2;           // no record here (a record's bad id stays what it is)
+                }
             }
         };
         auto load_keys32 = [&](const Cols &r, uint4 (&k)[4]) __attribute__((always_inline)) {
@@ -734,6 +768,30 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         h[j] = r.kl[j] > 0 ? fnv32_prefetched(keys[j], c.key_bytes + r.ko[j], (uint32_t)r.kl[j]) : kFnvInit;
+                }
+                if (FUSE) {
+                    // MessageMetrics::handle_message (metric.rs:207-252) for the tile's records, keyed or not
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool there = r.pt[j] != -2;
+                        const bool ok = there && (uint32_t)r.pt[j] < fz.P;                 // (unsigned: negative ids are out as well)
+                        const uint32_t tomb = (uint32_t)r.vl[j] >> 31, knull = (uint32_t)r.kl[j] >> 31;   // payload None / key None (metric.rs:227-244)
+                        const uint32_t ks = knull ? 0u : (uint32_t)r.kl[j], vs = tomb ? 0u : (uint32_t)r.vl[j];
+                        const long long t = r.ts[j] == -1ll ? 0ll : r.ts[j];               // to_millis() None -> unwrap_or(0) (metric.rs:209)
+                        f_bad += there && !ok ? 1u : 0u;
+                        if (ok) {
+                            f_tmin = t < f_tmin ? t : f_tmin;
+                            f_tmax = t > f_tmax ? t : f_tmax;
+                            if (!tomb) {                                                   // metric.rs:249-251
+                                f_smin = min(f_smin, ks + vs);
+                                f_smax = max(f_smax, ks + vs);
+                            }
+                            unsigned long long *a = s_acc + 3u * (uint32_t)r.pt[j];
+                            atomicAdd(a, 1ull | ((unsigned long long)tomb << kFuseCntBits) | ((unsigned long long)knull << (2 * kFuseCntBits)));
+                            atomicAdd(a + 1, (unsigned long long)ks);
+                            atomicAdd(a + 2, (unsigned long long)vs);
+                        }
+                    }
                 }
                 uint32_t pr[4];
                 bool keyed[4];
@@ -912,7 +970,53 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             }
         }
     }
+    if (FUSE) {                                        // the waves' extrema (the consumers' are the neutral elements)
+        long long tmin = f_tmin, tmax = f_tmax, smin = (long long)f_smin, smax = (long long)f_smax, bad = (long long)f_bad;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long a = __shfl_xor(tmin, off), b2 = __shfl_xor(tmax, off), c2 = __shfl_xor(smin, off), d2 = __shfl_xor(smax, off);
+            bad += __shfl_xor(bad, off);
+            tmin = a < tmin ? a : tmin;
+            tmax = b2 > tmax ? b2 : tmax;
+            smin = c2 < smin ? c2 : smin;
+            smax = d2 > smax ? d2 : smax;
+        }
+        if (lane == 0) {
+            long long *o = s_red + wave * 5u;
+            o[0] = tmin, o[1] = tmax, o[2] = smin, o[3] = smax, o[4] = bad;
+        }
+    }
     __syncthreads();
+    if (FUSE) {                                        // this workgroup's row of the scan's partial workspace (kta_fold_partials)
+        uint64_t *row = fz.partials + (uint64_t)w * fz.row_len;
+        constexpr unsigned long long kMask = (1ull << kFuseCntBits) - 1ull;
+        for (uint32_t p = threadIdx.x; p < fz.P; p += kPartThreads) {
+            const unsigned long long a = s_acc[3u * p];
+            uint64_t *o = row + (uint64_t)p * kScanCols;
+            o[0] = a & kMask, o[1] = (a >> kFuseCntBits) & kMask, o[2] = (a >> (2 * kFuseCntBits)) & kMask;
+            o[3] = s_acc[3u * p + 1u], o[4] = s_acc[3u * p + 2u];
+        }
+        if (threadIdx.x == 0) {
+            long long tmin = LLONG_MAX, tmax = LLONG_MIN, smin = 0xFFFFFFFFll, smax = 0, bad = 0;
+            for (uint32_t v = 0; v < (uint32_t)kPartWaves; v++) {
+                const long long *o = s_red + v * 5u;
+                tmin = o[0] < tmin ? o[0] : tmin;
+                tmax = o[1] > tmax ? o[1] : tmax;
+                smin = o[2] < smin ? o[2] : smin;
+                smax = o[3] > smax ? o[3] : smax;
+                bad += o[4];
+            }
+            uint64_t *g = row + (uint64_t)fz.P * kScanCols;
+            g[SG_TMIN] = (uint64_t)tmin;
+            g[SG_TMAX] = (uint64_t)tmax;
+            g[SG_SMIN] = smin == 0xFFFFFFFFll ? (uint64_t)LLONG_MAX : (uint64_t)smin;     // (no record with a payload: as the scan says it)
+            g[SG_SMAX] = (uint64_t)smax;
+            g[SG_BAD] = (uint64_t)bad;
+            g[SG_NREC] = 0;
+            g[6] = 0;
+            g[7] = 0;
+        }
+    }
     // the last, partial block of every segment, and the segment fills for pass 2
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         const uint32_t f = s_pos[b], k = f / kBlk32, rem = f % kBlk32;
@@ -1742,7 +1846,7 @@ hipEvent_t g_ub_ev[4];
 
 template <int BLOG2>
 hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
-                       const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
+                       const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s, const AliveFuse *fuse)
 {
     constexpr uint32_t B = 1u << BLOG2;
     unsigned long long *pp = reinterpret_cast<unsigned long long *>(ws.pairs);
@@ -1762,13 +1866,26 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                         (kSliceBytes > kQueueBytes ? kSliceBytes : kQueueBytes);
     if (bitmap) {
         // 4-byte pairs; 4-byte column loads: any alignment of the columns will do
-        const size_t lds1 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard + (size_t)kConsumers * 64 * 4 + 16 + 64;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e != hipSuccess) return e;
-        KTA_UB_MARK(0);
-        hipLaunchKernelGGL((kta_alive_partition32<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
-                           reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist);
+        const size_t lds0 = (size_t)B * kRing32 * 4 + (size_t)B * 6 + (size_t)kProducers * kGuard + (size_t)kConsumers * 64 * 4 + 16 + 64;
+        if (fuse) {
+            // both handlers in this pass: the scan's sums in LDS behind the rings (see FuseArgs)
+            if (fuse->P > kFuseMaxP || (uint64_t)pl.tiles_per_wg * kTile >= (1ull << kFuseCntBits)) return hipErrorInvalidValue;
+            const size_t lds1 = lds0 + (size_t)3 * kFuseMaxP * 8 + (size_t)kPartWaves * 5 * 8;
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) return e;
+            KTA_UB_MARK(0);
+            hipLaunchKernelGGL((kta_alive_partition32<BLOG2, true>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
+                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist,
+                               FuseArgs{fuse->partition, fuse->ts_ms, fuse->P, fuse->partials, fuse->row_len});
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+            if (e != hipSuccess) return e;
+            KTA_UB_MARK(0);
+            hipLaunchKernelGGL((kta_alive_partition32<BLOG2, false>), dim3(pl.segment_wgs), dim3(kPartThreads), lds0, s, c, n, pl.tiles_per_wg,
+                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist, FuseArgs{nullptr, nullptr, 0, nullptr, 0});
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         KTA_UB_MARK(1);
@@ -1797,6 +1914,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         return hipGetLastError();
     }
     // table state: 8-byte pairs (the survivors' sequence numbers come from their batch-local indices)
+    if (fuse) return hipErrorInvalidValue;              // (the fused pass exists for the bit set state)
     const uint32_t *skip = nullptr;
     if (c.seq) {
         hipLaunchKernelGGL(kta_seq_ascending, dim3(1024), dim3(kWG), 0, s, c.seq, n, flag);
@@ -1882,12 +2000,18 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
 }
 
 hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
-                                    const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s)
+                                    const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s,
+                                    const AliveFuse *fuse)
 {
 #ifdef KTA_P32_EXP_BLOG2
-    if (pl.pair32) return launch_pair<KTA_P32_EXP_BLOG2>(c, n, base_seq, st, pl, ws, stats, s);
+    if (pl.pair32) return launch_pair<KTA_P32_EXP_BLOG2>(c, n, base_seq, st, pl, ws, stats, s, fuse);
 #endif
-    return launch_pair<10>(c, n, base_seq, st, pl, ws, stats, s);
+    return launch_pair<10>(c, n, base_seq, st, pl, ws, stats, s, fuse);
+}
+
+bool alive_fuse_possible(const AlivePartitionPlan &pl, uint32_t P)
+{
+    return pl.pair32 && P <= kFuseMaxP && (uint64_t)pl.tiles_per_wg * kTile < (1ull << kFuseCntBits);
 }
 
 hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s)

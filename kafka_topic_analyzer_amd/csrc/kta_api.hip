@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <new>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,7 @@ struct kta_ctx {
     bool alive_stats_pending = false;
     // bit set state: batches of mostly unique keys are applied in smaller slices (see run_device_batch)
     uint64_t alive_slice = kta::kAlivePartitionMax;
+    bool fuse_handlers = true;      // both handlers of a batch in one pass where that is possible (KTA_NO_FUSE=1: never)
     bool alive_failed_pending = false;
     int alive_backoff = 0;
     std::vector<Stage> stages;
@@ -211,12 +213,23 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
     // every refusal comes before the first launch: a batch is counted by both handlers or by neither
     if ((which & 2) && ctx->alive && (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes))
         return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
+    // Both handlers over one batch (what kafka.rs:107-109 does with every message): in the bit set state, with at most 256
+    // partitions, pass 1 of the alive-key pass does the metrics handler's work as well (kta_alive.hip, FuseArgs) — the
+    // batch is read once, 40 B + key per record instead of 20 + 28.
+    bool fuse = false;
+    if (which == 3 && ctx->alive && !ctx->alive_table && !ctx->analytics && ctx->fuse_handlers) {
+        const uint64_t first = n > ctx->alive_slice ? ctx->alive_slice : n;
+        const kta::AlivePartitionPlan pl0 = kta::plan_alive_partition(first, ctx->alive_wgs, ctx->cu_count, true);
+        fuse = kta::alive_fuse_possible(pl0, ctx->P) && pl0.segment_wgs <= ctx->max_rows;
+    }
     if (which & 1) {
         if (!c->partition || !c->key_len || !c->val_len || !c->ts_ms)
             return fail(ctx, KTA_ERR_INVALID, "metric columns missing");
         if (!aligned16(c->partition) || !aligned16(c->key_len) || !aligned16(c->val_len) ||
             !aligned16(c->ts_ms))
             return fail(ctx, KTA_ERR_INVALID, "device columns must be 16-byte aligned");
+    }
+    if ((which & 1) && !fuse) {
         kta::ScanColumns sc{c->partition, c->key_len, c->val_len, c->ts_ms};
         kta::ScanPlan pl = kta::plan_scan(ctx->P, n, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant,
                                           ctx->analytics);
@@ -328,8 +341,24 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,
                                    ctx->d_alive_running, written_list(ctx)};
                 kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from};
-                KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws,
-                                                           report ? ctx->d_alive_stats : nullptr, ctx->s_compute));
+                if (fuse && kta::alive_fuse_possible(pl, ctx->P) && pl.segment_wgs <= ctx->max_rows) {
+                    const uint32_t row_len = kta::scan_row_len(ctx->P, false);
+                    const kta::AliveFuse fz{c->partition + at, c->ts_ms + at, ctx->P, ctx->d_partials, row_len};
+                    KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws, nullptr, ctx->s_compute, &fz));
+                    KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.segment_wgs, ctx->P, ctx->d_vec, row_len, ctx->d_avec,
+                                                           ctx->s_compute));
+                } else {
+                    if (fuse) {      // (a slice the fused pass does not take: its records go through the scan)
+                        kta::ScanColumns sc{c->partition + at, c->key_len + at, c->val_len + at, c->ts_ms + at};
+                        kta::ScanPlan spl = kta::plan_scan(ctx->P, take, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant, ctx->analytics);
+                        if (spl.workgroups > ctx->max_rows) spl.workgroups = ctx->max_rows;
+                        KTA_HIP(ctx, kta::launch_metrics_scan(spl, sc, take, ctx->P, ctx->d_partials, ctx->s_compute));
+                        KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, spl.workgroups, ctx->P, ctx->d_vec, spl.row_len, ctx->d_avec,
+                                                               ctx->s_compute));
+                    }
+                    KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws,
+                                                               report ? ctx->d_alive_stats : nullptr, ctx->s_compute));
+                }
                 if (sl.seq)   // the batch's seq column did not ascend: the pair did nothing, this runs instead
                     KTA_HIP(ctx, kta::launch_alive_update(sl, take, base_seq + at, ctx->d_table, 0, 2, nullptr,
                                                           ctx->d_alive_running, ctx->s_compute,
@@ -425,6 +454,10 @@ int kta_create(const kta_config *cfg, kta_ctx **out)
     ctx->P = (uint32_t)cfg->n_partitions;
     ctx->alive = cfg->count_alive_keys != 0;
     ctx->analytics = (cfg->flags & KTA_FLAG_ANALYTICS) != 0;
+    {
+        const char *nf = getenv("KTA_NO_FUSE");      // A/B switch of bench.py and the tests: the two handlers as two passes
+        ctx->fuse_handlers = !(nf && nf[0] == '1');
+    }
     ctx->stage_seq = (cfg->flags & KTA_FLAG_SEQ_COLUMN) != 0;
     ctx->alive_table = ctx->alive && (cfg->flags & (KTA_FLAG_SEQ_COLUMN | KTA_FLAG_ALIVE_TABLE)) != 0;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -127,9 +127,21 @@ struct AliveWorkspace {
     uint32_t *fail_from;    // u32[buckets] (bit set state)
 };
 AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32);
+// Both handlers in one pass (bit set state): pass 1 also reads partition and ts_ms and writes one row of the scan's partial
+// workspace per partition workgroup (plan.segment_wgs rows of row_len words), to be folded by launch_fold_partials —
+// MessageMetrics::handle_message (metric.rs:207-252) without a second reading of key_len and val_len.
+struct AliveFuse {
+    const int32_t *partition;
+    const int64_t *ts_ms;
+    uint32_t P;
+    uint64_t *partials;
+    uint32_t row_len;
+};
+bool alive_fuse_possible(const AlivePartitionPlan &plan, uint32_t P);   // P <= 256, and less than 2^21 records per workgroup
 hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t base_seq, const AliveState &st,
                                     const AlivePartitionPlan &plan, const AliveWorkspace &ws,
-                                    uint64_t *stats /* [pairs, claims] += ; may be null */, hipStream_t s);
+                                    uint64_t *stats /* [pairs, claims] += ; may be null */, hipStream_t s,
+                                    const AliveFuse *fuse = nullptr /* null: the alive-key pass only */);
 // device word that the launch pair sets when the batch's seq column does not ascend (the pair then did nothing)
 const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2);
 // bit set state: the word that counts the buckets the last launch pair handed to kta_alive_fallback

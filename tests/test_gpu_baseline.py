@@ -155,6 +155,11 @@ def test_baseline_config_3_alive_keys_2e30_records():
         res, c = h.finish()
         assert res.alive_keys == o.alive_keys() and 0 < res.alive_keys <= 10_000_000
         assert np.array_equal(c, o.counters(P)) and res.overall_count == n
+        # (both handlers of a slice ran as ONE pass over it — the fused partition kernel: the extrema come from there too)
+        mm = kta.MessageMetrics(res, c, NOW)
+        assert mm.earliest_message() == o.earliest() and mm.latest_message() == o.latest()
+        assert mm.smallest_message() == o.get("smallest_message") and mm.largest_message() == o.get("largest_message")
+        assert mm.overall_size() == o.get("overall_size")
         assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
         h.device_batch_free(b)
     o.close()

@@ -417,6 +417,57 @@ def test_partitioned_alive_pass_at_scale_vs_oracle(hc, ht, state, preset, log2n)
     hc.device_batch_free(b)
 
 
+@pytest.mark.parametrize("P,n,runs", [(1, 70_001, False), (8, 300_000, True), (64, 2_500_000, False), (256, 3_000_003, True),
+                                      (257, 200_000, False)])
+def test_both_handlers_in_one_pass_vs_oracle(P, n, runs):
+    """which = 3 in the bit set state with at most 256 partitions: the partition kernel of the alive-key pass also does
+    MessageMetrics::handle_message (/root/reference/src/kafka.rs:107-109: every handler sees every message) — counters,
+    extrema, averages and panics, alive count and every bit against the oracle; null / empty keys and values, -1
+    timestamps, sizes up to 2^31 - 1, batch lengths that are multiples of nothing, two batches.  257 partitions take the
+    two passes (the fused pass keeps 256 partitions' sums in LDS)."""
+    rng = np.random.default_rng(4000 + P)
+    o = Oracle(NOW, True)
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+        for part in range(2):
+            cols = random_cols(rng, n // (part + 1), P, key_space=50_000, tomb=0.3, runs=runs, big_sizes=(P == 8))
+            o.run_soa(cols)
+            b, nb = h.upload_batch(cols, with_keys=True)
+            h.submit_device(b, nb, 0, which=3)
+            h.device_batch_free(b)
+        _compare(h, o, P, check_bitmap=True)
+    o.close()
+
+
+def test_both_handlers_in_one_pass_equals_two_passes_with_bad_partition_ids():
+    """The fused pass and the two passes (KTA_NO_FUSE=1) leave the same vector, bit for bit, also for what the reference
+    has no word for: partition ids outside [0, P) (counted and reported, never accumulated) — while the alive set, which
+    ignores the partition (metric.rs:289-304), takes those records' keys either way."""
+    P, n = 64, 1_200_007
+    rng = np.random.default_rng(4100)
+    cols = random_cols(rng, n, P, key_space=20_000, tomb=0.4)
+    cols["partition"][::1001] = 64
+    cols["partition"][5::7777] = -3
+    cols["partition"][11::9001] = 2**31 - 1
+    got = []
+    for no_fuse in ("0", "1"):
+        os.environ["KTA_NO_FUSE"] = no_fuse
+        try:
+            h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+        finally:
+            del os.environ["KTA_NO_FUSE"]
+        b, nb = h.upload_batch(cols, with_keys=True)
+        h.submit_device(b, nb, 0, which=3)
+        h.device_batch_free(b)
+        res, c = h.finish(allow_bad_partition=True)      # (waits for the batch)
+        vec = h.result_vector_host().copy()
+        got.append((vec, c.copy(), int(res.bad_partition_records), int(res.alive_keys), h.export_alive_bitmap()))
+        h.close()
+    bad = int(((cols["partition"] < 0) | (cols["partition"] >= P)).sum())
+    assert got[0][2] == got[1][2] == bad > 0
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert got[0][3] == got[1][3] and np.array_equal(got[0][4], got[1][4])
+
+
 def _fnv32_np(keys16):
     """The reference's FNV variant (src/fnv32.rs:92-101: multiplier = offset basis) over the rows of a [n, 16] byte array."""
     h = np.full(len(keys16), 0x811c9dc5, np.uint64)
