@@ -339,8 +339,41 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
                 uint32_t off = s_body[g][k] + 1;                               // + record attributes byte
                 const uint64_t rec_end = (k + 1 < found) ? wbase + s_start[g][k + 1] : next;
                 long long ts_delta = 0, od = 0, kl = 0, vl = 0;
-                if (!(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
-                      lds_varlong(win, off, limit, kl))) {
+                // The three varints behind the attributes byte — timestamp delta, offset delta, key length — are
+                // 3 to 8 bytes for ordinary records: three dwords of the window (ONE LDS round trip) hold them, and
+                // they are taken apart in registers.  (Byte by byte, every byte is a dependent LDS read: the parse
+                // phase was a chain of ten round trips.)  Anything else — a varint of more than four bytes, more than
+                // eight bytes in all, the window's edge — takes the byte loop.
+                bool head = false;
+                {
+                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+                    const uint32_t i0 = off >> 2, sh = off & 3u;
+                    const uint32_t d0 = w32[i0], d1 = w32[i0 + 1], d2 = w32[i0 + 2];   // (inside s_win: off < W, and s_win has 16 bytes more)
+                    unsigned long long x = (unsigned long long)__builtin_amdgcn_alignbyte(d1, d0, sh) |
+                                           ((unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+                    uint32_t used = 0, val[3];
+                    bool ok = true;
+#pragma unroll
+                    for (int f = 0; f < 3; f++) {
+                        const uint32_t w = (uint32_t)x, stop = ~w & 0x80808080u;
+                        const uint32_t nb = stop ? ((uint32_t)__builtin_ctz(stop) + 1u) >> 3 : 5u;
+                        ok = ok && nb <= 4u && used + nb <= 8u;
+                        uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
+                        v &= 0xFFFFFFFFu >> (32u - 7u * (nb <= 4u ? nb : 4u));
+                        val[f] = v;
+                        x >>= 8u * (nb <= 4u ? nb : 4u);
+                        used += nb;
+                    }
+                    if (ok && off + used <= limit) {
+                        ts_delta = (long long)(val[0] >> 1) ^ -(long long)(val[0] & 1u);
+                        od = (long long)(val[1] >> 1) ^ -(long long)(val[1] & 1u);
+                        kl = (long long)(val[2] >> 1) ^ -(long long)(val[2] & 1u);
+                        off += used;
+                        head = true;
+                    }
+                }
+                if (!head && !(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
+                               lds_varlong(win, off, limit, kl))) {
                     atomicMin(&s_first_incomplete[g], k);                      // header not inside this window
                     continue;
                 }
@@ -352,7 +385,20 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
                     uint64_t after = 0;                                        // position after the value length
                     if (vpos < wlimit_abs) {
                         uint32_t voff = (uint32_t)(vpos - wbase);
-                        got = lds_varlong(win, voff, limit, vl);
+                        // the value length: one to four bytes inside the window as a rule — two dwords, one round trip
+                        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+                        const uint32_t w = __builtin_amdgcn_alignbyte(w32[(voff >> 2) + 1], w32[voff >> 2], voff & 3u);
+                        const uint32_t stop = ~w & 0x80808080u;
+                        const uint32_t nb = stop ? ((uint32_t)__builtin_ctz(stop) + 1u) >> 3 : 5u;
+                        if (nb <= 4u && voff + nb <= limit) {
+                            uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
+                            v &= 0xFFFFFFFFu >> (32u - 7u * nb);
+                            vl = (long long)(v >> 1) ^ -(long long)(v & 1u);
+                            voff += nb;
+                            got = true;
+                        } else {
+                            got = lds_varlong(win, voff, limit, vl);
+                        }
                         after = wbase + voff;
                     }
                     if (!got) {                                                // value length lies beyond the window
