@@ -224,9 +224,6 @@ constexpr int kPartWaves = kPartThreads / 64;
 #ifndef KTA_DBG_LEVEL
 #define KTA_DBG_LEVEL 0                            // ablation levels of tools/ubench_alive.hip; the library is built with 0
 #endif
-#ifndef KTA_PART_SLEEP
-#define KTA_PART_SLEEP 8
-#endif
 constexpr int kConsumers = KTA_PART_CONSUMERS;     // waves that move completed blocks from the rings to memory (one per SIMD)
 constexpr int kProducers = kPartWaves - kConsumers; // waves that stream, hash and insert
 constexpr uint32_t kTile = 256;                    // records of one wave step: four consecutive records per lane
@@ -512,7 +509,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             }
             if (!any_ready) {
                 if (done == (uint32_t)kProducers) break;                          // nothing left that is complete
-                __builtin_amdgcn_s_sleep(KTA_PART_SLEEP);
+                __builtin_amdgcn_s_sleep(8);
             }
         }
     }
@@ -565,15 +562,8 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 //     Records with equal hashes always share their index, so every group with two or more members has a loser and is
 //     looked at: after the guard no two records of one instruction have the same hash.  One round, exact.
 // Hot keys — which used to fill their bucket's ring and stall the workgroup — mostly die in the guard.
-// The stream is read once: non-temporal loads keep it out of the caches the pair blocks are written through.
-#ifndef KTA_P32_NT
-#define KTA_P32_NT 1
-#endif
-#if KTA_P32_NT
+// The stream is read once: non-temporal loads (measured against plain ones: the same time, within the noise).
 #define KTA_P32_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define KTA_P32_LOAD(p) (*(p))
-#endif
 typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));   // 16 key bytes at any address (unaligned access mode)
 #ifndef KTA_P32_BLOCK
 #define KTA_P32_BLOCK 16
@@ -582,14 +572,8 @@ constexpr uint32_t kBlk32 = KTA_P32_BLOCK;         // pairs of a block: what lea
 constexpr uint32_t kRing32 = 2 * kBlk32;           // pairs per bucket ring: two blocks
 constexpr uint32_t kBlkLanes = kBlk32 / 4;         // lanes that move a block (16 bytes each)
 constexpr uint32_t kBlkPerTrip = 64 / kBlkLanes;   // blocks a consumer wave moves at a time
-// experiments of tools/ubench_alive.hip on the block stores (the library is built with none of them)
-#if defined(KTA_P32_STORE_NT)
-#define KTA_P32_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
-#elif defined(KTA_P32_STORE_SC1)
-#define KTA_P32_STORE(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(val) : "memory")
-#else
+// (the block stores as non-temporal or write-through stores measured the same as plain ones: ± 0.03 ms of 1.9)
 #define KTA_P32_STORE(ptr, val) (*(ptr) = (val))
-#endif
 #ifndef KTA_P32_GUARD
 #define KTA_P32_GUARD 1024
 #endif
@@ -923,9 +907,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 #if KTA_DBG_LEVEL == 4   /* 4: the whole protocol, but the blocks are not stored */
                             if (d.x == 0x1234567u)
 #endif
-#ifdef KTA_P32_TIMEMAJOR   /* experiment: block k of every segment side by side (what is written at one time lies together) */
-                            KTA_P32_STORE(reinterpret_cast<v4u *>(pairs + (((uint64_t)k * B + bb) * W + w) * kBlk32 + piece * 4u), ((v4u){d.x, d.y, d.z, d.w}));
-#else
                             {
                                 uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
 #ifdef KTA_P32_STORE_LOG       /* experiment: the blocks of a consumer wave one behind the other, in the order they leave */
@@ -946,7 +927,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 #endif
                                 KTA_P32_STORE(reinterpret_cast<v4u *>(pairs + at), ((v4u){d.x, d.y, d.z, d.w}));
                             }
-#endif
                         } else {                                                   // the segment is full: to the pool, with what a pair32 leaves implicit
                             unsigned long long at_pool = 0;
                             if (piece == 0u) {
@@ -966,7 +946,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             }
             if (!any_ready) {
                 if (done == (uint32_t)kProducers) break;                          // nothing left that is complete
-                __builtin_amdgcn_s_sleep(KTA_PART_SLEEP);
+                __builtin_amdgcn_s_sleep(8);
             }
         }
     }
@@ -1054,10 +1034,7 @@ constexpr uint32_t kOvfProbes = 32;                // linear probes before the s
 constexpr uint32_t kSliceSets = 128;               // sets of one bitmap slice
 constexpr uint32_t kNoFail = 0xFFFFFFFFu;
 constexpr uint32_t kMissQueue = 320;               // pairs a wave queues for the long way of the merge
-#ifndef KTA_APPLY_DEPTH
-#define KTA_APPLY_DEPTH 4
-#endif
-constexpr int kApplyDepth = KTA_APPLY_DEPTH;       // units of a wave's walk: one being merged, the others in flight
+constexpr int kApplyDepth = 4;                     // units of a wave's walk: one being merged, the others in flight (2, 3, 4: the same time)
 
 // One lookup: which of the set's eight 16-bit tags equals `tag` (8 = none).  t = the set's 16 bytes.  Entry i < 4 is
 // the low half of dword i, entry i >= 4 the high half of dword i - 4 (the order a search finds them in: of two
@@ -1447,6 +1424,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         const uint32_t cnt = on ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[on ? seg : 0u]) : 0u;
         if (BITMAP) {
             const uint32_t *sp = region_pairs32 + (uint64_t)(on ? seg : 0u) * cap;
+            // (a segment's 64-byte blocks read as scattered halves of 128-byte lines — even blocks, then odd ones — cost pass 2
+            // 0.02 ms of 0.68: gathered blocks would be affordable)
             const uint32_t k = (r0 << 8) + 4u * lane;
             un.nv[0] = r0 < loads && k < cnt ? (cnt - k >= 4u ? 4u : cnt - k) : 0u;
             un.nv[1] = ((on ? seg : 0u) << (ksh + 9u)) | (k << 1);

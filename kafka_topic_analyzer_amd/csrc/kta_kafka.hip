@@ -57,8 +57,11 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
     if (n_batches < 2048) return 2;
     const uint64_t mean = blob_len / n_batches;
     // (batches of 64 KiB and more: 4000 batches of 134 KiB are 2000 waves of the <2, 8 KiB> geometry — two per SIMD —
-    // and 17 windows each: 0.223 ms where <4, 4 KiB> took 0.316 and <1, 8 KiB> 0.333, round 4)
-    return mean < 4096 ? 5 : (mean < 65536 ? 4 : 7);
+    // and 17 windows each: 0.223 ms where <4, 4 KiB> took 0.316 and <1, 8 KiB> 0.333, round 4.  16 KiB batches: a 2 KiB
+    // window holds 7 or 8 records of the 256-byte mean, so 16 records per round — one parse round of the 16 lanes — is
+    // enough: 0.276 / 0.144 ms at 4 M / 2 M records where 32 per round took 0.282 / 0.157; <8, 2 KiB>, <4, 4 KiB, 32>
+    // measured slower: the kernel is bound by instruction issue, 95 % of the SIMDs' cycles, profiles/r04_sq_decode.txt)
+    return mean < 4096 ? 5 : (mean < 65536 ? 8 : 7);
 }
 
 // ---- device-side byte reader over the blob: aligned 16-byte loads, one block cached -------------
@@ -1271,7 +1274,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..7 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..8 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1669,6 +1672,7 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     case 4: KTA_DECODE_COOP(4, 2048u, 32u); break;    // 16 lanes per batch, 2 KiB windows
     case 6: KTA_DECODE_COOP(4, 8192u, 128u); break;   // 16 lanes per batch, 8 KiB windows
     case 7: KTA_DECODE_COOP(2, 8192u, 128u); break;   // 32 lanes per batch, 8 KiB windows: batches of 64 KiB and more
+    case 8: KTA_DECODE_COOP(4, 2048u, 16u); break;    // 16 lanes per batch, 2 KiB windows, ONE parse round per window: 16 KiB batches
     default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
     }
 #undef KTA_DECODE_COOP
@@ -1929,7 +1933,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 7) return KTA_ERR_INVALID;
+    if (!ctx || variant < 0 || variant > 8) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }
