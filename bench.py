@@ -109,7 +109,7 @@ def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
     return out
 
 
-def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
+def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras=True):
     """The --count-alive-keys pass (FNV + the reference's bit set) on the config-3 shape.  The batch is as large as
     the ABI takes with 16-byte keys (key_off is a u32: < 4 GiB of key bytes): the bit set's 512 MiB are streamed
     through LDS once per batch, whatever its size."""
@@ -167,17 +167,21 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
         hh.set_timing(False)
         return wall, [a if c else 0.0 for a, c in zip(avg, cnt)], cnt
     wall3, avg3, cnt3 = both(h)
-    os.environ["KTA_NO_FUSE"] = "1"
-    try:
-        h2 = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
-    finally:
-        del os.environ["KTA_NO_FUSE"]
-    wall2, avg2, cnt2 = both(h2)
-    r1, c1 = h.finish()
-    r2, c2 = h2.finish()
-    h2.close()
-    # (h saw the alive-only steps before: the alive sets agree, the counters of the which=3 steps must be equal)
-    assert r1.alive_keys == r2.alive_keys and (c1 == c2).all(), "the fused pass and the two passes disagree"
+    two = None
+    if extras:
+        os.environ["KTA_NO_FUSE"] = "1"
+        try:
+            h2 = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
+        finally:
+            del os.environ["KTA_NO_FUSE"]
+        wall2, avg2, cnt2 = both(h2)
+        r1, c1 = h.finish()
+        r2, c2 = h2.finish()
+        h2.close()
+        # (h saw the alive-only steps before: the alive sets agree, the counters of the which=3 steps must be equal)
+        assert r1.alive_keys == r2.alive_keys and (c1 == c2).all(), "the fused pass and the two passes disagree"
+        two = {"value": n_records * steps / wall2, "kernel_ms": avg2[0] + avg2[1] + avg2[2], "scan_ms": avg2[0],
+               "fold_ms": avg2[1], "alive_ms": avg2[2]}
     both_ms = avg3[0] + avg3[1] + avg3[2]
     # the scan reads partition, key_len, val_len, ts_ms (20 B), the alive pass key_len, val_len, key_off and the key
     # (12 B + key): 8 B of the two are the same columns — 40 B per record with 16-byte keys, read once by the fused pass
@@ -187,15 +191,16 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds):
             "roofline": {"bound": "hbm", "kernel": "kta_alive_partition32<fused> + kta_fold_partials + kta_alive_apply",
                          "achieved": algo3 / (both_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo3 / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo3,
-                         "kernel_ms": both_ms, "scan_launches": int(cnt3[0]), "launches": int(cnt3[2]), "traffic": None,
+                         "kernel_ms": both_ms, "scan_launches": int(cnt3[0]), "launches": int(cnt3[2]),
+                         "traffic": _traffic(["kta_alive_partition32_fused", "kta_alive_apply"], n_records),
+                         "traffic_source": TRAFFIC_SOURCE,
                          "note": "algorithmic bytes = the union of the two handlers' columns (40 B per record with 16-byte "
                                  "keys), which the fused pass reads once; kernel_ms = HIP events around partition (with the "
                                  "metrics handler's sums) + fold + apply"},
-            "two_passes": {"value": n_records * steps / wall2, "kernel_ms": avg2[0] + avg2[1] + avg2[2], "scan_ms": avg2[0],
-                           "fold_ms": avg2[1], "alive_ms": avg2[2],
-                           "frac": algo3 / ((avg2[0] + avg2[1] + avg2[2]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "KTA_NO_FUSE=1: kta_metrics_scan + kta_fold_partials, then the alive-key pass (48 B per "
-                                   "record touched: key_len and val_len twice)"}}
+            "two_passes": None if two is None else dict(
+                two, frac=algo3 / (two["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                note="KTA_NO_FUSE=1: kta_metrics_scan + kta_fold_partials, then the alive-key pass (48 B per record touched: "
+                     "key_len and val_len twice)")}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)
     passes, t_total = 0, 0.0
@@ -251,7 +256,9 @@ def alive_table_report(kta, device, steps, n_records):
            "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply (table state)",
                         "achieved": algo / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo,
-                        "kernel_ms": avg_ms[2], "launches": int(cnt[2]), "traffic": None,
+                        "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
+                        "traffic": _traffic(["kta_seq_ascending", "kta_alive_partition", "kta_alive_apply_table"], n_records),
+                        "traffic_source": TRAFFIC_SOURCE,
                         "note": "algorithmic bytes = alive_pass's 12 B + key per record + the 8-byte seq column of a sharded "
                                 "rank's batches (SURVEY 8e): 36 B per record with 16-byte keys"}}
     for b in batches:
@@ -607,6 +614,9 @@ def main():
     ap.add_argument("--alive-records", type=int, default=15 << 24,
                     help="records per batch of the alive-key pass (default 15 x 2^24: 3.75 GiB of 16-byte keys, the most a "
                          "batch's u32 key offsets address)")
+    ap.add_argument("--no-alive-extras", action="store_true",
+                    help="skip the legs of the alive rows that launch the same kernels at other sizes or on other data (the two-pass "
+                         "comparison of both_handlers, alive_pass_hot_key): a counter pass then sees every kernel at ONE launch size")
     ap.add_argument("--no-decode", action="store_true", help="skip the Kafka record-batch decode sub-benchmark")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the PCIe-inclusive legs (host_fed, raw_log_e2e)")
     ap.add_argument("--decode-records", type=int, default=4_000_000)
@@ -788,9 +798,11 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_alive and not c5:
             line["alive_pass"], line["both_handlers"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
-                                                                          args.alive_records, args.cpu_seconds)
+                                                                          args.alive_records, args.cpu_seconds,
+                                                                          extras=not args.no_alive_extras)
             line["alive_pass_table"] = alive_table_report(kta, local_rank, 5, args.alive_records)
-            line["alive_pass_hot_key"] = alive_hot_key_report(kta, local_rank, 1 << 26)
+            if not args.no_alive_extras:
+                line["alive_pass_hot_key"] = alive_hot_key_report(kta, local_rank, 1 << 26)
         if world == 1 and not args.no_decode and not c5:
             line["kafka_decode"] = kafka_decode_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                        args.decode_records, args.cpu_seconds)

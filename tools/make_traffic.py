@@ -49,7 +49,7 @@ def find(sub, counter, largest_grid=False):
 KIB = 1024.0
 out = {"round": 4, "source": path,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 5 --warmup 1 "
-                 "--preroll 5 --no-cpu-baseline` (tools/profile_r04.sh), turned into this file by tools/make_traffic.py; counters "
+                 "--preroll 5 --no-cpu-baseline` (tools/profile_r04.sh; --no-alive-extras: every kernel at one launch size), turned into this file by tools/make_traffic.py; counters "
                  "are KiB per launch (average over the launches of the kernel unless stated).  FETCH_SIZE is doubled for wide "
                  "coalesced streaming reads per the gfx950 correction (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  "
                  "bench.py replays these numbers (roofline.traffic, traffic_source), it does not measure them."}
@@ -64,43 +64,57 @@ out["kta_metrics_scan"] = {"kernel": "kta_metrics_scan<0,true,false>", "records_
 print("scan: read %.3f GB vs 20 B x 2^30 = %.3f GB" % (rd / 1e9, 20 * n_scan / 1e9), file=sys.stderr)
 
 n_alive = 15 << 24                            # bench.py --alive-records
-f, w = find("kta_alive_partition32<10>", "FETCH_SIZE"), find("kta_alive_partition32<10>", "WRITE_SIZE")
-# the factor of FETCH_SIZE for this kernel's mix of request widths: the one (1 or 2) that brings the reads closest to the
-# 28 B per record the kernel is known to read (it reads nothing else)
-factor = min((1.0, 2.0), key=lambda x: abs(x * f[1] * KIB - 28 * n_alive))
-rd, wr = factor * f[1] * KIB, w[1] * KIB
-out["kta_alive_partition32"] = {"kernel": "kta_alive_partition32<10>", "records_per_launch": n_alive,
-                                "algorithmic_bytes_per_launch": 28 * n_alive, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
-                                "FETCH_SIZE_factor": factor,
-                                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                                "note": "reads = the batch (key_len, val_len, key_off, 16 B keys: 28 B/record); writes = the partitioned "
-                                        "4-byte pairs (slot in bucket, window, alive), one per record that survives the guard, in "
-                                        "aligned 64-byte blocks",
-                                **src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")}
-print("partition32: read %.3f GB (FETCH_SIZE x %g) vs 28 B x %d = %.3f GB; wrote %.3f GB vs 4 B x records = %.3f GB"
-      % (rd / 1e9, factor, n_alive, 28 * n_alive / 1e9, wr / 1e9, 4 * n_alive / 1e9), file=sys.stderr)
+ALIVE_SRC = src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")
 
-f, w = find("kta_alive_apply<10, true>", "FETCH_SIZE"), find("kta_alive_apply<10, true>", "WRITE_SIZE")
-rd, wr = 2 * f[1] * KIB, w[1] * KIB
-out["kta_alive_apply"] = {"kernel": "kta_alive_apply<10,true>", "records_per_launch": n_alive, "algorithmic_bytes_per_launch": 0,
-                          "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1], "hbm_read_bytes_per_launch": rd,
-                          "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                          "note": "reads = the pair stream (4 B x records) + the 512 MiB bit set, both wide coalesced streams "
-                                  "(FETCH_SIZE doubled); writes = the 512 MiB bit set in whole lines.  None of this is algorithmic "
-                                  "input: the batch's algorithmic bytes are booked on kta_alive_partition32",
-                          **src("kafka_topic_analyzer_amd/csrc/kta_alive.hip")}
+
+def entry(key, kernel, match, algo, fetch_factor, note, source=ALIVE_SRC, n=n_alive):
+    f, w = find(match, "FETCH_SIZE"), find(match, "WRITE_SIZE")
+    rd, wr = fetch_factor * f[1] * KIB, w[1] * KIB
+    out[key] = {"kernel": kernel, "records_per_launch": n, "algorithmic_bytes_per_launch": algo, "launches_fetch_pass": f[0],
+                "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1], "FETCH_SIZE_factor": fetch_factor,
+                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "note": note, **source}
+    return rd, wr
+
+
+# The factor of FETCH_SIZE is 2 for these kernels as for the scan: pass 1 reads its columns 4 bytes per lane and the keys 16
+# bytes per lane, and FETCH_SIZE x 2 lands on the 28 (fused: 40) bytes per record it is known to read — the cross-check below.
+rd, wr = entry("kta_alive_partition32", "kta_alive_partition32<10,false>", "kta_alive_partition32<10, false>", 28 * n_alive, 2.0,
+               "reads = the batch (key_len, val_len, key_off, 16 B keys: 28 B/record); writes = the partitioned 4-byte pairs (slot in "
+               "bucket, window, alive), one per record that survives the guard, in aligned 64-byte blocks")
+print("partition32: read %.3f GB vs 28 B x %d = %.3f GB; wrote %.3f GB vs 4 B x records = %.3f GB"
+      % (rd / 1e9, n_alive, 28 * n_alive / 1e9, wr / 1e9, 4 * n_alive / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_partition32_fused", "kta_alive_partition32<10,true>", "kta_alive_partition32<10, true>", 40 * n_alive, 2.0,
+               "both handlers in one pass: reads = partition, key_len, val_len, ts_ms, key_off, 16 B keys (40 B/record); writes = the "
+               "4-byte pairs + one row of the scan's partial workspace per workgroup")
+print("partition32 fused: read %.3f GB vs 40 B x %d = %.3f GB; wrote %.3f GB" % (rd / 1e9, n_alive, 40 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_apply", "kta_alive_apply<10,true>", "kta_alive_apply<10, true>", 0, 2.0,
+               "reads = the pair stream (4 B x records) + the 512 MiB bit set, both wide coalesced streams (FETCH_SIZE doubled); "
+               "writes = the 512 MiB bit set in whole lines.  None of this is algorithmic input: the batch's algorithmic bytes are "
+               "booked on kta_alive_partition32")
 print("apply: read %.3f GB vs pairs %.3f + bit set 0.537 GB; wrote %.3f GB vs 0.537" % (rd / 1e9, 4 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
+# table state (alive_pass_table): the order check of the seq column, pass 1 with 8-byte pairs, pass 2 on the 32 GiB table
+rd, wr = entry("kta_seq_ascending", "kta_seq_ascending", "kta_seq_ascending", 8 * n_alive, 2.0, "reads the batch's seq column (8 B/record)")
+print("seq_ascending: read %.3f GB vs 8 B x records = %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_partition", "kta_alive_partition<10>", "kta_alive_partition<10>", 28 * n_alive, 2.0,
+               "table state: reads = the batch (28 B/record); writes = 8-byte pairs (hash, batch-local index, alive) in 64-byte blocks")
+print("partition (table state): read %.3f GB vs %.3f GB; wrote %.3f GB vs 8 B x records = %.3f GB"
+      % (rd / 1e9, 28 * n_alive / 1e9, wr / 1e9, 8 * n_alive / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false>", "kta_alive_apply<10, false>", 0, 2.0,
+               "table state: reads = the 8-byte pair stream (doubled: a wide stream) + one 8-byte table entry and one seq value per "
+               "surviving slot (the doubling overstates those scattered reads); writes = one partial write per slot whose entry changes "
+               "+ the written list")
+print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
-f, w = find("kafka_decode_coop<4, 2048u, 32u>", "FETCH_SIZE", True), find("kafka_decode_coop<4, 2048u, 32u>", "WRITE_SIZE", True)
+f, w = find("kafka_decode_coop<4, 2048u, 16u>", "FETCH_SIZE", True), find("kafka_decode_coop<4, 2048u, 16u>", "WRITE_SIZE", True)
 raw_log = 1075251127                          # bytes of the 4 M-record raw log bench.py's kafka_decode.roofline describes
-rd, wr = 2 * f[3] * KIB, w[3] * KIB
-out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<4, 2048u, 32u>", "records_per_launch": 4000000,
-                            "algorithmic_bytes_per_launch": raw_log, "FETCH_SIZE_kib_max": f[3], "WRITE_SIZE_kib_max": w[3],
+rd, wr = 2 * f[1] * KIB, w[1] * KIB
+out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<4, 2048u, 16u>", "records_per_launch": 4000000,
+                            "algorithmic_bytes_per_launch": raw_log, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                             "ratio_to_algorithmic": (rd + wr) / raw_log,
-                            "note": "rows are per launch size where the summary carries grid sizes (the largest grid = the 4 M-record / "
-                                    "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them); the MAX of the row is "
-                                    "used, which also picks that launch out of a mixed row" % f[0],
+                            "note": "rows are per launch size (the summary carries grid sizes): the largest grid = the 4 M-record / "
+                                    "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them" % f[0],
                             **src("kafka_topic_analyzer_amd/csrc/kta_kafka.hip")}
+print("decode: read %.3f GB + wrote %.3f GB vs raw log %.3f GB" % (rd / 1e9, wr / 1e9, raw_log / 1e9), file=sys.stderr)
 json.dump(out, sys.stdout, indent=1)
 print()

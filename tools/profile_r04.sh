@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the counter passes run with --no-alive-extras: every kernel at ONE launch size, so a row's average is that launch)
 # Round-4 profile recipe (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
 # command, and the HBM traffic counters in their own passes.  tools/make_traffic.py turns pmc.txt into
 # profiles/traffic.json; the text summaries are copied to profiles/ by hand.
@@ -11,10 +12,10 @@ cd $ROOT
 timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 tail -c 600 $OUT/bench_n1.err
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $RAW/stats -o r -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hostfed > $OUT/bench_stats_run.json 2> $OUT/stats.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $RAW/stats -o r -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hostfed --no-alive-extras > $OUT/bench_stats_run.json 2> $OUT/stats.err
 python $ROOT/tools/summarize_rocprof.py stats $(find $RAW/stats -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c --kernel-trace -d $RAW/pmc_$c -o r -- python $ROOT/bench.py --steps 5 --warmup 1 --preroll 5 --no-cpu-baseline --no-hostfed > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  timeout 400 rocprofv3 --pmc $c --kernel-trace -d $RAW/pmc_$c -o r -- python $ROOT/bench.py --steps 5 --warmup 1 --preroll 5 --no-cpu-baseline --no-hostfed --no-alive-extras > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python $ROOT/tools/summarize_rocprof.py pmc $(find $RAW/pmc_* -name '*.db') > $OUT/pmc_hbm.txt 2>&1
 # the multi-GPU modes with ONE rank and the collectives forced (a 1-GPU box): config 5 (both handlers + the whole
