@@ -247,7 +247,7 @@ def alive_table_report(kta, device, steps, n_records):
     h.set_timing(False)
     res, _ = h.finish()
     # (a sharded rank's batches carry the global consumption index of every record: + 8 B per record, SURVEY §8e — read
-    # by the check that the column ascends inside the batch, and for the survivors)
+    # by pass 1, which checks that the column ascends inside the batch, and for the survivors)
     algo = (4 + 4 + 4 + 8) * n_records + kb
     rep = {"workload": f"c3 law, table state, seq column: {steps} consecutive batches of {n_records} records, 16 B keys, 10M distinct, "
                        "10% tombstones (the partitioned pass: kta_alive_partition + kta_alive_apply<table>)",
@@ -257,7 +257,7 @@ def alive_table_report(kta, device, steps, n_records):
                         "achieved": algo / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo,
                         "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": _traffic(["kta_seq_ascending", "kta_alive_partition", "kta_alive_apply_table"], n_records),
+                        "traffic": _traffic(["kta_alive_partition", "kta_alive_apply_table"], n_records),
                         "traffic_source": TRAFFIC_SOURCE,
                         "note": "algorithmic bytes = alive_pass's 12 B + key per record + the 8-byte seq column of a sharded "
                                 "rank's batches (SURVEY 8e): 36 B per record with 16-byte keys"}}

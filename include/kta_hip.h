@@ -209,7 +209,10 @@ int kta_batch_submit(kta_ctx *ctx, uint64_t n_records, uint64_t n_key_bytes, uin
  * the context's compute stream. */
 int kta_submit_device(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records, uint64_t base_seq);
 /* Run only one of the two handlers over a device batch (profiling / benchmarks):
- * which = 1 MessageMetrics, 2 LogCompactionInMemoryMetrics, 3 both. */
+ * which = 1 MessageMetrics, 2 LogCompactionInMemoryMetrics, 3 both.  With both, -c, the bit set state and at most 256
+ * partitions the batch is read ONCE: the first kernel of the alive-key pass also does the metrics handler's work
+ * (src/kafka.rs:107-109 hands every message to every handler; same results bit for bit, environment KTA_NO_FUSE=1
+ * at kta_create keeps the two passes).  kta_batch_submit and kta_handle_message submit with which = 3. */
 int kta_submit_device_ex(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records,
                          uint64_t base_seq, int which);
 int kta_device_batch_alloc(kta_ctx *ctx, uint64_t capacity, uint64_t key_bytes_capacity,

@@ -236,6 +236,8 @@ typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
 struct TileCols {
     int4 kl, vl;
     uint4 ko;
+    unsigned long long sq[5];                      // SEQ: the sequence numbers of the lane's four records and of the one behind them
+    uint32_t sq_ok;                                // SEQ: bit j: records j and j + 1 both exist (their order is to be checked)
 };
 struct TileKeys {
     uint4 k[4];                                    // the 16 bytes at each key's offset
@@ -246,6 +248,7 @@ struct TileKeys {
 // wait for every prefetch issued in between.  The columns are 16-byte aligned and tiles start at multiples
 // of four records, so the last, partial group of four is read inside its own aligned 16 bytes.
 // The first `skip` (0..3) positions lie before the batch: the three columns were aligned down by that many records.
+template <bool SEQ>
 __device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uint32_t skip, uint64_t tile, bool tile_ok, TileCols &r)
 {
     const uint64_t base = tile * kTile + (uint64_t)(threadIdx.x & 63u) * 4u;
@@ -260,6 +263,20 @@ __device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uin
     r.kl.y = in1 ? r.kl.y : -1;
     r.kl.z = in2 ? r.kl.z : -1;
     r.kl.w = in3 ? r.kl.w : -1;
+    if (SEQ) {
+        // the seq column is NOT aligned down with the others: record `base + j` of the aligned columns is seq[base + j - skip].
+        // Five values, clamped into the column (what is clamped is masked): the order of neighbours is checked here, in
+        // the kernel that reads the batch anyway, instead of by a kernel of its own that read the whole column first
+        // (0.52 ms of a 3.8 ms pass at 15 x 2^24 records).
+        const uint64_t nrec = n - skip;               // records of the batch
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const uint64_t i = base + (uint64_t)j;
+            r.sq[j] = c.seq[i >= skip && i - skip < nrec ? i - skip : 0u];
+        }
+        const bool in4 = tile_ok && base + 4 < n;
+        r.sq_ok = (in0 && in1 ? 1u : 0u) | (in1 && in2 ? 2u : 0u) | (in2 && in3 ? 4u : 0u) | (in3 && in4 ? 8u : 0u);
+    }
 }
 
 // The first 16 bytes at every key's offset, whatever the key's length: the bytes past a shorter key are
@@ -302,13 +319,15 @@ enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS =
 //              64-byte store — its entries are zeroed, `out` advances by 8.  They never load from memory.
 // Whoever holds a position in the oldest unwritten block of a bucket never waits (p - out < 8), so that block
 // completes and leaves: no deadlock, wherever its writers sit.
-template <int BLOG2>
+// SEQ: the batch carries a seq column, which has to ascend inside the batch for pass 2 (it orders a batch's records by
+// their index): the producers check it on the way and raise *order_flag, which pass 2 and what runs in its stead read.
+template <int BLOG2, bool SEQ>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint32_t skip, uint32_t tiles_per_wg,
                                                                     unsigned long long *__restrict__ pairs,
                                                                     uint32_t *__restrict__ counts, uint32_t cap,
                                                                     unsigned long long *__restrict__ pool,
                                                                     unsigned long long *__restrict__ pool_ctl,
-                                                                    uint32_t *__restrict__ pool_hist)
+                                                                    uint32_t *__restrict__ pool_hist, uint32_t *__restrict__ order_flag)
 {
     constexpr uint32_t B = 1u << BLOG2;
     static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
@@ -357,8 +376,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
         if (t_a < span) {
             TileCols cols_a, cols_b;
             TileKeys keys_a, keys_b;
-            load_cols(c, n, skip, at(t_a), true, cols_a);
-            load_cols(c, n, skip, at(t_b < span ? t_b : t_a), t_b < span, cols_b);
+            load_cols<SEQ>(c, n, skip, at(t_a), true, cols_a);
+            load_cols<SEQ>(c, n, skip, at(t_b < span ? t_b : t_a), t_b < span, cols_b);
+            bool disorder = false;                            // SEQ: a record whose sequence number is not below its successor's
             load_keys(c, cols_a, keys_a);
             // one step: hash the tile in (r, keys) — walk index t — and insert its pairs; request the key bytes of the
             // next tile (its columns were requested a step ago) and the columns of the tile after that, into r
@@ -384,10 +404,14 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                     keyed[j] = kl[j] >= 0;
                     pr[j] = ((unsigned long long)h[j] << 32) | ((unsigned long long)(i0 + j + 1) << 1) | (vl[j] >= 0 ? 1ull : 0ull);
                 }
+                if (SEQ) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) disorder |= ((r.sq_ok >> j) & 1u) && r.sq[j] >= r.sq[j + 1];
+                }
                 KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
                 load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
                 t = t_new;
-                load_cols(c, n, skip, at(t < span ? t : 0u), t < span, r);   // r is spent: hashed
+                load_cols<SEQ>(c, n, skip, at(t < span ? t : 0u), t < span, r);   // r is spent: hashed
 #if KTA_DBG_LEVEL == 1   /* ablation builds of tools/ubench_alive.hip only.  1: stream + hash, nothing else */
                 dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
                 return;
@@ -442,6 +466,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                 step(cols_b, keys_b, t_b, cols_a, keys_a);
                 if (t_a >= span) break;
             }
+            if (SEQ && __any(disorder) && lane == 0) atomicOr(order_flag, 1u);
         }
 #if KTA_DBG_LEVEL
         if (dummy == 0x1234567) counts[0] = 1;
@@ -1787,14 +1812,6 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     add_running(delta, running, s_w);
 }
 
-// seq column of a batch: strictly ascending?  (the merge of pass 2 orders a batch's records by their index)
-__global__ __launch_bounds__(kWG) void kta_seq_ascending(const uint64_t *__restrict__ seq, uint64_t n, uint32_t *flag)
-{
-    bool bad = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * kWG + threadIdx.x; i + 1 < n; i += (uint64_t)gridDim.x * kWG) bad |= seq[i] >= seq[i + 1];
-    if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
-}
-
 // bit set state: table of bits -> count (sum_all_alive, metric.rs:282-284)
 __global__ __launch_bounds__(kWG) void kta_bitmap_count(const uint4 *__restrict__ words, uint64_t n16, unsigned long long *out)
 {
@@ -1894,11 +1911,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     }
     // table state: 8-byte pairs (the survivors' sequence numbers come from their batch-local indices)
     if (fuse) return hipErrorInvalidValue;              // (the fused pass exists for the bit set state)
-    const uint32_t *skip = nullptr;
-    if (c.seq) {
-        hipLaunchKernelGGL(kta_seq_ascending, dim3(1024), dim3(kWG), 0, s, c.seq, n, flag);
-        skip = flag;
-    }
+    const uint32_t *skip = c.seq ? flag : nullptr;       // (raised by pass 1 when the batch's seq column does not ascend)
     // the kernel reads the three i32 columns 16 bytes at a time: align them down together
     const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(c.key_len) & 15u) / 4u);
     if ((reinterpret_cast<uintptr_t>(c.val_len) & 15u) / 4u != head || (reinterpret_cast<uintptr_t>(c.key_off) & 15u) / 4u != head ||
@@ -1909,11 +1922,19 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     ca.val_len -= head;
     ca.key_off -= head;
     const size_t lds1 = (size_t)B * kRing * 8 + (size_t)B * 8 + (size_t)kConsumers * 64 * 4 + 16;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kta_alive_partition<BLOG2>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head, pl.tiles_per_wg, pp,
-                       ws.counts, pl.cap, pool, ctl, hist);
+    if (c.seq) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_partition<BLOG2, true>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head,
+                           pl.tiles_per_wg, pp, ws.counts, pl.cap, pool, ctl, hist, flag);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_partition<BLOG2, false>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head,
+                           pl.tiles_per_wg, pp, ws.counts, pl.cap, pool, ctl, hist, flag);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef KTA_DBG_PART_ONLY
