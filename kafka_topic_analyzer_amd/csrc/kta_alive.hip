@@ -5,27 +5,32 @@
 // there, in consumption order (BitSet::insert / remove, metric.rs:273-280).  One memory-side atomic (or even
 // one L2-missing read) per record caps a direct implementation at 20-50 G records/s, so:
 //
-//   pass 1  kta_alive_partition   streams the batch once (16-byte loads, a lane owns four consecutive
-//           records), hashes every key (fnv32.rs:92-101) and appends the pair (hash, batch-local index,
-//           alive) to the segment [bucket = top hash bits][workgroup].  Workgroups take contiguous ranges
-//           of the batch, so segment w of a bucket holds an older range than segment w + 1.  Pairs reach
-//           memory through a ring of 16 pairs per bucket in LDS and leave it in whole aligned 64-byte
-//           blocks (a partial block write costs a memory-side read-modify-write, 28 G/s whatever its size:
-//           tools/ubench_scatter.hip).  No workgroup barrier in the loop: a writer reserves a position with
-//           an LDS atomic, writes its pair, and counts the block's arrivals; whoever completes a block queues
-//           it and the wave writes its queued blocks out together.
+//   pass 1  kta_alive_partition32 (bit set state) / kta_alive_partition (table state)   streams the batch once, hashes
+//           every key (fnv32.rs:92-101) and appends a pair — what pass 2 needs to know of the record — to the segment
+//           [bucket = top 10 hash bits][workgroup].  Workgroups take contiguous ranges of the batch, so segment w of a
+//           bucket holds an older range than segment w + 1.  Pairs reach memory through a ring of two 64-byte blocks
+//           per bucket in LDS and leave it in whole aligned blocks (a partial block write costs a memory-side
+//           read-modify-write, 28 G/s whatever its size: tools/ubench_scatter.hip).  No workgroup barrier in the loop:
+//           twelve PRODUCER waves stream, hash and insert (one returning LDS atomic, one read, one write per record),
+//           four CONSUMER waves sweep the rings' counters and write completed blocks out.
+//             bit set state: a pair is 4 bytes — slot in the bucket, window, alive — and the ORDER of two pairs of one
+//               slot is implicit in (workgroup, window, position in the segment); a guard keeps two records of one hash
+//               out of the same wave instruction (exactly, in one round).  With at most 256 partitions the same kernel
+//               also does the metrics handler's work (FUSE: both handlers of kafka.rs:107-109 in one pass).
+//             table state: a pair is 8 bytes — hash, batch-local index, alive: a survivor's global sequence number comes
+//               from its index; a batch's seq column is checked for order on the way.
 //   pass 2  kta_alive_apply       one workgroup owns one bucket, i.e. one contiguous region of the slot
 //           space.  It merges the bucket's pairs in an LDS table (8-way sets of 16-bit tags chosen by the
-//           slot's ADDRESS, one 16-byte read per lookup; the largest index per slot survives), then applies
+//           slot's ADDRESS, one 16-byte read per lookup; the newest pair per slot survives), then applies
 //           the survivors:
-//             bitmap state (in-order batches, the single-GPU default): the region of the reference's own
-//               512 MiB bit set is streamed through LDS in 32 KiB slices — survivors set / clear their bit
-//               with LDS atomics, the slice goes back in whole lines.  No partial writes, no 32 GiB table.
+//             bit set state (in-order batches, the single-GPU default): the region of the reference's own
+//               512 MiB bit set is streamed through LDS, 2 KiB per wave at a time — survivors set / clear their bit
+//               with LDS atomics, the piece goes back in whole lines.  No partial writes, no 32 GiB table.
 //             table state (global sequence numbers: sharded runs): table[slot] = max(table[slot],
-//               ((seq + 1) << 1) | alive) by the region's only writer, as in round 2.
+//               ((seq + 1) << 1) | alive) by the region's only writer.
 //
 // Exactness never depends on sizes or luck.  A pair that finds no room in its segment goes to a pool; a
-// record that finds its set full goes to a small LDS list that is resolved at the end of the merge.  In table
+// record that finds its set full goes to a small LDS side table that is applied with the sets.  In table
 // state both end in the direct path (pre-read + atomicMax, commutative).  In bitmap state a bucket that cannot
 // be finished on chip (pool pairs, list overflow) is left untouched and reported to kta_alive_fallback, which
 // resolves it exactly in direct-indexed passes over the bucket's pairs.  A bucket with more distinct slots

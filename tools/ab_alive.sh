@@ -2,7 +2,7 @@
 # A/B of build switches of the alive pass (kta_alive.hip) with tools/ubench_alive.hip, many variants per gpurun call
 # (a call costs about half a GPU-minute before the command starts).
 #
-#   build container:   tools/ab_alive.sh build base: one:-DKTA_APPLY_SITES=1 stage0:-DKTA_PART_STAGE=0
+#   build container:   tools/ab_alive.sh build base: l4:"-DKTA_DBG_LEVEL=4 -DKTA_DBG_PART_ONLY" b128:"-DKTA_P32_EXP_BLOG2=9 -DKTA_P32_BLOCK=32 -DKTA_DBG_PART_ONLY"
 #                      -> tools/ubench_alive_ab_<tag>, one binary per "tag:flags" (timing builds: no phase counters)
 #   GPU box:           gpurun --timeout 120 -- 'AB_FULL=tools/ubench_alive_ab_base bash tools/ab_alive.sh run > gpurun_out/ab.txt 2>&1'
 #                      -> per binary: best of 4 repetitions (whole pass and per kernel) on the headline workload, and whether
