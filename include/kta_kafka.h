@@ -115,6 +115,16 @@ int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint
 /* The single-pass form (the device's one-lane-per-batch kernel, kta_kafka_set_variant 1). */
 int64_t kta_gzip_inflate_lane_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 
+/* The record decode kernel's rounds on the host (csrc/kta_records.h: the chain over the length prefixes and the parse
+ * of one record are the device's own code): a group of `lanes` lanes (a divisor of 64) per batch, `window` bytes per
+ * round (a multiple of 16 * lanes), at most `per_round` records per round (a multiple of `lanes`).  `blob` holds the
+ * bytes the descriptors point into (payload_end <= blob_len); key_off may be NULL; offsets are relative to `blob`.
+ * Test infrastructure for the CPU suite — the product decodes on the device (kta_kafka_decode_device). */
+int kta_kafka_decode_rounds_host(const uint8_t *blob, uint64_t blob_len, const kta_kafka_batch_desc *descs,
+                                 uint64_t n_batches, uint32_t lanes, uint32_t window, uint32_t per_round,
+                                 int32_t *partition, int32_t *key_len, int32_t *val_len, int64_t *ts_ms,
+                                 uint32_t *key_off, uint64_t *n_key_bytes, uint64_t *n_bad_batches);
+
 /* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned,
  * readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
  * Keys are ZERO-COPY: when out->key_off is set, key_off[i] is the offset of record i's key inside the
@@ -179,7 +189,7 @@ uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
  * inflate kernels of all four codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
  * 5 = 8 batches per wave (1 KiB windows), 6 / 7 = 4 / 2 batches per wave with 8 KiB windows (7: what the automatic choice takes
  * for batches of 64 KiB and more), 8 = 4 batches per wave, 2 KiB windows, 16 records per round (the automatic choice for
- * batches of 4 ... 64 KiB). */
+ * batches of 4 ... 64 KiB), 9 = 8 batches per wave with 2 KiB windows, 10 = 4 batches per wave with 3 KiB windows. */
 int kta_kafka_set_variant(kta_ctx *ctx, int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);

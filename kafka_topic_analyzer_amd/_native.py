@@ -160,6 +160,9 @@ SIGNATURES = {
     "kta_kafka_decode_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,
                                           C.c_uint64, C.POINTER(KtaBatch), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]),
+    "kta_kafka_decode_rounds_host": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(KtaKafkaBatchDesc), C.c_uint64,
+                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kta_kafka_configure": (C.c_int, [_P, C.c_uint64, C.c_int]),
     "kta_kafka_blob_acquire": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "kta_kafka_blob_submit": (C.c_int, [_P, C.c_uint64, C.c_int32, C.POINTER(KtaKafkaIndexStats)]),

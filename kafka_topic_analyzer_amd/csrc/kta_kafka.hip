@@ -26,6 +26,7 @@
 #include "kta_lz4.h"
 #include "kta_gzip.h"
 #include "kta_zstd.h"
+#include "kta_records.h"
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -181,47 +182,18 @@ __device__ __forceinline__ void pin(uint4 &v)
 // only as many active lanes as there are batches.  Here a group of L = 64/G lanes owns one batch:
 //   1. the group streams a window of the batch into LDS with coalesced 16-byte loads (all in flight);
 //   2. the group's first lane chains the record length prefixes inside the window (LDS latency) and
-//      publishes the record starts.  This step is serial per batch and costs a full wave instruction
-//      per operation whatever the number of active lanes, so G > 1 matters: the G leaders of a wave
-//      chain their batches in the same instruction stream (G = 1 spends half of the kernel here);
-//   3. the group's lanes parse one record each from LDS and write the columns (consecutive indices:
-//      coalesced stores); keys stay where they are (key_off points into the blob);
+//      publishes the record starts (kta::rec::chain).  This step is serial per batch and costs a full wave
+//      instruction per operation whatever the number of active lanes, so G > 1 matters: the G leaders of
+//      a wave chain their batches in the same instruction stream (G = 1 spends half of the kernel here) —
+//      and so the chain does nothing but follow the lengths: judging them is the parse's work;
+//   3. the group's lanes parse one record each from LDS (kta::rec::parse_record: the header from one round
+//      trip) and write the columns (consecutive indices: coalesced stores); keys stay where they are
+//      (key_off points into the blob);
 //   4. the next window starts at the first record that did not fit — or, after a large value, at the
 //      next record start, so value bytes beyond the window are never loaded.
-// Every group runs its own rounds; the wave loops until its last group is done.
-
-// zig-zag varint at byte offset `off` of the LDS window.  Fast path (values < 2^28, i.e. <= 4 bytes —
-// every length/delta of ordinary records): two aligned dword reads, one v_alignbyte, branch-free bit
-// compaction; otherwise the generic byte loop.
-__device__ __forceinline__ bool lds_varlong(const uint8_t *win, uint32_t &off, uint32_t limit, long long &out)
-{
-    if (off + 4u <= limit) {
-        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-        const uint32_t i = off >> 2;
-        const uint32_t w = __builtin_amdgcn_alignbyte(w32[i + 1], w32[i], off & 3u);   // 4 bytes at `off`
-        const uint32_t stop = ~w & 0x80808080u;                                       // first byte without MSB
-        if (stop) {
-            const uint32_t nb = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;            // 1..4 bytes
-            uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
-            v &= 0xFFFFFFFFu >> (32u - 7u * nb);
-            off += nb;
-            out = (long long)(v >> 1) ^ -(long long)(v & 1u);
-            return true;
-        }
-    }
-    unsigned long long v = 0;
-    for (uint32_t shift = 0; shift < 70; shift += 7) {
-        if (off >= limit) return false;
-        const uint32_t b = win[off++];
-        v |= (unsigned long long)(b & 0x7Fu) << (shift < 64 ? shift : 63);
-        if (!(b & 0x80u)) {
-            out = (long long)(v >> 1) ^ -(long long)(v & 1ull);
-            return true;
-        }
-    }
-    return false;
-}
-
+// Every group runs its own rounds; the wave loops until its last group is done.  The kernel is bound by
+// instruction issue (profiles/r04_sq_decode.txt), not by memory: the round is written for few instructions
+// on the ordinary record, and everything unusual leaves the straight line.
 template <int G, uint32_t W, uint32_t R>   // batches per wave, window bytes and records per round of a group
 __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                         uint64_t n_batches, int want_keys, int32_t *part,
@@ -229,13 +201,13 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
                                                         unsigned long long *n_bad, unsigned long long *n_keyb)
 {
+    namespace rec = kta::rec;
     constexpr uint32_t L = 64 / G;                // lanes per batch
     constexpr uint32_t NLOAD = W / (L * 16);      // staged 16-byte loads per lane and window
     constexpr uint32_t NT = R / L;                // parse rounds per window
     static_assert(W % (L * 16) == 0 && R % L == 0, "window geometry");
-    __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the fast varint path reads one dword ahead
-    __shared__ uint32_t s_start[G][R];            // record start, relative to the window base
-    __shared__ uint32_t s_body[G][R];             // offset of the record body (after the length varint)
+    __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the register paths read whole dwords up to 16 bytes ahead
+    __shared__ uint32_t s_start[G][R + 1];        // record starts relative to the window base; [found]: where the last one ends
     __shared__ uint64_t s_next[G];                // absolute position after the last chained record
     __shared__ uint32_t s_found[G], s_first_incomplete[G], s_bad[G];
     const uint32_t lane = threadIdx.x, g = lane / L, sub = lane % L;
@@ -243,183 +215,102 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
     const uint64_t b = (uint64_t)blockIdx.x * G + g;      // the dispatcher balances the waves
     unsigned long long kb = 0;                            // this lane's share of the key bytes
     uint64_t end = 0, pos = 0, record_base = 0;
-    int64_t base_ts = 0, max_ts = 0;
-    uint32_t total = 0, flags = 0, j = 0;                 // j: records finished
+    int64_t ts_base = 0, ts_mask = 0;
+    uint32_t total = 0, j = 0;                            // j: records finished
     int32_t partition = 0;
     bool bad = false;
     if (b < n_batches) {
         const kta_kafka_batch_desc &d = descs[b];
         end = d.payload_end; pos = d.payload_off; record_base = d.record_base;
-        base_ts = d.base_ts_ms; max_ts = d.max_ts_ms;
-        total = (uint32_t)d.n_records; flags = d.flags; partition = d.partition;
+        const bool append_time = (d.flags & KTA_KB_LOG_APPEND_TIME) != 0;   // every record carries maxTimestamp
+        ts_base = append_time ? d.max_ts_ms : d.base_ts_ms;
+        ts_mask = append_time ? 0 : -1;
+        total = (uint32_t)d.n_records; partition = d.partition;
         bad = d.status != 0;                              // failed check.crcs or inflate: the batch is not delivered
     }
     bool run = !bad && j < total;                         // uniform inside a group
     while (__any(run)) {
-        uint64_t wbase = 0, wlimit_abs = 0;
-        uint32_t limit = 0;                               // valid bytes in the window
+        uint64_t wbase = 0;
+        uint32_t limit = 0, end_rel = 0;                  // valid bytes in the window; the batch's end seen from its base
+        bool to_the_end = false;                          // the window reaches the end of the batch
         if (run && pos >= end) { bad = true; run = false; }
         if (run) {
             wbase = pos & ~15ull;
-            const uint64_t span = ((end + 15) & ~15ull) - wbase;
-            const uint32_t wbytes = span < W ? (uint32_t)span : W;
-            wlimit_abs = wbase + wbytes < end ? wbase + wbytes : end;
-            limit = (uint32_t)(wlimit_abs - wbase);
-            // all loads of the window are in flight together (clamped address, conditional LDS store)
+            const uint64_t span = ((end + 15) & ~15ull) - wbase, rest = end - wbase;
+            const uint32_t wbytes = span < W ? (uint32_t)span : W;         // a multiple of 16, at least 16
+            to_the_end = rest <= wbytes;
+            limit = to_the_end ? (uint32_t)rest : wbytes;
+            end_rel = rest < 0xF0000000ull ? (uint32_t)rest : 0xF0000000u;
+            // all loads of the window are in flight together; a lane behind the batch's last block loads that block
+            // again and stores it where its own would go — bytes at and behind `limit`, which decide nothing
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + wbase;
             uint4 stage[NLOAD];
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) {
                 const uint32_t o = (sub + u * L) * 16;
-                stage[u] = blocks[(wbase + (o < wbytes ? o : wbytes - 16)) >> 4];
+                stage[u] = *reinterpret_cast<const uint4 *>(src + (o < wbytes - 16 ? o : wbytes - 16));
             }
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
 #pragma unroll
-            for (uint32_t u = 0; u < NLOAD; u++) {
-                const uint32_t o = (sub + u * L) * 16;
-                if (o < wbytes) s_win[g][o >> 4] = stage[u];
-            }
-            if (sub == 0) { s_bad[g] = 0; s_found[g] = 0; s_first_incomplete[g] = R; }
+            for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = stage[u];
+            if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
         }
         __syncthreads();
         if (run && sub == 0) {                                                 // chain the length prefixes
-            // Offsets are relative to the window base.  Fast step: the length is a 1..4 byte varint inside
-            // the window (always, for ordinary records) — one LDS read, straight-line integer code.
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-            const uint64_t end_rel64 = end - wbase;
-            const uint32_t end_rel = end_rel64 > 0xF0000000ull ? 0xF0000000u : (uint32_t)end_rel64;
             const uint32_t want = total - j < R ? total - j : R;
             uint32_t k = 0, cur = (uint32_t)(pos - wbase);
-            uint64_t next = 0;                                                 // set when the slow step leaves the window
-            uint32_t flag_bad = 0;
-            while (k < want && cur < limit) {
-                uint32_t stop = 0, w = 0;
-                if (cur + 4u <= limit) {
-                    w = __builtin_amdgcn_alignbyte(w32[(cur >> 2) + 1], w32[cur >> 2], cur & 3u);
-                    stop = ~w & 0x80808080u;
-                }
-                if (stop) {
-                    const uint32_t nb = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;
-                    uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
-                    v &= 0xFFFFFFFFu >> (32u - 7u * nb);
-                    const uint32_t body = cur + nb, rec_end = body + (v >> 1);  // < 2^13 + 2^27: no overflow
-                    if ((v & 1u) || rec_end > end_rel) { flag_bad = 1; break; } // negative length / overruns the batch
-                    s_start[g][k] = cur;
-                    s_body[g][k] = body;
-                    k++;
-                    cur = rec_end;
-                    continue;
-                }
-                uint32_t off = cur;                                            // slow step: long varint or window edge
+            uint64_t next = 0;
+            if (rec::chain(w32, limit, want, s_start[g], k, cur)) {
+                // a length of five bytes or more in front of the chain — a record of 128 MiB, or a padded encoding:
+                // byte by byte, and the round ends behind this record
+                uint32_t off = cur;
                 long long len;
-                if (!lds_varlong(win, off, limit, len)) {
-                    if (wlimit_abs == end) flag_bad = 1;                       // ran into the end of the batch
-                    break;                                                     // else it straddles the window: next round
-                }
-                const uint64_t rec_end = wbase + off + (uint64_t)len;
-                if (len < 0 || rec_end > end) { flag_bad = 1; break; }
-                s_start[g][k] = cur;
-                s_body[g][k] = off;
-                k++;
-                if (rec_end >= wlimit_abs) { next = rec_end; break; }
-                cur = (uint32_t)(rec_end - wbase);
+                if (rec::window_varlong(win, off, limit, len)) {
+                    const uint64_t rec_end = wbase + off + (uint64_t)len;
+                    if (len < 0 || rec_end > end) s_bad[g] = 1;
+                    else { s_start[g][k++] = cur; next = rec_end; }
+                } else if (to_the_end) {
+                    s_bad[g] = 1;                                              // ran into the end of the batch
+                }                                                              // (else it straddles the window: next round)
             }
-            if (flag_bad) s_bad[g] = 1;
+            if (!next) next = wbase + cur;
+            const uint64_t next_rel = next - wbase;
+            s_start[g][k] = next_rel < 0xFFFFFFFFull ? (uint32_t)next_rel : 0xFFFFFFFFu;
             s_found[g] = k;
-            s_next[g] = next ? next : wbase + cur;
+            s_next[g] = next;
         }
         __syncthreads();
-        long long my_kl[NT];
+        uint32_t my_kl[NT];
 #pragma unroll
         for (uint32_t t = 0; t < NT; t++) my_kl[t] = 0;
         if (run) {
             const uint32_t found = s_found[g];
-            const uint64_t next = s_next[g];
+            const uint32_t key_base = (uint32_t)(wbase - blob_base);           // key offsets are 32 bits wide
 #pragma unroll
             for (uint32_t t = 0; t < NT; t++) {                                // one record per lane and round
                 const uint32_t k = sub + L * t;
                 if (k >= found) continue;
-                uint32_t off = s_body[g][k] + 1;                               // + record attributes byte
-                const uint64_t rec_end = (k + 1 < found) ? wbase + s_start[g][k + 1] : next;
-                long long ts_delta = 0, od = 0, kl = 0, vl = 0;
-                // The three varints behind the attributes byte — timestamp delta, offset delta, key length — are
-                // 3 to 8 bytes for ordinary records: three dwords of the window (ONE LDS round trip) hold them, and
-                // they are taken apart in registers.  (Byte by byte, every byte is a dependent LDS read: the parse
-                // phase was a chain of ten round trips.)  Anything else — a varint of more than four bytes, more than
-                // eight bytes in all, the window's edge — takes the byte loop.
-                bool head = false;
-                {
-                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-                    const uint32_t i0 = off >> 2, sh = off & 3u;
-                    const uint32_t d0 = w32[i0], d1 = w32[i0 + 1], d2 = w32[i0 + 2];   // (inside s_win: off < W, and s_win has 16 bytes more)
-                    unsigned long long x = (unsigned long long)__builtin_amdgcn_alignbyte(d1, d0, sh) |
-                                           ((unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
-                    uint32_t used = 0, val[3];
-                    bool ok = true;
-#pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        const uint32_t w = (uint32_t)x, stop = ~w & 0x80808080u;
-                        const uint32_t nb = stop ? ((uint32_t)__builtin_ctz(stop) + 1u) >> 3 : 5u;
-                        ok = ok && nb <= 4u && used + nb <= 8u;
-                        uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
-                        v &= 0xFFFFFFFFu >> (32u - 7u * (nb <= 4u ? nb : 4u));
-                        val[f] = v;
-                        x >>= 8u * (nb <= 4u ? nb : 4u);
-                        used += nb;
-                    }
-                    if (ok && off + used <= limit) {
-                        ts_delta = (long long)(val[0] >> 1) ^ -(long long)(val[0] & 1u);
-                        od = (long long)(val[1] >> 1) ^ -(long long)(val[1] & 1u);
-                        kl = (long long)(val[2] >> 1) ^ -(long long)(val[2] & 1u);
-                        off += used;
-                        head = true;
-                    }
+                const uint32_t start = s_start[g][k], rec_end = s_start[g][k + 1];
+                if (rec_end > end_rel) { s_bad[g] = 1; continue; }             // the record overruns the batch
+                rec::Record r;
+                uint32_t verdict = rec::parse_record(win, start, rec_end, limit, r);
+                if (verdict == rec::REC_VALUE_LENGTH_OUTSIDE) {                // behind a key of the window's size
+                    Reader gr{blocks, wbase + r.after, ~0ull, make_uint4(0, 0, 0, 0)};
+                    r.val_len = read_varlong(gr);
+                    verdict = rec::value_fits(r.val_len, gr.pos - wbase, rec_end);
                 }
-                if (!head && !(lds_varlong(win, off, limit, ts_delta) && lds_varlong(win, off, limit, od) &&
-                               lds_varlong(win, off, limit, kl))) {
-                    atomicMin(&s_first_incomplete[g], k);                      // header not inside this window
-                    continue;
-                }
-                const uint64_t key_pos = wbase + off;
-                const uint64_t vpos = key_pos + (kl > 0 ? (uint64_t)kl : 0);
-                bool rec_ok = kl >= -1 && vpos < rec_end;
-                if (rec_ok) {
-                    bool got = false;
-                    uint64_t after = 0;                                        // position after the value length
-                    if (vpos < wlimit_abs) {
-                        uint32_t voff = (uint32_t)(vpos - wbase);
-                        // the value length: one to four bytes inside the window as a rule — two dwords, one round trip
-                        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-                        const uint32_t w = __builtin_amdgcn_alignbyte(w32[(voff >> 2) + 1], w32[voff >> 2], voff & 3u);
-                        const uint32_t stop = ~w & 0x80808080u;
-                        const uint32_t nb = stop ? ((uint32_t)__builtin_ctz(stop) + 1u) >> 3 : 5u;
-                        if (nb <= 4u && voff + nb <= limit) {
-                            uint32_t v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u) | ((w >> 2) & 0x1FC000u) | ((w >> 3) & 0xFE00000u);
-                            v &= 0xFFFFFFFFu >> (32u - 7u * nb);
-                            vl = (long long)(v >> 1) ^ -(long long)(v & 1u);
-                            voff += nb;
-                            got = true;
-                        } else {
-                            got = lds_varlong(win, voff, limit, vl);
-                        }
-                        after = wbase + voff;
-                    }
-                    if (!got) {                                                // value length lies beyond the window
-                        Reader gr{blocks, vpos, ~0ull, make_uint4(0, 0, 0, 0)};
-                        vl = read_varlong(gr);
-                        after = gr.pos;
-                    }
-                    rec_ok = vl >= -1 && after + (uint64_t)(vl > 0 ? vl : 0) <= rec_end;
-                }
-                if (!rec_ok) { s_bad[g] = 1; continue; }
+                if (verdict == rec::REC_INCOMPLETE) { atomicMin(&s_first_incomplete[g], k); continue; }
+                if (verdict != rec::REC_OK) { s_bad[g] = 1; continue; }
                 const uint64_t i = record_base + j + k;
                 part[i] = partition;
-                klen[i] = (int32_t)kl;
-                vlen[i] = (int32_t)vl;
-                ts[i] = (flags & KTA_KB_LOG_APPEND_TIME) ? max_ts : base_ts + ts_delta;
+                klen[i] = (int32_t)r.key_len;
+                vlen[i] = (int32_t)r.val_len;
+                ts[i] = ts_base + (r.ts_delta & ts_mask);
                 if (seq) seq[i] = seq_base + i;
-                if (want_keys) koff[i] = (uint32_t)(kl > 0 ? key_pos - blob_base : 0);
-                my_kl[t] = kl;
+                if (want_keys) koff[i] = r.key_len > 0 ? key_base + r.key : 0u;
+                my_kl[t] = r.key_len > 0 ? (uint32_t)r.key_len : 0u;
             }
         }
         __syncthreads();
@@ -432,7 +323,7 @@ __global__ __launch_bounds__(64) void kafka_decode_coop(const uint4 *blocks, con
             } else {
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++)
-                    if (sub + L * t < done && my_kl[t] > 0) kb += (unsigned long long)my_kl[t];
+                    if (sub + L * t < done) kb += my_kl[t];
                 j += done;
                 pos = done < found ? wbase + s_start[g][done] : s_next[g];     // records >= done are redone
                 run = j < total;
@@ -1274,7 +1165,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..8 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..10 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1544,6 +1435,115 @@ int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, ui
     return kta::snappy_inflate(src, n, dst, cap);
 }
 
+// The rounds of kafka_decode_coop on the host: one group of `lanes` lanes per batch, its lanes one after the other
+// (inside a phase the kernel's lanes only meet in s_bad and s_first_incomplete), over kta::rec::chain and
+// kta::rec::parse_record as the device compiles them.  The window holds the batch's valid bytes and poison behind
+// them — what the device finds there is whatever the last window left.
+int kta_kafka_decode_rounds_host(const uint8_t *blob, uint64_t blob_len, const kta_kafka_batch_desc *descs,
+                                 uint64_t n_batches, uint32_t lanes, uint32_t window, uint32_t per_round,
+                                 int32_t *partition, int32_t *key_len, int32_t *val_len, int64_t *ts_ms,
+                                 uint32_t *key_off, uint64_t *n_key_bytes, uint64_t *n_bad_batches)
+{
+    namespace rec = kta::rec;
+    if (!blob || (!descs && n_batches) || !partition || !key_len || !val_len || !ts_ms) return KTA_ERR_INVALID;
+    if (lanes == 0 || 64 % lanes != 0 || window == 0 || window % (lanes * 16) != 0 || per_round == 0 || per_round % lanes != 0)
+        return KTA_ERR_INVALID;
+    const uint32_t W = window, R = per_round;
+    std::vector<uint32_t> win_words(W / 4 + 4), starts(R + 1);
+    uint8_t *win = reinterpret_cast<uint8_t *>(win_words.data());
+    uint64_t key_bytes = 0, n_bad = 0;
+    for (uint64_t b = 0; b < n_batches; b++) {
+        const kta_kafka_batch_desc &d = descs[b];
+        const uint64_t end = d.payload_end;
+        if (end > blob_len || d.payload_off > end) return KTA_ERR_INVALID;
+        const bool append_time = (d.flags & KTA_KB_LOG_APPEND_TIME) != 0;
+        const int64_t ts_base = append_time ? d.max_ts_ms : d.base_ts_ms, ts_mask = append_time ? 0 : -1;
+        const uint32_t total = (uint32_t)d.n_records;
+        uint64_t pos = d.payload_off, kb = 0;
+        uint32_t j = 0;
+        bool bad = d.status != 0, run = !bad && j < total;
+        while (run) {
+            if (pos >= end) { bad = true; break; }
+            const uint64_t wbase = pos & ~15ull;
+            const uint64_t span = ((end + 15) & ~15ull) - wbase, rest = end - wbase;
+            const uint32_t wbytes = span < W ? (uint32_t)span : W;
+            const bool to_the_end = rest <= wbytes;
+            const uint32_t limit = to_the_end ? (uint32_t)rest : wbytes;
+            const uint32_t end_rel = rest < 0xF0000000ull ? (uint32_t)rest : 0xF0000000u;
+            memset(win, 0xA5 ^ (int)(pos & 0x5A), W + 16);
+            memcpy(win, blob + wbase, limit);
+            bool s_bad = false;
+            uint32_t first_incomplete = R;
+            // the leader
+            const uint32_t want = total - j < R ? total - j : R;
+            uint32_t k = 0, cur = (uint32_t)(pos - wbase);
+            uint64_t next = 0;
+            if (rec::chain(win_words.data(), limit, want, starts.data(), k, cur)) {
+                uint32_t off = cur;
+                long long len;
+                if (rec::window_varlong(win, off, limit, len)) {
+                    const uint64_t rec_end = wbase + off + (uint64_t)len;
+                    if (len < 0 || rec_end > end) s_bad = true;
+                    else { starts[k++] = cur; next = rec_end; }
+                } else if (to_the_end) {
+                    s_bad = true;
+                }
+            }
+            if (!next) next = wbase + cur;
+            const uint64_t next_rel = next - wbase;
+            starts[k] = next_rel < 0xFFFFFFFFull ? (uint32_t)next_rel : 0xFFFFFFFFu;
+            const uint32_t found = k;
+            // the lanes
+            std::vector<uint32_t> my_kl(found, 0);
+            for (k = 0; k < found; k++) {
+                const uint32_t start = starts[k], rec_end = starts[k + 1];
+                if (rec_end > end_rel) { s_bad = true; continue; }
+                rec::Record r;
+                uint32_t verdict = rec::parse_record(win, start, rec_end, limit, r);
+                if (verdict == rec::REC_VALUE_LENGTH_OUTSIDE) {
+                    uint64_t at = wbase + r.after;
+                    unsigned long long v = 0;
+                    for (uint32_t shift = 0; shift < 70; shift += 7) {
+                        const uint32_t byte = at < blob_len ? blob[at] : 0u;      // (the device's blob is padded)
+                        at++;
+                        v |= (unsigned long long)(byte & 0x7Fu) << (shift < 64 ? shift : 63);
+                        if (!(byte & 0x80u)) break;
+                    }
+                    r.val_len = (long long)(v >> 1) ^ -(long long)(v & 1ull);
+                    verdict = rec::value_fits(r.val_len, at - wbase, rec_end);
+                }
+                if (verdict == rec::REC_INCOMPLETE) { if (k < first_incomplete) first_incomplete = k; continue; }
+                if (verdict != rec::REC_OK) { s_bad = true; continue; }
+                const uint64_t i = d.record_base + j + k;
+                partition[i] = d.partition;
+                key_len[i] = (int32_t)r.key_len;
+                val_len[i] = (int32_t)r.val_len;
+                ts_ms[i] = ts_base + (r.ts_delta & ts_mask);
+                if (key_off) key_off[i] = r.key_len > 0 ? (uint32_t)wbase + r.key : 0u;
+                my_kl[k] = r.key_len > 0 ? (uint32_t)r.key_len : 0u;
+            }
+            const uint32_t done = first_incomplete < found ? first_incomplete : found;
+            if (s_bad || done == 0) { bad = true; break; }
+            for (k = 0; k < done; k++) kb += my_kl[k];
+            j += done;
+            pos = done < found ? wbase + starts[done] : next;
+            run = j < total;
+        }
+        if (bad) {
+            for (uint32_t r = j; r < total; r++) {
+                const uint64_t i = d.record_base + r;
+                partition[i] = -1; key_len[i] = -1; val_len[i] = -1; ts_ms[i] = -1;
+                if (key_off) key_off[i] = 0u;
+            }
+            n_bad++;
+        }
+        key_bytes += kb;
+    }
+    if (n_key_bytes) *n_key_bytes = key_bytes;
+    if (n_bad_batches) *n_bad_batches = n_bad;
+    return KTA_OK;
+}
+
 int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
                             const kta_kafka_batch_desc *descs_host, uint64_t n_batches, uint64_t n_records,
                             const kta_batch *out, uint64_t *n_key_bytes, uint64_t *n_bad_batches)
@@ -1673,6 +1673,8 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     case 6: KTA_DECODE_COOP(4, 8192u, 128u); break;   // 16 lanes per batch, 8 KiB windows
     case 7: KTA_DECODE_COOP(2, 8192u, 128u); break;   // 32 lanes per batch, 8 KiB windows: batches of 64 KiB and more
     case 8: KTA_DECODE_COOP(4, 2048u, 16u); break;    // 16 lanes per batch, 2 KiB windows, ONE parse round per window: 16 KiB batches
+    case 9: KTA_DECODE_COOP(8, 2048u, 16u); break;    // 8 lanes per batch, 2 KiB windows: eight leaders chain side by side
+    case 10: KTA_DECODE_COOP(4, 3072u, 16u); break;   // 16 lanes per batch, 3 KiB windows: ~11 records of the 256-byte mean
     default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
     }
 #undef KTA_DECODE_COOP
@@ -1933,7 +1935,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 8) return KTA_ERR_INVALID;
+    if (!ctx || variant < 0 || variant > 10) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }

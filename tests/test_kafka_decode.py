@@ -237,7 +237,7 @@ def _decode_on_device(h, blob, partition, with_keys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
                                                         (6, True, 3000)])
 def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, variant):
@@ -264,12 +264,61 @@ def test_device_decode_reports_corrupt_batches():
     bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
     blob = good + bad + good
     want, ost = kafka_decode(blob, 0)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         with kta.HipMetricHandler(2, now=NOW) as h:
             h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, nbad = _decode_on_device(h, blob, 0, True)
             assert nbad == 1 == ost.bad_batches
             assert list(cols["partition"]) == list(want["partition"]) == [0, 0, 0, 0, -1, 0, 0]
+
+
+# kta_kafka_set_variant -> (lanes per batch, window bytes, records per round) of kafka_decode_coop (csrc/kta_kafka.hip)
+GEOMETRY_OF_VARIANT = {2: (64, 8192, 256), 3: (16, 4096, 64), 4: (16, 2048, 32), 5: (8, 1024, 16), 6: (16, 8192, 128),
+                       7: (32, 8192, 128), 8: (16, 2048, 16), 9: (8, 2048, 16), 10: (16, 3072, 16)}
+
+
+@pytest.mark.gpu
+def test_device_rounds_equal_their_host_statement_bit_for_bit():
+    """The kernel against kta_kafka_decode_rounds_host in the same geometry: unusual encodings (padded and long
+    varints, keys and values larger than a window), every malformed record of tests/test_decode_rounds.py and randomly
+    damaged record sets — identical columns, including WHICH records of a reported batch are withheld."""
+    import test_decode_rounds as R
+    blobs = []
+    filler = [(i, b"key-%d" % i, b"x" * (37 * i % 400)) for i in range(40)]
+    for recs in R.UNUSUAL:
+        raw = b"".join(R.record(r[0], r[1], r[2], r[3], offset_delta=i) for i, r in enumerate(recs))
+        blobs.append(K.encode_batch(0, filler, 1000) + K.encode_batch(40, recs, 10**12, raw_records=raw) +
+                     K.encode_batch(50, filler, 2000))
+    for what in sorted(R.MALFORMED):
+        for before in (0, 3, 60):
+            good = [(i, b"key-%d" % i, b"x" * (53 * i % 300)) for i in range(before)]
+            raw = b"".join(K.encode_record(i, *r) for i, r in enumerate(good)) + R.MALFORMED[what]()
+            blobs.append(K.encode_batch(0, filler, 1000) +
+                         K.encode_batch(20, good + [(0, b"?", b"?")], 5000, raw_records=raw) +
+                         K.encode_batch(100, filler, 2000))
+    rng = np.random.default_rng(77)
+    clean, _, _ = random_record_set(rng, 8, max_records=120, with_noise=False, big=True)
+    _, descs, st = index_host(clean, 1)
+    for _ in range(40):
+        hurt = bytearray(clean)
+        for _ in range(int(rng.integers(1, 4))):
+            d = descs[int(rng.integers(0, st.n_batches))]
+            at = int(rng.integers(d.payload_off, d.payload_end))
+            hurt[at] = int(rng.integers(0, 256))
+        blobs.append(bytes(hurt))
+    reported = 0
+    with kta.HipMetricHandler(8, now=NOW) as h:
+        for variant, geometry in sorted(GEOMETRY_OF_VARIANT.items()):
+            h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
+            for n, blob in enumerate(blobs):
+                want, _, _, want_bad = R.rounds_host(blob, 1, geometry)
+                cols, _, bad = _decode_on_device(h, blob, 1, True)
+                assert bad == want_bad, (variant, n)
+                reported += bad
+                for k in ("partition", "key_len", "val_len", "ts_ms", "key_off"):
+                    assert np.array_equal(cols[k], want[k]), (variant, n, k)
+                assert cols["n_key_bytes"] == want["n_key_bytes"], (variant, n)
+    assert reported > 100
 
 
 @pytest.mark.gpu
