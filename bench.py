@@ -45,10 +45,12 @@ TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / 
 
 
 def _source_hash(rel):
-    """sha256 of a kernel source file as it lies in the tree (what tools/make_traffic.py recorded)."""
+    """sha256 of a kernel's source as it lies in the tree (what tools/make_traffic.py recorded): of the file, or — for
+    a kernel that lives in several files, "a.hip+b.h+c.h" — of the files' digests one after the other."""
     import hashlib
     try:
-        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+        digests = [hashlib.sha256(open(os.path.join(ROOT, r), "rb").read()).hexdigest() for r in rel.split("+")]
+        return (digests[0] if len(digests) == 1 else hashlib.sha256("".join(digests).encode()).hexdigest())[:16]
     except OSError:
         return None
 

@@ -34,6 +34,22 @@ def test_traffic_is_null_once_the_kernel_source_changes(tmp_path):
     assert b._traffic("k", 1000) is None                     # the kernel is no longer the measured one
 
 
+def test_a_kernel_in_several_files_is_stale_when_any_of_them_changes(tmp_path):
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "csrc").mkdir()
+    files = [tmp_path / "csrc" / n for n in ("k.hip", "k_body.h")]
+    files[0].write_text('#include "k_body.h"\n')
+    files[1].write_text("__global__ void k() {}\n")
+    digests = "".join(hashlib.sha256(f.read_bytes()).hexdigest() for f in files)
+    table = {"k": {"records_per_launch": 10, "hbm_bytes_per_launch": 5.0, "source_file": "csrc/k.hip+csrc/k_body.h",
+                   "source_sha256_16": hashlib.sha256(digests.encode()).hexdigest()[:16]}}
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(table))
+    b = _bench(tmp_path)
+    assert b._traffic("k", 10) == 5.0
+    files[1].write_text("__global__ void k() { /* touched */ }\n")
+    assert b._traffic("k", 10) is None
+
+
 def test_committed_traffic_file_matches_the_tree_or_yields_null():
     """Whatever profiles/traffic.json holds, every entry either carries the hash of its source file as committed,
     or bench.py reports null for it."""

@@ -27,7 +27,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def src(rel):
-    return {"source_file": rel, "source_sha256_16": hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]}
+    """rel: one file, or the files a kernel lives in joined by "+" (bench.py: _source_hash reads it the same way)."""
+    digests = [hashlib.sha256(open(os.path.join(ROOT, r), "rb").read()).hexdigest() for r in rel.split("+")]
+    return {"source_file": rel,
+            "source_sha256_16": (digests[0] if len(digests) == 1 else hashlib.sha256("".join(digests).encode()).hexdigest())[:16]}
 
 path = sys.argv[1]
 rows = {}          # (kernel prefix, counter) -> (n, avg, min, max)
@@ -114,7 +117,8 @@ out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<4, 2048u, 16u>", "recor
                             "ratio_to_algorithmic": (rd + wr) / raw_log,
                             "note": "rows are per launch size (the summary carries grid sizes): the largest grid = the 4 M-record / "
                                     "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them" % f[0],
-                            **src("kafka_topic_analyzer_amd/csrc/kta_kafka.hip")}
+                            **src("kafka_topic_analyzer_amd/csrc/kta_kafka.hip+kafka_topic_analyzer_amd/csrc/kta_decode_coop.h+"
+                                  "kafka_topic_analyzer_amd/csrc/kta_records.h")}
 print("decode: read %.3f GB + wrote %.3f GB vs raw log %.3f GB" % (rd / 1e9, wr / 1e9, raw_log / 1e9), file=sys.stderr)
 json.dump(out, sys.stdout, indent=1)
 print()
