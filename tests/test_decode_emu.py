@@ -10,6 +10,7 @@ Memory safety of the kernel's global accesses (the blob's 64 readable bytes behi
         python -m pytest tests/test_decode_emu.py
 builds the emulated kernel with AddressSanitizer + UBSan (the blob copy is a heap block of exactly that size)."""
 import ctypes as C
+import functools
 import os
 import subprocess
 
@@ -36,7 +37,7 @@ ORDERS = [(0, 0), (1, 0), (2, 7)]            # (lane order between meeting point
 def emu(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("emu") / "libkta_decode_emu.so")
     sanitize = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if os.environ.get("KTA_EMU_ASAN") else []
-    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", *sanitize,
+    r = subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", *sanitize,
                         "-I", CSRC, "-I", NATIVE, os.path.join(NATIVE, "decode_coop_emu.cpp"), "-o", so],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -96,14 +97,21 @@ def test_the_emulator_runs_lanes_in_the_order_asked_and_sees_a_missing_barrier(e
     assert b"different points" in emu.kta_emu_last_error()
 
 
+@functools.lru_cache(maxsize=None)
+def _random_case(seed, max_records):
+    """One record set per seed for all geometries (the Python encoder is most of a case's time)."""
+    rng = np.random.default_rng(seed)
+    blob, expected, _ = random_record_set(rng, 60 if max_records < 1000 else 6, max_records=max_records, big=(seed == 5))
+    want, _ = kafka_decode(blob, 3)
+    return blob, expected, want
+
+
 @pytest.mark.parametrize("geometry", GEOMETRIES)
 @pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
                                                         (6, True, 3000)])
 def test_kernel_source_matches_encoder_and_oracle(emu, seed, with_keys, max_records, geometry):
     """The cases of test_device_decode_matches_encoder_and_oracle (tests/test_kafka_decode.py), lane orders in turn."""
-    rng = np.random.default_rng(seed)
-    blob, expected, _ = random_record_set(rng, 60 if max_records < 1000 else 6, max_records=max_records, big=(seed == 5))
-    want, _ = kafka_decode(blob, 3)
+    blob, expected, want = _random_case(seed, max_records)
     host, _, _, _ = R.rounds_host(blob, 3, geometry, with_keys)
     order = ORDERS[(seed + geometry[1] // 64) % len(ORDERS)]
     cols, bad = run_kernel(emu, blob, 3, geometry, order, with_keys=with_keys, with_seq=(seed % 2 == 1), seq_base=10**12)
@@ -118,6 +126,7 @@ def test_kernel_source_matches_encoder_and_oracle(emu, seed, with_keys, max_reco
         assert np.array_equal(cols["seq"], 10**12 + np.arange(len(cols["seq"]), dtype=np.uint64))
 
 
+@functools.lru_cache(maxsize=None)
 def _awkward_blobs():
     """The blobs of test_device_rounds_equal_their_host_statement_bit_for_bit (tests/test_kafka_decode.py)."""
     blobs = []
