@@ -71,8 +71,11 @@ __device__ __forceinline__ void pin(uint4 &v)
 // 100 / 102 VGPRs without a hint — four waves per SIMD where their LDS (8.6 / 9.0 KiB per workgroup) admits 4.75 — and to
 // 96 with it: no spills, the same instruction counts (the kernel measured in round 4 had 89).  The geometries with more
 // than 8 KiB of windows per wave do not fit five waves and are compiled without the hint.
+#ifndef KTA_WAVES_PER_EU   // (tests/native/wave_emu.h defines it away: a host compiler does not parse the attribute)
+#define KTA_WAVES_PER_EU(least, most) __attribute__((amdgpu_waves_per_eu(least, most)))
+#endif
 template <int G, uint32_t W, uint32_t R>   // batches per wave, window bytes and records per round of a group
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G * W <= 8192 ? 5 : 1, 8))) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
+__global__ __launch_bounds__(64) KTA_WAVES_PER_EU(G * W <= 8192 ? 5 : 1, 8) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                         uint64_t n_batches, int want_keys, int32_t *part,
                                                         int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,

@@ -29,6 +29,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define KTA_WAVES_PER_EU(least, most)
 
 struct uint4 {
     uint32_t x, y, z, w;

@@ -37,7 +37,7 @@ ORDERS = [(0, 0), (1, 0), (2, 7)]            # (lane order between meeting point
 def emu(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("emu") / "libkta_decode_emu.so")
     sanitize = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if os.environ.get("KTA_EMU_ASAN") else []
-    r = subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", "-Wno-attributes", *sanitize,
+    r = subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", *sanitize,
                         "-I", CSRC, "-I", NATIVE, os.path.join(NATIVE, "decode_coop_emu.cpp"), "-o", so],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
