@@ -954,7 +954,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..10 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..12 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1464,6 +1464,8 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     case 8: KTA_DECODE_COOP(4, 2048u, 16u); break;    // 16 lanes per batch, 2 KiB windows, ONE parse round per window: 16 KiB batches
     case 9: KTA_DECODE_COOP(8, 2048u, 16u); break;    // 8 lanes per batch, 2 KiB windows: eight leaders chain side by side
     case 10: KTA_DECODE_COOP(4, 3072u, 16u); break;   // 16 lanes per batch, 3 KiB windows: ~11 records of the 256-byte mean
+    case 11: KTA_DECODE_COOP(2, 8192u, 32u); break;   // as 7 with ONE parse round per window (an 8 KiB window holds ~31 records
+    case 12: KTA_DECODE_COOP(2, 8192u, 64u); break;   //   of the 256-byte mean) and with two: candidates for batches >= 64 KiB, untimed
     default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
     }
 #undef KTA_DECODE_COOP
@@ -1724,7 +1726,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 10) return KTA_ERR_INVALID;
+    if (!ctx || variant < 0 || variant > 12) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }

@@ -107,6 +107,8 @@ int kta_emu_decode_coop(uint32_t lanes, uint32_t window, uint32_t per_round, int
     GEOMETRY(4, 2048u, 32u);
     GEOMETRY(4, 8192u, 128u);
     GEOMETRY(2, 8192u, 128u);
+    GEOMETRY(2, 8192u, 32u);
+    GEOMETRY(2, 8192u, 64u);
     GEOMETRY(4, 2048u, 16u);
     GEOMETRY(8, 2048u, 16u);
     GEOMETRY(4, 3072u, 16u);
