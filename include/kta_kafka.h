@@ -190,7 +190,8 @@ uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
  * 5 = 8 batches per wave (1 KiB windows), 6 / 7 = 4 / 2 batches per wave with 8 KiB windows (7: what the automatic choice takes
  * for batches of 64 KiB and more), 8 = 4 batches per wave, 2 KiB windows, 16 records per round (the automatic choice for
  * batches of 4 ... 64 KiB), 9 = 8 batches per wave with 2 KiB windows, 10 = 4 batches per wave with 3 KiB windows,
- * 11 / 12 = as 7 with 32 / 64 records per round (one / two parse rounds per window instead of four). */
+ * 11 / 12 = as 7 with 32 / 64 records per round (one / two parse rounds per window instead of four), 13 / 14 = as 7 / 12
+ * with the next window's blocks in flight while a round chains and parses. */
 int kta_kafka_set_variant(kta_ctx *ctx, int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);

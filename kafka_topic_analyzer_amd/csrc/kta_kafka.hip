@@ -954,7 +954,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..12 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..14 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1450,6 +1450,10 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
                        words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
                        out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
+#define KTA_DECODE_COOP_PF(G, W, R)                                                                                   \
+    hipLaunchKernelGGL((kafka_decode_coop_pf<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s, \
+                       words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
+                       out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
     switch (decode_variant_for(st->variant, n_batches, blob_len)) {
     case 1: // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
@@ -1466,9 +1470,12 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     case 10: KTA_DECODE_COOP(4, 3072u, 16u); break;   // 16 lanes per batch, 3 KiB windows: ~11 records of the 256-byte mean
     case 11: KTA_DECODE_COOP(2, 8192u, 32u); break;   // as 7 with ONE parse round per window (an 8 KiB window holds ~31 records
     case 12: KTA_DECODE_COOP(2, 8192u, 64u); break;   //   of the 256-byte mean) and with two: candidates for batches >= 64 KiB, untimed
+    case 13: KTA_DECODE_COOP_PF(2, 8192u, 128u); break;   // as 7 / 12 with the next window's blocks in flight during chain and
+    case 14: KTA_DECODE_COOP_PF(2, 8192u, 64u); break;    //   parse (kta_decode_coop.h: PF): candidates likewise, untimed
     default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
     }
 #undef KTA_DECODE_COOP
+#undef KTA_DECODE_COOP_PF
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
     if (n_bad_batches || n_key_bytes) {
@@ -1726,7 +1733,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 12) return KTA_ERR_INVALID;
+    if (!ctx || variant < 0 || variant > 14) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }

@@ -237,7 +237,7 @@ def _decode_on_device(h, blob, partition, with_keys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
                                                         (6, True, 3000)])
 def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, variant):
@@ -264,7 +264,7 @@ def test_device_decode_reports_corrupt_batches():
     bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
     blob = good + bad + good
     want, ost = kafka_decode(blob, 0)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
         with kta.HipMetricHandler(2, now=NOW) as h:
             h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, nbad = _decode_on_device(h, blob, 0, True)
