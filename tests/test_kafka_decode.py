@@ -3,6 +3,7 @@ header index against record sets built by the independent encoder (expected outp
 and against a committed byte-level fixture.  GPU: the device decode and the end-to-end
 `kta_kafka_consume` against the oracle."""
 import ctypes as C
+import functools
 import json
 import os
 
@@ -236,6 +237,17 @@ def _decode_on_device(h, blob, partition, with_keys):
     return cols, st, bad.value
 
 
+@functools.lru_cache(maxsize=None)
+def _device_decode_case(seed, max_records):
+    """One record set (and the oracle's columns) per seed for all variants: seed 5's 360 MB take the Python encoder
+    half a minute."""
+    rng = np.random.default_rng(seed)
+    blob, expected, _ = random_record_set(rng, 300 if max_records < 1000 else 12, max_records=max_records,
+                                          big=(seed == 5))
+    want, _ = kafka_decode(blob, 3)
+    return blob, expected, want
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
@@ -243,10 +255,7 @@ def _decode_on_device(h, blob, partition, with_keys):
 def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, variant):
     """Every decode kernel (1 / 4 / 8 batches per wave through LDS windows, lane-per-batch); batches from one
     record up to thousands (many LDS windows), values/keys larger than a window with seed 5."""
-    rng = np.random.default_rng(seed)
-    blob, expected, _ = random_record_set(rng, 300 if max_records < 1000 else 12, max_records=max_records,
-                                          big=(seed == 5))
-    want, _ = kafka_decode(blob, 3)
+    blob, expected, want = _device_decode_case(seed, max_records)
     with kta.HipMetricHandler(8, now=NOW) as h:
         h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
         cols, st, bad = _decode_on_device(h, blob, 3, with_keys)
