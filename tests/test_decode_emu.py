@@ -100,13 +100,7 @@ def test_the_emulator_runs_lanes_in_the_order_asked_and_sees_a_missing_barrier(e
     assert b"different points" in emu.kta_emu_last_error()
 
 
-@functools.lru_cache(maxsize=None)
-def _random_case(seed, max_records):
-    """One record set per seed for all geometries (the Python encoder is most of a case's time)."""
-    rng = np.random.default_rng(seed)
-    blob, expected, _ = random_record_set(rng, 60 if max_records < 1000 else 6, max_records=max_records, big=(seed == 5))
-    want, _ = kafka_decode(blob, 3)
-    return blob, expected, want
+_random_case = R._random_case          # one record set per seed, shared with the host statement's tests
 
 
 @pytest.mark.parametrize("geometry", GEOMETRIES)
