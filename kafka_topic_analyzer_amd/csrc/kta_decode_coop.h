@@ -178,7 +178,7 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             uint32_t k = 0, cur = (uint32_t)(pos - wbase);
             uint64_t next = 0;
             if (rec::chain(w32, limit, want, s_start[g], k, cur)) {
-                // a length of five bytes or more in front of the chain — a record of 128 MiB, or a padded encoding:
+                // a length of three bytes or more in front of the chain — a record of 8 KiB or more, or a padded encoding:
                 // byte by byte, and the round ends behind this record
                 uint32_t off = cur;
                 long long len;

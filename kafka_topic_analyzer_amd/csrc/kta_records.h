@@ -47,6 +47,16 @@ KTA_REC_HD bool varint4(uint32_t w, uint32_t &nb, uint32_t &v)
     return stop != 0u;
 }
 
+// A varint of one or two bytes at the start of w — the length prefix of every record below 8 KiB: its length and
+// its (still zig-zag) value.  False when the second byte does not end it.
+KTA_REC_HD bool varint2(uint32_t w, uint32_t &nb, uint32_t &v)
+{
+    const uint32_t two = (w >> 7) & 1u;                     // the first byte goes on
+    nb = 1u + two;
+    v = (w & 0x7Fu) | ((w >> 1) & 0x3F80u & (0u - two));
+    return (w & 0x8080u) != 0x8080u;
+}
+
 // Zig-zag varlong at byte offset `off` of the window, byte by byte (any length, the window's edge): the cold path.
 KTA_REC_HD bool window_varlong(const uint8_t *win, uint32_t &off, uint32_t limit, long long &out)
 {
@@ -63,30 +73,33 @@ KTA_REC_HD bool window_varlong(const uint8_t *win, uint32_t &off, uint32_t limit
     return false;
 }
 
-// The leader's chain: from `cur`, follow the length prefixes while they are ordinary — one to four bytes, all four
-// bytes at `cur` inside the window — and publish the record starts; at most `want` records in all (k counts them).
+// The leader's chain: from `cur`, follow the length prefixes while they are ordinary — one or two bytes (a record below
+// 8 KiB; a longer one does not fit a window, so the round ends with it anyway), all four bytes at `cur` inside the
+// window — and publish the record starts; at most `want` records in all (k counts them).
 // Stops at the window's edge (fewer than four bytes left: the next window begins at `cur`), at `want`, or — returning
-// true — in front of a length of five bytes or more, which the caller takes the long way.  The chain does not judge
+// true — in front of a length of three bytes or more, which the caller takes the long way.  The chain does not judge
 // the lengths: a negative one or one that overruns the batch leaves garbage starts behind it, all of them inside
-// [0, 2^29), and the lane that parses the record reports it (parse_record and its caller), which condemns the batch.
+// [0, 2^15), and the lane that parses the record reports it (parse_record and its caller), which condemns the batch.
 // One step is an LDS round trip and some twenty operations on the leader's lane alone; it is what a batch costs in
 // serial time, so nothing that can wait for the parse is done here.
 KTA_REC_HD bool chain(const uint32_t *w32, uint32_t limit, uint32_t want, uint32_t *starts, uint32_t &k, uint32_t &cur)
 {
     if (limit < 4u) return false;
     const uint32_t last = limit - 4u;                // a step reads the four bytes at `cur`
-    bool ordinary = true, go = k < want && cur <= last;
+    constexpr uint32_t LONG = 0x80000000u;           // `cur` in front of a long one: beyond every `last`
+    bool go = (k < want) & (cur <= last);
     while (go) {                                     // one block, one branch: the leaders of a wave run it in step
         const uint32_t i = cur >> 2;
         uint32_t nb, v;
-        ordinary = varint4(bytes4(w32[i], w32[i + 1], cur), nb, v);
+        const bool ordinary = varint2(bytes4(w32[i], w32[i + 1], cur), nb, v);
         starts[k] = cur;                             // (k < want: inside the array; it stays only if k moves on)
         k += ordinary ? 1u : 0u;
-        cur += nb + (v >> 1);                        // < 2^11 + 4 + 2^27: no overflow, whatever the bytes
-        go = ordinary && k < want && cur <= last;
+        cur = ordinary ? cur + nb + (v >> 1) : LONG; // < 2^13 + 2 + 2^13: no overflow, whatever the bytes
+        go = (k < want) & (cur <= last);
     }
-    if (!ordinary) cur = starts[k];                  // back in front of the long one
-    return !ordinary;
+    if (cur != LONG) return false;
+    cur = starts[k];                                 // back in front of the long one
+    return true;
 }
 
 enum : uint32_t {
