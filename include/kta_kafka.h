@@ -187,8 +187,8 @@ uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 /* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and
  * their mean size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch
  * inflate kernels of all four codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
- * 5 = 8 batches per wave (1 KiB windows), 6 / 7 = 4 / 2 batches per wave with 8 KiB windows (7: what the automatic choice takes
- * for batches of 64 KiB and more), 8 = 4 batches per wave, 2 KiB windows, 16 records per round (the automatic choice for
+ * 5 = 8 batches per wave (1 KiB windows), 6 / 7 = 4 / 2 batches per wave with 8 KiB windows (7: what the automatic choice took
+ * for batches of 64 KiB and more while it was the measured one; now 14), 8 = 4 batches per wave, 2 KiB windows, 16 records per round (the automatic choice for
  * batches of 4 ... 64 KiB), 9 = 8 batches per wave with 2 KiB windows, 10 = 4 batches per wave with 3 KiB windows,
  * 11 / 12 = as 7 with 32 / 64 records per round (one / two parse rounds per window instead of four), 13 / 14 = as 7 / 12
  * with the next window's blocks in flight while a round chains and parses. */

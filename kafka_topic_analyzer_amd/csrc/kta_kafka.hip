@@ -9,7 +9,8 @@
 //                                                                then the copies one wave per batch
 //           kafka_zstd_inflate_coop                              zstd one wave per batch (uniform parsing, LDS tables,
 //                                                                64-byte copy steps, Huffman streams on four lanes)
-//           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows
+//           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows (kta_decode_coop.h;
+//           kafka_decode_coop_pf<G, W, R>  the same with the next window's blocks in flight: large batches)
 //           kafka_decode / kafka_inflate_lane / kafka_gzip_inflate / kafka_zstd_inflate
 //                                                                one-lane-per-batch forms kept for comparison
 //                                                                (kta_kafka_set_variant 1)
@@ -62,7 +63,11 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
     // window holds 7 or 8 records of the 256-byte mean, so 16 records per round — one parse round of the 16 lanes — is
     // enough: 0.276 / 0.144 ms at 4 M / 2 M records where 32 per round took 0.282 / 0.157; <8, 2 KiB>, <4, 4 KiB, 32>
     // measured slower: the kernel is bound by instruction issue, 95 % of the SIMDs' cycles, profiles/r04_sq_decode.txt)
-    return mean < 4096 ? 5 : (mean < 65536 ? 8 : 7);
+    // Batches of 64 KiB and more since the end of round 4: the same <2, 8 KiB> geometry with 64 records per round (two
+    // parse rounds per window instead of four) and the next window's blocks in flight during chain and parse
+    // (kafka_decode_coop_pf) — chosen from the emulator's counts and the budget of a round, NOT yet from a
+    // timing: set_variant 7 is the measured one, tools/first_call.sh times 7 / 11 / 12 / 13 / 14 side by side.
+    return mean < 4096 ? 5 : (mean < 65536 ? 8 : 14);
 }
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>
