@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the N > 1 path: the partition->rank map and the exchange step
+"""world_size-2 ... 8 gloo tests (CPU) of the N > 1 path: the partition->rank map and the exchange step
 (one all-reduce SUM over the counter prefix + one all-reduce MAX over the four extrema) reproduce the
 unsharded result; the alive-table MAX merge reproduces sequential last-writer-wins.  Shard-local
 results are produced by the oracle here (no GPU); the reduction code is the product's."""
@@ -92,13 +92,15 @@ def _worker(rank, world, port, P, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P,seed", [(8, 1), (5, 2)])
-def test_two_rank_exchange_equals_unsharded(P, seed):
+@pytest.mark.parametrize("world,P,seed", [(2, 8, 1), (2, 5, 2), (8, 256, 3), (8, 5, 4)])
+def test_exchange_equals_unsharded(world, P, seed):
+    """Two ranks, and the target machine's eight: config 4's 256 partitions (32 per rank, p % 8) and a topic with
+    fewer partitions than ranks (three ranks own nothing and still end with the job's result)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, P, seed, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
@@ -207,7 +209,7 @@ def _route_worker(rank, world, port, q):
     try:
         # every rank's "table": slots all over the 32-bit range, values ((seq+1)<<1)|alive with global seq
         rng = np.random.default_rng(100 + rank)
-        n = [4000, 0, 2500][rank]
+        n = [4000, 0, 2500, 1200, 0, 3100, 700, 1][rank]                  # (ranks with nothing to send take part all the same)
         pool = np.unique(np.concatenate([np.random.default_rng(7).integers(0, 1 << 32, 6000, dtype=np.uint64),
                                          np.array([0, (1 << 32) - 1, 1431655765, 1431655766, 2863311530, 2863311531],
                                                   np.uint64)]))   # shared by the ranks: slots collide across shards
@@ -232,14 +234,16 @@ def _route_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_hash_range_exchange_counts_the_merged_alive_set_three_ranks():
+@pytest.mark.parametrize("world", [3, 8])
+def test_hash_range_exchange_counts_the_merged_alive_set(world):
     """SURVEY section 8(e) option ii: entries travel to the owner of their hash range (all-to-all), the owner
-    merges by MAX and counts; the sum equals the alive count of the element-wise MAX of all tables."""
+    merges by MAX and counts; the sum equals the alive count of the element-wise MAX of all tables.  Three ranks, and
+    the target machine's eight."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_route_worker, args=(r, 3, port, q)) for r in range(3)]
+    procs = [ctx.Process(target=_route_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in procs]
@@ -251,7 +255,7 @@ def test_hash_range_exchange_counts_the_merged_alive_set_three_ranks():
         for sl, v in zip(slots, vals):
             merged[sl] = max(merged.get(sl, 0), v)
     want = sum(v & 1 for v in merged.values())
-    assert [o[3] for o in outs] == [want] * 3
+    assert [o[3] for o in outs] == [want] * world
     assert sum(o[4] for o in outs) == sum(len(o[1]) for o in outs)   # every entry went to exactly one owner
     for w in (1, 2, 3, 7, 8):                                         # ranges tile [0, 2^32) exactly
         rs = [D.hash_range(r, w) for r in range(w)]
