@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB
 BYTES_PER_RECORD = 20        # partition i32 + key_len i32 + val_len i32 + ts_ms i64
 
 
-TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r04.sh, " \
+TRAFFIC_SOURCE = "profiles/traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, " \
                  "not measured in this run; null when the kernel's source file changed since those passes)"
 
 
@@ -153,7 +153,7 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras
     # ---- both handlers over the same resident batch: the product's actual -c step (/root/reference/src/kafka.rs:107-109
     # calls every handler for every message) — reset-free, like a topic that keeps growing.  Twice: as the library runs it
     # (ONE pass: the partition kernel of the alive-key pass also does the metrics handler's work) and, in a second context
-    # created with KTA_NO_FUSE=1, as two passes (scan + fold, then the alive-key pass).
+    # with kta_set_fuse(ctx, 0), as two passes (scan + fold, then the alive-key pass).
     def both(hh):
         for k in range(warmup):
             hh.submit_device(b, n_records, 0, which=3)
@@ -171,11 +171,8 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras
     wall3, avg3, cnt3 = both(h)
     two = None
     if extras:
-        os.environ["KTA_NO_FUSE"] = "1"
-        try:
-            h2 = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
-        finally:
-            del os.environ["KTA_NO_FUSE"]
+        h2 = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
+        h2.set_fuse(False)
         wall2, avg2, cnt2 = both(h2)
         r1, c1 = h.finish()
         r2, c2 = h2.finish()
@@ -201,7 +198,7 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras
                                  "metrics handler's sums) + fold + apply"},
             "two_passes": None if two is None else dict(
                 two, frac=algo3 / (two["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                note="KTA_NO_FUSE=1: kta_metrics_scan + kta_fold_partials, then the alive-key pass (48 B per record touched: "
+                note="kta_set_fuse(ctx, 0): kta_metrics_scan + kta_fold_partials, then the alive-key pass (48 B per record touched: "
                      "key_len and val_len twice)")}
     m = min(n_records, 1 << 24)
     cols = h.download_batch(b, m, m * 16)

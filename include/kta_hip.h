@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 4   /* 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
+#define KTA_ABI_VERSION 5   /* 5: kta_set_fuse, kta_alive_pass_info; 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
 
 /* status codes */
 #define KTA_OK 0
@@ -211,8 +211,8 @@ int kta_submit_device(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records, u
 /* Run only one of the two handlers over a device batch (profiling / benchmarks):
  * which = 1 MessageMetrics, 2 LogCompactionInMemoryMetrics, 3 both.  With both, -c, the bit set state and at most 256
  * partitions the batch is read ONCE: the first kernel of the alive-key pass also does the metrics handler's work
- * (src/kafka.rs:107-109 hands every message to every handler; same results bit for bit, environment KTA_NO_FUSE=1
- * at kta_create keeps the two passes).  kta_batch_submit and kta_handle_message submit with which = 3. */
+ * (src/kafka.rs:107-109 hands every message to every handler; same results bit for bit; kta_set_fuse(ctx, 0)
+ * keeps the two passes).  kta_batch_submit and kta_handle_message submit with which = 3. */
 int kta_submit_device_ex(kta_ctx *ctx, const kta_batch *cols, uint64_t n_records,
                          uint64_t base_seq, int which);
 int kta_device_batch_alloc(kta_ctx *ctx, uint64_t capacity, uint64_t key_bytes_capacity,
@@ -359,6 +359,19 @@ int kta_kernel_time_stats(kta_ctx *ctx, float avg_ms[3], uint64_t launches[3]);
  * keys were mostly unique; 13 / 14 the partitioned pass for every batch (tests); 8 / 9 ablation halves. */
 int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int alive_workgroups,
                    int alive_variant);
+/* Both handlers of a batch (kafka.rs:107-109: every handler for every message) as ONE pass over it where that is
+ * possible (bit set state, at most 256 partitions, no analytics): on by default; 0 = always two passes (scan, then
+ * the alive-key pass).  Results are bit-identical either way.  The environment variable KTA_NO_FUSE=1, read by
+ * kta_create, only sets the initial value.  In the fused pass all kernel time is booked on timer kind 2 (the
+ * alive-key update) and kinds 0 / 1 see only the fold: kta_kernel_time_stats returns launches[0] == 0 there. */
+int kta_set_fuse(kta_ctx *ctx, int enable);
+/* What the partitioned alive-key pass did since kta_create / kta_reset — host-side counters, nothing is waited for:
+ * out[0] the slice size in force for the bit set state (batches larger than it are applied slice by slice; it drops
+ * from 2^28 to 2^26 records after a batch that handed buckets to the fallback kernel), out[1] slices launched,
+ * out[2] of them with both handlers in the one pass, out[3] of them whose metrics handler ran as a scan although
+ * the batch began fused, out[4] buckets handed to the fallback kernel as far as sampled (the last slice of each
+ * batch of >= 2^27 records, read when the NEXT batch or this call finds the copy complete), out[5] the fuse switch. */
+int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

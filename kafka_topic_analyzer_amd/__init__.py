@@ -385,6 +385,17 @@ class HipMetricHandler:
                                              alive_variant))
 
     # views with the reference's accessor names
+    def set_fuse(self, on: bool) -> None:
+        """Both handlers of a batch in one pass where possible (default) or always as two passes; same results."""
+        self._check(self._lib.kta_set_fuse(self._ctx, 1 if on else 0))
+
+    def alive_pass_info(self) -> dict:
+        """Host-side counters of the partitioned alive-key pass since create / reset (kta_alive_pass_info)."""
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.kta_alive_pass_info(self._ctx, C.byref(out)))
+        return {"slice": int(out[0]), "slices": int(out[1]), "fused": int(out[2]), "scanned": int(out[3]),
+                "failed_buckets": int(out[4]), "fuse": bool(out[5])}
+
     def metrics(self) -> "MessageMetrics":
         res, counters = self.finish()
         return MessageMetrics(res, counters, self.now)

@@ -145,6 +145,8 @@ SIGNATURES = {
     "kta_set_timing": (C.c_int, [_P, C.c_int]),
     "kta_kernel_time_stats": (C.c_int, [_P, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint64 * 3)]),
     "kta_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kta_set_fuse": (C.c_int, [_P, C.c_int]),
+    "kta_alive_pass_info": (C.c_int, [_P, C.POINTER(C.c_uint64 * 6)]),
     "kta_synth_fill_host": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.POINTER(KtaBatch),
                                       C.POINTER(C.c_uint64)]),
     "kta_synth_fill_device": (C.c_int, [_P, C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64,
@@ -182,7 +184,7 @@ SIGNATURES = {
 _lib = None
 
 
-KTA_ABI_VERSION = 4  # include/kta_hip.h
+KTA_ABI_VERSION = 5  # include/kta_hip.h
 
 
 def load() -> C.CDLL:

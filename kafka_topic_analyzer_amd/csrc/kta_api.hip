@@ -89,6 +89,10 @@ struct kta_ctx {
     bool fuse_handlers = true;      // both handlers of a batch in one pass where that is possible (KTA_NO_FUSE=1: never)
     bool alive_failed_pending = false;
     int alive_backoff = 0;
+    // what the partitioned pass did since kta_create / kta_reset (kta_alive_pass_info): slices launched, of them with both
+    // handlers in the one pass, of them with the metrics handler through the scan although the batch began fused, and the
+    // buckets the sampled slices handed to kta_alive_fallback (the word of a batch's LAST slice, read one batch late)
+    uint64_t info_slices = 0, info_fused = 0, info_scanned = 0, info_failed_buckets = 0;
     std::vector<Stage> stages;
     uint64_t batch_capacity = 0, key_bytes_capacity = 0;
     int cur = 0;
@@ -309,6 +313,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             // batches that follow are applied in slices of 2^26 records: 16 segments of a bucket then hold 4 k pairs.
             if (!ctx->alive_table && ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
                 ctx->alive_failed_pending = false;
+                ctx->info_failed_buckets += ctx->h_alive_stats[2];
                 if (ctx->h_alive_stats[2] != 0 && ctx->alive_slice > (1ull << 26)) ctx->alive_slice = 1ull << 26;
             }
             uint64_t first_take = 0;
@@ -341,7 +346,9 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,
                                    ctx->d_alive_running, written_list(ctx)};
                 kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from};
+                ctx->info_slices++;
                 if (fuse && kta::alive_fuse_possible(pl, ctx->P) && pl.segment_wgs <= ctx->max_rows) {
+                    ctx->info_fused++;
                     const uint32_t row_len = kta::scan_row_len(ctx->P, false);
                     const kta::AliveFuse fz{c->partition + at, c->ts_ms + at, ctx->P, ctx->d_partials, row_len};
                     KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws, nullptr, ctx->s_compute, &fz));
@@ -349,6 +356,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                                                            ctx->s_compute));
                 } else {
                     if (fuse) {      // (a slice the fused pass does not take: its records go through the scan)
+                        ctx->info_scanned++;
                         kta::ScanColumns sc{c->partition + at, c->key_len + at, c->val_len + at, c->ts_ms + at};
                         kta::ScanPlan spl = kta::plan_scan(ctx->P, take, ctx->cu_count, ctx->scan_wgs, ctx->scan_variant, ctx->analytics);
                         if (spl.workgroups > ctx->max_rows) spl.workgroups = ctx->max_rows;
@@ -404,6 +412,13 @@ int reset_state(kta_ctx *ctx)
         }
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
         ctx->running_valid = true;
+        // a new topic: what the old one's batches taught about slicing and backing off does not carry over (a word still
+        // on its way lands in h_alive_stats before any later copy — same stream — and is never looked at)
+        ctx->alive_slice = kta::kAlivePartitionMax;
+        ctx->alive_failed_pending = false;
+        ctx->alive_stats_pending = false;
+        ctx->alive_backoff = 0;
+        ctx->info_slices = ctx->info_fused = ctx->info_scanned = ctx->info_failed_buckets = 0;
     }
     ctx->next_seq = 0;
     return KTA_OK;
@@ -1090,6 +1105,31 @@ int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int aliv
     ctx->scan_variant = scan_variant;
     ctx->alive_wgs = alive_workgroups;
     ctx->alive_variant = alive_variant;
+    return KTA_OK;
+}
+
+int kta_set_fuse(kta_ctx *ctx, int enable)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    ctx->fuse_handlers = enable != 0;
+    return KTA_OK;
+}
+
+int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6])
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    // the word of the last batch that was sampled, if it has arrived (never waited for)
+    if (ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
+        ctx->alive_failed_pending = false;
+        ctx->info_failed_buckets += ctx->h_alive_stats[2];
+        if (ctx->h_alive_stats[2] != 0 && ctx->alive_slice > (1ull << 26)) ctx->alive_slice = 1ull << 26;
+    }
+    out[0] = ctx->alive_slice;
+    out[1] = ctx->info_slices;
+    out[2] = ctx->info_fused;
+    out[3] = ctx->info_scanned;
+    out[4] = ctx->info_failed_buckets;
+    out[5] = ctx->fuse_handlers ? 1 : 0;
     return KTA_OK;
 }
 

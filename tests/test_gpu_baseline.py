@@ -165,6 +165,77 @@ def test_baseline_config_3_alive_keys_2e30_records():
     o.close()
 
 
+
+_C5_ONE_GPU = {}
+
+
+def _c5_one_gpu_oracle(n):
+    """ONE oracle (both handlers) over the first n records of config 5's topic, in consumption order; kept for the
+    two parametrisations of the test below (the BitSet is order dependent: one instance, chunk after chunk)."""
+    if n in _C5_ONE_GPU:
+        return _C5_ONE_GPU[n]
+    from concurrent.futures import ThreadPoolExecutor
+    sp, _ = kta.synth_preset("c5")
+    P = int(sp.n_partitions)
+    o = Oracle(NOW, True)
+    chunks = [(lo, min(CHUNK * 4, n - lo)) for lo in range(0, n, CHUNK * 4)]
+    pool = ThreadPoolExecutor(6)
+    ahead = [pool.submit(kta.synth_fill_host, sp, lo, m, True) for lo, m in chunks[:8]]
+    for k in range(len(chunks)):
+        cols = ahead.pop(0).result()
+        if k + 8 < len(chunks):
+            ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 8][0], chunks[k + 8][1], True))
+        o.run_soa(cols)
+    pool.shutdown()
+    want = {"alive_keys": o.alive_keys(), "words": o.alive_words().copy(), "counters": o.counters(P).copy(),
+            "earliest": o.earliest(), "latest": o.latest(), "smallest": o.get("smallest_message"),
+            "largest": o.get("largest_message"), "overall_size": o.get("overall_size")}
+    o.close()
+    _C5_ONE_GPU[n] = want
+    return want
+
+
+@pytest.mark.parametrize("which", [2, 3])
+def test_sliced_bit_set_path_config_5_key_law_three_batches_vs_oracle(which):
+    """The path a single GPU takes on config 5's key law (100 M distinct 16-byte keys, 50 % tombstones) in the bit set
+    state: the first batch of 2^27 records hands buckets to kta_alive_fallback (more distinct slots per bucket than an
+    instalment of pass 2 holds), and every following batch is then applied in slices of 2^26 records
+    (kta_api.hip: alive_slice) — with which = 3 each slice either as the fused pass or as scan + alive pass.  Three
+    consecutive batches against ONE oracle fed in consumption order (/root/reference/src/metric.rs:288-305 is order
+    dependent, kafka.rs:107-109 runs both handlers per message): alive count, every bit of the set, and for
+    which = 3 the counters and extrema; the library's own counters say that the sliced path did run."""
+    sp, _ = kta.synth_preset("c5")
+    P, nb, batches = int(sp.n_partitions), 1 << 27, 3
+    want = _c5_one_gpu_oracle(nb * batches)
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+        b = h.device_batch_alloc(nb, nb * 16)
+        infos = []
+        for k in range(batches):
+            assert h.synth_fill_device(sp, k * nb, nb, b) == nb * 16
+            h.submit_device(b, nb, k * nb, which=which)
+            h.sync()                      # (the word of the batch's last slice has arrived: the next batch sees it)
+            infos.append(h.alive_pass_info())
+        res, c = h.finish()
+        # batch 1 whole (one slice), handed buckets over; batches 2 and 3 in two slices of 2^26 each
+        assert infos[0]["slices"] == 1 and infos[0]["failed_buckets"] > 0 and infos[0]["slice"] == 1 << 26, infos
+        assert infos[1]["slices"] == 3 and infos[2]["slices"] == 5, infos
+        if which == 3:
+            assert infos[2]["fused"] + infos[2]["scanned"] == 5, infos
+        else:
+            assert infos[2]["fused"] == 0 and infos[2]["scanned"] == 0, infos
+        assert res.alive_keys == want["alive_keys"] and 0 < res.alive_keys
+        assert np.array_equal(h.export_alive_bitmap(), want["words"])
+        if which == 3:
+            assert np.array_equal(c, want["counters"]) and res.overall_count == nb * batches
+            mm = kta.MessageMetrics(res, c, NOW)
+            assert mm.earliest_message() == want["earliest"] and mm.latest_message() == want["latest"]
+            assert mm.smallest_message() == want["smallest"] and mm.largest_message() == want["largest"]
+            assert mm.overall_size() == want["overall_size"]
+        # a reset context starts over: whole batches again (ADVICE r4: the slice size used to stay small for ever)
+        h.reset()
+        assert h.alive_pass_info()["slice"] > 1 << 26 and h.alive_pass_info()["slices"] == 0
+        h.device_batch_free(b)
+
 _C5_WORKER = r'''
 import os, sys, threading
 root, log2n = sys.argv[1], int(sys.argv[2])

@@ -439,7 +439,7 @@ def test_both_handlers_in_one_pass_vs_oracle(P, n, runs):
 
 
 def test_both_handlers_in_one_pass_equals_two_passes_with_bad_partition_ids():
-    """The fused pass and the two passes (KTA_NO_FUSE=1) leave the same vector, bit for bit, also for what the reference
+    """The fused pass and the two passes (kta_set_fuse(ctx, 0)) leave the same vector, bit for bit, also for what the reference
     has no word for: partition ids outside [0, P) (counted and reported, never accumulated) — while the alive set, which
     ignores the partition (metric.rs:289-304), takes those records' keys either way."""
     P, n = 64, 1_200_007
@@ -449,12 +449,9 @@ def test_both_handlers_in_one_pass_equals_two_passes_with_bad_partition_ids():
     cols["partition"][5::7777] = -3
     cols["partition"][11::9001] = 2**31 - 1
     got = []
-    for no_fuse in ("0", "1"):
-        os.environ["KTA_NO_FUSE"] = no_fuse
-        try:
-            h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
-        finally:
-            del os.environ["KTA_NO_FUSE"]
+    for fuse in (True, False):
+        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+        h.set_fuse(fuse)
         b, nb = h.upload_batch(cols, with_keys=True)
         h.submit_device(b, nb, 0, which=3)
         h.device_batch_free(b)

@@ -1,18 +1,18 @@
 #!/bin/bash
 # First GPU call of a round whose tree holds a decode kernel the builder has not run on the GPU yet:
-# its parity gate, its timing per batch size and geometry, then the round's evidence (tools/profile_r04.sh writes
-# gpurun_out/prof_r04; copy the summaries to profiles/rNN_* and rerun tools/make_traffic.py on the SAME tree).
+# its parity gate, its timing per batch size and geometry, then the round's evidence (tools/profile_round.sh writes
+# gpurun_out/prof_rNN; copy the summaries to profiles/rNN_* and rerun tools/make_traffic.py on the SAME tree).
 #   gpurun --timeout 2400 -- bash tools/first_call.sh
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/first_call
 mkdir -p $OUT
 cd $ROOT
-timeout 900 python -m pytest tests/test_kafka_decode.py -x -q -m gpu > $OUT/pytest_decode.txt 2>&1
+[ -n "$SKIP_PYTEST" ] || timeout 900 python -m pytest tests/test_kafka_decode.py -x -q -m gpu > $OUT/pytest_decode.txt 2>&1
 tail -3 $OUT/pytest_decode.txt
 # automatic choice (0) and the geometries around it: 5 = <8, 1 KiB, 16>, 8 = <4, 2 KiB, 16>, 9 = <8, 2 KiB, 16>,
 # 10 = <4, 3 KiB, 16>, 7 = <2, 8 KiB, 128>, 11 / 12 = <2, 8 KiB, 32 / 64>, 13 / 14 = <2, 8 KiB, 128 / 64> prefetching, 6 = <4, 8 KiB, 128>, 2 = <1, 8 KiB, 256>
 timeout 600 python tools/bench_decode.py --rpb 8,60,500 --variants 0,5,8,9,10,7,11,12,13,14,6,2 > $OUT/bench_decode.txt 2>&1
 tail -30 $OUT/bench_decode.txt
-bash tools/profile_r04.sh > $OUT/profile.log 2>&1
+bash tools/profile_round.sh r05 > $OUT/profile.log 2>&1
 tail -5 $OUT/profile.log

@@ -1,10 +1,10 @@
-"""profiles/traffic.json from the PMC summary of tools/profile_r04.sh (profiles/rNN_pmc_hbm.txt): HBM bytes per
+"""profiles/traffic.json from the PMC summary of tools/profile_round.sh (profiles/rNN_pmc_hbm.txt): HBM bytes per
 launch of the kernels bench.py reports a roofline for.  bench.py replays this file (roofline.traffic); it
 does not measure traffic itself.  Every entry records the kernel's source file and its sha256 (first 16 hex
 digits) AS THE FILE LIES IN THE TREE WHEN THIS SCRIPT RUNS — run it on the tree the passes were taken with;
 bench.py returns "traffic": null for a kernel whose file has changed since.
 
-    python tools/make_traffic.py profiles/r04_pmc_hbm.txt > profiles/traffic.json
+    python tools/make_traffic.py profiles/r05_pmc_hbm.txt > profiles/traffic.json
 
 Counters are KiB per launch.  FETCH_SIZE under-reports wide coalesced streaming reads by a factor of two on
 gfx950 (MI355X_MICROARCH.md, HBM section), so the streaming part of a kernel's reads is doubled:
@@ -50,9 +50,9 @@ def find(sub, counter, largest_grid=False):
 
 
 KIB = 1024.0
-out = {"round": 4, "source": path,
+out = {"round": 5, "source": path,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 5 --warmup 1 "
-                 "--preroll 5 --no-cpu-baseline` (tools/profile_r04.sh; --no-alive-extras: every kernel at one launch size), turned into this file by tools/make_traffic.py; counters "
+                 "--preroll 5 --no-cpu-baseline` (tools/profile_round.sh; --no-alive-extras: every kernel at one launch size), turned into this file by tools/make_traffic.py; counters "
                  "are KiB per launch (average over the launches of the kernel unless stated).  FETCH_SIZE is doubled for wide "
                  "coalesced streaming reads per the gfx950 correction (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  "
                  "bench.py replays these numbers (roofline.traffic, traffic_source), it does not measure them."}

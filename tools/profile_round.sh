@@ -1,12 +1,13 @@
 #!/bin/bash
 # (the counter passes run with --no-alive-extras: every kernel at ONE launch size, so a row's average is that launch)
-# Round-4 profile recipe (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
+# Per-round profile recipe (tools/profile_round.sh rNN) (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
 # command, and the HBM traffic counters in their own passes.  tools/make_traffic.py turns pmc.txt into
 # profiles/traffic.json; the text summaries are copied to profiles/ by hand.
+TAG=${1:-r05}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r04
-RAW=/tmp/prof_r04
+OUT=$ROOT/gpurun_out/prof_${TAG}
+RAW=/tmp/prof_${TAG}
 mkdir -p $OUT $RAW
 cd $ROOT
 timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
