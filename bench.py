@@ -75,6 +75,21 @@ def _traffic(kernels, records_per_launch):
         return None
 
 
+def _alive_checked(got, preset, distinct, n_upto):
+    """The alive-key count a `-c` leg reports, held against the C oracle's count for the same records
+    (tests/golden/bench_alive_counts.json, made on the CPU by tests/golden/make_bench_alive_counts.py from the generator's
+    records in consumption order).  A leg whose shape is not in the file says so; a count that differs ends the run: a
+    bench that times a wrong result times nothing."""
+    key = f"{preset}:{distinct}:0:{n_upto}"
+    try:
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_alive_counts.json")))["alive_keys"].get(key)
+    except Exception:
+        want = None
+    if want is not None and int(got) != int(want):
+        raise AssertionError(f"alive keys of {key}: the GPU says {int(got)}, the oracle {int(want)}")
+    return {"alive_keys": int(got), "alive_keys_checked": want is not None}
+
+
 def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
     """Time the C oracle (1 thread) over the first n_sample records of the resident batch."""
     from oracle_c import Oracle
@@ -138,7 +153,7 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras
     algo_bytes = (4 + 4 + 4) * n_records + kb
     out = {"workload": f"c3 shape: 64 partitions, {n_records} records, 16 B keys, 10M distinct, 10% tombstones",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
-           "alive_keys": int(res.alive_keys),
+           **_alive_checked(res.alive_keys, "c3", 0, n_records),
            "roofline": {"bound": "hbm", "kernel": "kta_alive_partition32 + kta_alive_apply",
                         "achieved": algo_bytes / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -251,7 +266,7 @@ def alive_table_report(kta, device, steps, n_records):
     rep = {"workload": f"c3 law, table state, seq column: {steps} consecutive batches of {n_records} records, 16 B keys, 10M distinct, "
                        "10% tombstones (the partitioned pass: kta_alive_partition + kta_alive_apply<table>)",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
-           "alive_keys": int(res.alive_keys),
+           **_alive_checked(res.alive_keys, "c3", 0, n_records * (steps + 1)),
            "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply (table state)",
                         "achieved": algo / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo,
@@ -289,7 +304,7 @@ def alive_hot_key_report(kta, device, n_records):
         h.set_timing(False)
         res, _ = h.finish()
         rows.append({"distinct_keys": distinct, "records": n_records, "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                     "records_per_s": n_records / (avg_ms[2] * 1e-3), "alive_keys": int(res.alive_keys)})
+                     "records_per_s": n_records / (avg_ms[2] * 1e-3), **_alive_checked(res.alive_keys, "c3", distinct, n_records)})
         h.device_batch_free(b)
         h.close()
     # mostly unique keys (config 5's law: 100 M distinct, 50 % tombstones) on ONE GPU in the bit set state: a bucket holds
@@ -311,7 +326,7 @@ def alive_hot_key_report(kta, device, n_records):
     h.device_batch_free(b)
     h.close()
     unique = {"workload": f"c5 law (100 M distinct 16 B keys, 50 % tombstones), bit set state, {n5} records per batch, 4 batches",
-              "kernel_ms_per_batch": per_launch, "records_per_s_last": n5 / (per_launch[-1] * 1e-3), "alive_keys": int(res.alive_keys),
+              "kernel_ms_per_batch": per_launch, "records_per_s_last": n5 / (per_launch[-1] * 1e-3), **_alive_checked(res.alive_keys, "c5", 0, n5),
               "note": "batch 1 is applied whole (buckets that fit neither the LDS table nor an instalment go to the fallback "
                       "kernel: exact, slow); the count of such buckets comes back with the stream and the following batches are "
                       "applied in slices of 2^26 records"}

@@ -184,14 +184,13 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n);
 /* CRC-32C of host bytes (the same tables the device uses; check value of "123456789": 0xE3069283). */
 uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 
-/* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and
- * their mean size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch
- * inflate kernels of all four codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch (8 KiB LDS windows), 3 / 4 = 4 batches per wave (4 / 2 KiB windows),
- * 5 = 8 batches per wave (1 KiB windows), 6 / 7 = 4 / 2 batches per wave with 8 KiB windows (7: what the automatic choice took
- * for batches of 64 KiB and more while it was the measured one; now 14), 8 = 4 batches per wave, 2 KiB windows, 16 records per round (the automatic choice for
- * batches of 4 ... 64 KiB), 9 = 8 batches per wave with 2 KiB windows, 10 = 4 batches per wave with 3 KiB windows,
- * 11 / 12 = as 7 with 32 / 64 records per round (one / two parse rounds per window instead of four), 13 / 14 = as 7 / 12
- * with the next window's blocks in flight while a round chains and parses. */
+/* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and their mean
+ * size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch inflate kernels of all four
+ * codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch with 8 KiB LDS windows (calls with
+ * fewer than 2048 batches), 10 = four batches per wave, 3 KiB windows, 16 records per round (batches below 8 KiB),
+ * 11 = two batches per wave, 8 KiB windows, 32 records per round (batches of 8 KiB and more).  Any other value:
+ * KTA_ERR_INVALID (3 ... 9 and 12 ... 14 were geometries that lost the side-by-side timing of round 5 and were deleted:
+ * profiles/r05_decode_geometries.jsonl). */
 int kta_kafka_set_variant(kta_ctx *ctx, int variant);
 
 /* Average duration (ms) of the decode kernel since the previous call ([1]; [0] is reserved, -1);

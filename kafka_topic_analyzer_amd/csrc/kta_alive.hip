@@ -223,13 +223,7 @@ __device__ __forceinline__ uint32_t lds_add(uint32_t *p, uint32_t v)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kPartThreads = 1024;                 // one workgroup per CU: the rings take most of the LDS
 constexpr int kPartWaves = kPartThreads / 64;
-#ifndef KTA_PART_CONSUMERS
-#define KTA_PART_CONSUMERS 4
-#endif
-#ifndef KTA_DBG_LEVEL
-#define KTA_DBG_LEVEL 0                            // ablation levels of tools/ubench_alive.hip; the library is built with 0
-#endif
-constexpr int kConsumers = KTA_PART_CONSUMERS;     // waves that move completed blocks from the rings to memory (one per SIMD)
+constexpr int kConsumers = 4;                      // waves that move completed blocks from the rings to memory (one per SIMD)
 constexpr int kProducers = kPartWaves - kConsumers; // waves that stream, hash and insert
 constexpr uint32_t kTile = 256;                    // records of one wave step: four consecutive records per lane
 constexpr uint32_t kRing = 16;                     // pairs per bucket ring: two 64-byte blocks
@@ -374,9 +368,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             if (lane == 0) g = lds_add(&s_misc[1], 1u);
             return (uint64_t)__builtin_amdgcn_readfirstlane(g);
         };
-#if KTA_DBG_LEVEL
-        long long dummy = 0;
-#endif
         uint64_t t_a = grab(), t_b = grab();              // walk indices of the tiles in the two register sets
         if (t_a < span) {
             TileCols cols_a, cols_b;
@@ -417,26 +408,14 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                 load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
                 t = t_new;
                 load_cols<SEQ>(c, n, skip, at(t < span ? t : 0u), t < span, r);   // r is spent: hashed
-#if KTA_DBG_LEVEL == 1   /* ablation builds of tools/ubench_alive.hip only.  1: stream + hash, nothing else */
-                dummy += (long long)(h[0] ^ h[1] ^ h[2] ^ h[3]) + (long long)pr[0];
-                return;
-#endif
                 // Straight-line, so that a lane's four LDS atomics and its four reads are in flight together.
                 uint32_t bk[4], p[4], out[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) bk[j] = h[j] >> (32 - BLOG2);
 #pragma unroll
                 for (int j = 0; j < 4; j++) p[j] = keyed[j] ? lds_add(&s_ctl[bk[j]].x, 1u) : 0u;
-#if KTA_DBG_LEVEL == 2   /* 2: + the position atomics */
-                dummy += (long long)(p[0] + p[1] + p[2] + p[3]) + (long long)pr[0] + (long long)pr[1] + (long long)pr[2] + (long long)pr[3];
-                return;
-#endif
 #pragma unroll
                 for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if KTA_DBG_LEVEL == 3   /* 3: + the reads of `out` and the ring writes, never waiting; no consumers */
-#pragma unroll
-                for (int j = 0; j < 4; j++) out[j] = p[j] - (out[j] & 7u);
-#endif
                 KTA_LDS_ORDER();
                 uint32_t pending = 0;
 #pragma unroll
@@ -473,9 +452,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
             }
             if (SEQ && __any(disorder) && lane == 0) atomicOr(order_flag, 1u);
         }
-#if KTA_DBG_LEVEL
-        if (dummy == 0x1234567) counts[0] = 1;
-#endif
         KTA_LDS_ORDER();
         if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
     } else {
@@ -484,9 +460,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
         const uint32_t cw = wave - (uint32_t)kProducers;
         uint32_t *list = s_list + cw * 64u;
         for (;;) {
-#if KTA_DBG_LEVEL >= 1 && KTA_DBG_LEVEL <= 3
-            break;
-#endif
             const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
             KTA_LDS_ORDER();
             bool any_ready = false;                                               // wave-uniform
@@ -526,9 +499,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
                             }
                             dst = pool + __shfl(at_pool, (int)(lane & ~3u));
                         }
-#if KTA_DBG_LEVEL == 4   /* 4: the whole protocol, but the blocks are not stored */
-                        if (d.x == 0x1234567ull)
-#endif
                         *reinterpret_cast<v2ull *>(dst + piece * 2u) = (v2ull){d.x, d.y};
                         *src = make_ulonglong2(0ull, 0ull);
                         KTA_LDS_ORDER();
@@ -595,19 +565,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 // The stream is read once: non-temporal loads (measured against plain ones: the same time, within the noise).
 #define KTA_P32_LOAD(p) __builtin_nontemporal_load(p)
 typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));   // 16 key bytes at any address (unaligned access mode)
-#ifndef KTA_P32_BLOCK
-#define KTA_P32_BLOCK 16
-#endif
-constexpr uint32_t kBlk32 = KTA_P32_BLOCK;         // pairs of a block: what leaves the ring in one piece (64 bytes)
+constexpr uint32_t kBlk32 = 16;                    // pairs of a block: what leaves the ring in one piece (64 bytes)
 constexpr uint32_t kRing32 = 2 * kBlk32;           // pairs per bucket ring: two blocks
 constexpr uint32_t kBlkLanes = kBlk32 / 4;         // lanes that move a block (16 bytes each)
 constexpr uint32_t kBlkPerTrip = 64 / kBlkLanes;   // blocks a consumer wave moves at a time
 // (the block stores as non-temporal or write-through stores measured the same as plain ones: ± 0.03 ms of 1.9)
-#define KTA_P32_STORE(ptr, val) (*(ptr) = (val))
-#ifndef KTA_P32_GUARD
-#define KTA_P32_GUARD 1024
-#endif
-constexpr uint32_t kGuard = KTA_P32_GUARD;           // guard bytes (the lane that wrote last) per producer wave
+constexpr uint32_t kGuard = 1024;                  // guard bytes (the lane that wrote last) per producer wave
 constexpr uint32_t kPair32Shift = 10;
 
 __device__ __forceinline__ uint32_t ring32_at(uint32_t b, uint32_t p)   // (rows rotated by whole 16-byte pieces)
@@ -648,9 +611,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
 {
     constexpr uint32_t B = 1u << BLOG2;
     constexpr uint32_t RBITS = 32 - BLOG2;
-#ifndef KTA_P32_EXP_BLOG2
     static_assert(RBITS == 32 - kPair32Shift, "a pair32 holds the hash bits below the bucket");
-#endif
     static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
     extern __shared__ __attribute__((aligned(128))) uint32_t s_ring32[];           // B x kRing32 pairs
     uint32_t *s_pos = s_ring32 + (size_t)B * kRing32;                              // positions handed out
@@ -701,15 +662,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 const uint64_t i = tile * kTile + 64u * j + lane;
                 const bool in = ok && i < n;
                 const uint64_t ic = in ? i : n - 1;
-#if KTA_DBG_LEVEL == 5   /* 5: nothing is read — made-up records, everything else as it is */
-                r.kl[j] = 16;
-                r.vl[j] = (int32_t)(ic & 7u) - 1;
-                r.ko[j] = (uint32_t)ic;
-#else
                 r.kl[j] = KTA_P32_LOAD(c.key_len + ic);
                 r.vl[j] = KTA_P32_LOAD(c.val_len + ic);
                 r.ko[j] = KTA_P32_LOAD(c.key_off + ic);
-#endif
                 r.kl[j] = in ? r.kl[j] : -1;               // key None: ignored (metric.rs:302)
                 if (FUSE) {
                     r.pt[j] = KTA_P32_LOAD(fz.partition + ic);
@@ -722,12 +677,8 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         auto load_keys32 = [&](const Cols &r, uint4 (&k)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-#if KTA_DBG_LEVEL == 5
-                k[j] = make_uint4(r.ko[j] * 0x9E3779B9u, r.ko[j] * 0x85EBCA6Bu + 1u, r.ko[j] ^ 0x5bd1e995u, r.ko[j] * 0xC2B2AE35u);
-#else
                 const v4u_any kk = KTA_P32_LOAD(reinterpret_cast<const v4u_any *>(c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u)));
                 k[j] = make_uint4(kk.x, kk.y, kk.z, kk.w);
-#endif
             }
         };
         // The workgroup's range is cut into (at most 255) windows of consecutive tiles, and the waves take them as they
@@ -762,9 +713,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             tile = cur_tile;
             win = cur_win;
         };
-#if KTA_DBG_LEVEL
-        long long dummy = 0;
-#endif
         {
             Cols cols_a, cols_b;
             uint4 keys_a[4], keys_b[4];
@@ -821,10 +769,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     next_tile(tn, r.win);
                     load_cols32(tn, r.win != 0u, r);                 // r is spent: hashed
                 }
-#if KTA_DBG_LEVEL == 1   /* ablation builds of tools/ubench_alive.hip only.  1: stream + hash, nothing else */
-                dummy += (long long)(pr[0] ^ pr[1] ^ pr[2] ^ pr[3]);
-                return;
-#endif
                 // ---- the guard: among the records of one instruction, one record per hash (the newest) ----
                 uint32_t seen[4];
 #pragma unroll
@@ -848,10 +792,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     }
                     ins[j] = keyed[j] && !((drop >> lane) & 1ull);
                 }
-#if KTA_DBG_LEVEL == 2   /* 2: + the guard */
-                dummy += (long long)(pr[0] ^ pr[1] ^ pr[2] ^ pr[3]) + (ins[0] ? 1 : 0) + (ins[1] ? 2 : 0) + (ins[2] ? 4 : 0) + (ins[3] ? 8 : 0);
-                return;
-#endif
                 // ---- positions, then the pairs once their ring entries are free: straight-line, so that a lane's four
                 // LDS atomics and its four reads are in flight together ----
                 uint32_t bk[4], p[4], out[4];
@@ -891,9 +831,6 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 step(cols_b, keys_b, cols_a, keys_a);
             }
         }
-#if KTA_DBG_LEVEL
-        if (dummy == 0x1234567) counts[0] = 1;
-#endif
         KTA_LDS_ORDER();
         if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
     } else {
@@ -901,13 +838,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         constexpr uint32_t kChunks = B / (64u * kConsumers);
         const uint32_t cw = wave - (uint32_t)kProducers;
         uint32_t *list = s_list + cw * 64u;
-#ifdef KTA_P32_STORE_LOG
-        if (lane == 0) s_list[kConsumers * 64 + 4 + cw] = 0u;
-#endif
         for (;;) {
-#if KTA_DBG_LEVEL >= 1 && KTA_DBG_LEVEL <= 2
-            break;
-#endif
             const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
             KTA_LDS_ORDER();
             bool any_ready = false;                                               // wave-uniform
@@ -934,29 +865,8 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     const bool go = ((uint32_t)(vm >> (lane & ~(kBlkLanes - 1u))) & ((1u << kBlkLanes) - 1u)) == (1u << kBlkLanes) - 1u;   // all its pairs have arrived
                     if (go) {
                         if ((k + 1u) * kBlk32 <= cap) {
-#if KTA_DBG_LEVEL == 4   /* 4: the whole protocol, but the blocks are not stored */
-                            if (d.x == 0x1234567u)
-#endif
-                            {
-                                uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
-#ifdef KTA_P32_STORE_LOG       /* experiment: the blocks of a consumer wave one behind the other, in the order they leave */
-                                {
-                                    const unsigned long long gm = __builtin_amdgcn_ballot_w64(go && piece == 0u);
-                                    const uint32_t rank = (uint32_t)__popcll(gm & ((1ull << (lane & ~(kBlkLanes - 1u))) - 1ull));
-                                    const uint32_t cur = s_list[kConsumers * 64 + 4 + cw];      // (a word behind s_misc's two)
-                                    KTA_LDS_ORDER();
-                                    if (piece == 0u && rank == 0u) s_list[kConsumers * 64 + 4 + cw] = cur + (uint32_t)__popcll(gm);
-                                    at = ((uint64_t)(w * kConsumers + cw) * (B / kConsumers) * cap) + (uint64_t)(cur + rank) * kBlk32 + piece * 4u;
-                                }
-#endif
-#ifdef KTA_P32_STORE_WRAP      /* experiment: every block into the same 32 MB */
-                                at &= (8u << 20) - 1u;
-#endif
-#ifdef KTA_P32_STORE_HALF      /* experiment: every other block is not stored */
-                                if (!(k & 1u))
-#endif
-                                KTA_P32_STORE(reinterpret_cast<v4u *>(pairs + at), ((v4u){d.x, d.y, d.z, d.w}));
-                            }
+                            const uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
+                            *reinterpret_cast<v4u *>(pairs + at) = (v4u){d.x, d.y, d.z, d.w};
                         } else {                                                   // the segment is full: to the pool, with what a pair32 leaves implicit
                             unsigned long long at_pool = 0;
                             if (piece == 0u) {
@@ -1190,9 +1100,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
     static_assert(TAGBITS <= 15, "tags are 16 bit");
     constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
-#ifndef KTA_P32_EXP_BLOG2
     static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
-#endif
     // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
     // records that found their set full stay short up to about 0.75 load
     constexpr uint32_t kFlushAt = kEntries / 2 + kEntries / 4;
@@ -1667,6 +1575,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                         fail_from[b] = inst_start;
                         atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
                     }
+                    // (the instalments before this one ARE applied: what they changed belongs to the running count.  Round 5:
+                    // this path returned without it, and a bucket that gave up after its first instalment left sum_all_alive
+                    // short of the bit set — found by holding bench.py's c5 leg against the oracle)
+                    add_running(delta, running, sh.w);
                     return;
                 }
                 // (table state never fails in careful mode: its last resort is the direct path)
@@ -1890,11 +1802,6 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         KTA_UB_MARK(1);
-#ifdef KTA_DBG_PART_ONLY
-        KTA_UB_MARK(2);
-        KTA_UB_MARK(3);
-        return e;
-#endif
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
@@ -1942,9 +1849,6 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-#ifdef KTA_DBG_PART_ONLY
-    return e;
-#endif
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
@@ -1975,11 +1879,7 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
 {
     AlivePartitionPlan pl;
     pl.pair32 = pair32;
-#ifdef KTA_P32_EXP_BLOG2   /* experiment (partition kernel only): another number of buckets */
-    pl.bucket_log2 = pair32 ? KTA_P32_EXP_BLOG2 : 10u;
-#else
     pl.bucket_log2 = 10u;
-#endif
     pl.max_records = kAlivePartitionMax;
     if (n > pl.max_records) n = pl.max_records;
     if (n == 0) n = 1;
@@ -2008,9 +1908,6 @@ hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t 
                                     const AlivePartitionPlan &pl, const AliveWorkspace &ws, uint64_t *stats, hipStream_t s,
                                     const AliveFuse *fuse)
 {
-#ifdef KTA_P32_EXP_BLOG2
-    if (pl.pair32) return launch_pair<KTA_P32_EXP_BLOG2>(c, n, base_seq, st, pl, ws, stats, s, fuse);
-#endif
     return launch_pair<10>(c, n, base_seq, st, pl, ws, stats, s, fuse);
 }
 

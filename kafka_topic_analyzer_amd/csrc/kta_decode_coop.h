@@ -74,12 +74,7 @@ __device__ __forceinline__ void pin(uint4 &v)
 #ifndef KTA_WAVES_PER_EU   // (tests/native/wave_emu.h defines it away: a host compiler does not parse the attribute)
 #define KTA_WAVES_PER_EU(least, most) __attribute__((amdgpu_waves_per_eu(least, most)))
 #endif
-// PF (geometries for large batches, where fewer than two waves per SIMD hide nothing): while a round chains and parses,
-// the blocks of the W bytes behind its window are in flight into the staging registers.  A round usually ends with the
-// record that straddles the window's end (its header is inside, its value is skipped), so the next one begins shortly
-// behind that end: it takes the blocks if it begins in their first W / 8 bytes, else it loads its window as before.
-// A prefetched window only begins earlier than the round's first record: what the round delivers does not depend on it.
-template <int G, uint32_t W, uint32_t R, bool PF>   // batches per wave, window bytes, records per round of a group
+template <int G, uint32_t W, uint32_t R>   // batches per wave, window bytes, records per round of a group
 __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                    uint64_t n_batches, int want_keys, int32_t *part,
                                                    int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
@@ -114,64 +109,34 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
         bad = d.status != 0;                              // failed check.crcs or inflate: the batch is not delivered
     }
     bool run = !bad && j < total;                         // uniform inside a group
-    constexpr uint32_t OV = W >= 256 ? (W / 8) & ~15u : 16u;   // PF: how far into the blocks sent for a round may begin
-    uint4 ahead[PF ? NLOAD : 1];                          // PF: the blocks sent for during the last round
-#pragma unroll
-    for (uint32_t u = 0; u < (PF ? NLOAD : 1); u++) ahead[u] = make_uint4(0, 0, 0, 0);   // (uninitialised, the array stays in scratch)
-    uint64_t pf_base = ~0ull;                             // PF: base of the window they belong to; none
     while (__any(run)) {
         uint64_t wbase = 0;
         uint32_t limit = 0, end_rel = 0;                  // valid bytes in the window; the batch's end seen from its base
         bool to_the_end = false;                          // the window reaches the end of the batch
-        bool fetched = false;                             // PF: the window is the one the last round sent for
         if (run && pos >= end) { bad = true; run = false; }
         if (run) {
             wbase = pos & ~15ull;
-            if (PF) {
-                fetched = pf_base <= wbase && wbase - pf_base <= OV;
-                if (fetched) wbase = pf_base;
-            }
             const uint64_t span = ((end + 15) & ~15ull) - wbase, rest = end - wbase;
             const uint32_t wbytes = span < W ? (uint32_t)span : W;         // a multiple of 16, at least 16
             to_the_end = rest <= wbytes;
             limit = to_the_end ? (uint32_t)rest : wbytes;
             end_rel = rest < 0xF0000000ull ? (uint32_t)rest : 0xF0000000u;
-            if (!fetched) {
-                // all loads of the window are in flight together; a lane behind the batch's last block loads that block
-                // again and stores it where its own would go — bytes at and behind `limit`, which decide nothing
-                const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + wbase;
-                uint4 stage[NLOAD];
-#pragma unroll
-                for (uint32_t u = 0; u < NLOAD; u++) {
-                    const uint32_t o = (sub + u * L) * 16;
-                    stage[u] = *reinterpret_cast<const uint4 *>(src + (o < wbytes - 16 ? o : wbytes - 16));
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
-#pragma unroll
-                for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = stage[u];
-            } else if (PF) {                              // (its own registers and stores: no copies between the two ways)
-#pragma unroll
-                for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = ahead[u];
-            }
-            if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
-        }
-        __syncthreads();
-        if (PF) {
-            // Every lane issues the loads, wanted or not (a group that is done or at its batch's end reads the blob's
-            // first block): loads under a condition would merge with the old registers through copies, and a copy
-            // waits for its load.
-            const bool want = run && !to_the_end;         // (the window is full: W bytes, and the batch goes on behind it)
-            pf_base = want ? wbase + W : ~0ull;
-            const uint64_t from = want ? pf_base : 0ull, span = want ? ((end + 15) & ~15ull) - pf_base : 16ull;
-            const uint32_t wbytes = span < W ? (uint32_t)span : W;             // as the round that takes them computes it
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + from;
+            // all loads of the window are in flight together; a lane behind the batch's last block loads that block
+            // again and stores it where its own would go — bytes at and behind `limit`, which decide nothing
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + wbase;
+            uint4 stage[NLOAD];
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) {
                 const uint32_t o = (sub + u * L) * 16;
-                ahead[u] = *reinterpret_cast<const uint4 *>(src + (o < wbytes - 16 ? o : wbytes - 16));
+                stage[u] = *reinterpret_cast<const uint4 *>(src + (o < wbytes - 16 ? o : wbytes - 16));
             }
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = stage[u];
+            if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
         }
+        __syncthreads();
         if (run && sub == 0) {                                                 // chain the length prefixes
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
             const uint32_t want = total - j < R ? total - j : R;
@@ -232,11 +197,9 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
         if (run) {
             const uint32_t found = s_found[g], first_inc = s_first_incomplete[g];
             const uint32_t done = first_inc < found ? first_inc : found;
-            if (s_bad[g] || (done == 0 && !fetched)) {                         // done == 0: no progress, truncated batch
+            if (s_bad[g] || done == 0) {                                       // done == 0: no progress, truncated batch
                 bad = true;
                 run = false;
-            } else if (done == 0) {
-                pf_base = ~0ull;            // (PF) the window began too far before this record: the next one begins at it
             } else {
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++)
@@ -271,17 +234,6 @@ __global__ __launch_bounds__(64) KTA_WAVES_PER_EU(G * W <= 8192 ? 5 : 1, 8) void
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
                                                         unsigned long long *n_bad, unsigned long long *n_keyb)
 {
-    decode_coop_rounds<G, W, R, false>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, blob_base, seq, seq_base,
+    decode_coop_rounds<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, blob_base, seq, seq_base,
                                        n_bad, n_keyb);
-}
-
-template <int G, uint32_t W, uint32_t R>   // with the next window's blocks in flight (PF above)
-__global__ __launch_bounds__(64) void kafka_decode_coop_pf(const uint4 *blocks, const kta_kafka_batch_desc *descs,
-                                                           uint64_t n_batches, int want_keys, int32_t *part,
-                                                           int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
-                                                           uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
-                                                           unsigned long long *n_bad, unsigned long long *n_keyb)
-{
-    decode_coop_rounds<G, W, R, true>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, blob_base, seq, seq_base,
-                                      n_bad, n_keyb);
 }

@@ -9,8 +9,7 @@
 //                                                                then the copies one wave per batch
 //           kafka_zstd_inflate_coop                              zstd one wave per batch (uniform parsing, LDS tables,
 //                                                                64-byte copy steps, Huffman streams on four lanes)
-//           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows (kta_decode_coop.h;
-//           kafka_decode_coop_pf<G, W, R>  the same with the next window's blocks in flight: large batches)
+//           kafka_decode_coop<G, W, R>  record parse: G batches per wave through LDS windows (kta_decode_coop.h)
 //           kafka_decode / kafka_inflate_lane / kafka_gzip_inflate / kafka_zstd_inflate
 //                                                                one-lane-per-batch forms kept for comparison
 //                                                                (kta_kafka_set_variant 1)
@@ -50,24 +49,23 @@ namespace {
 constexpr int kLanesPerBlock = 64; // one wave per workgroup: spreads few batches over many CUs
 constexpr uint64_t kMaxBatchInflate = 512ull << 20;   // inflated size one batch may claim
 
-// Automatic choice (measured on MI355X, tools/explore_decode.py): sharing a wave between batches pays as
-// long as the waves still fill the chip; the smaller the batches, the smaller the windows (more waves
-// resident, fewer bytes staged for nothing).
+// Automatic choice.  Every geometry the library could dispatch at the start of round 5 was timed side by side on one
+// box (profiles/r05_decode_geometries.jsonl: 2 M records as ~2 / ~16 / ~134 KiB batches, kernel ms):
+//                          2 KiB    16 KiB   134 KiB
+//   <4, 3 KiB, 16>   (10)  0.130    0.146    0.231      <4, 2 KiB, 16>: 0.129 / 0.152 / 0.286;  <8, 1 KiB, 16>: 0.133 / 0.180 / 0.476
+//   <2, 8 KiB, 32>   (11)  0.253    0.141    0.149      128 / 64 records per round: 0.147 / 0.147 and 0.163 / 0.161;
+//                                                       with the next window prefetched into registers: 0.155 / 0.148 and 0.160 / 0.158
+//   <1, 8 KiB, 256>  (2)   0.283    0.142    0.154      <4, 8 KiB, 128>: 0.306 / 0.194 / 0.205
+// Sharing a wave between four batches pays while the batches are smaller than an 8 KiB window; from there on two batches
+// per wave with ONE parse round per window (an 8 KiB window holds ~31 records of the 256-byte mean).  The kernel is bound
+// by instruction issue (profiles/r04_sq_decode.txt): what wins is the geometry with the fewest rounds per byte that still
+// fills the SIMDs.  The losers' instantiations (and the prefetching form of the kernel) were deleted with their timings kept.
 int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 {
     if (forced) return forced;
-    if (n_batches < 2048) return 2;
+    if (n_batches < 2048) return 2;            // few batches: one wave each
     const uint64_t mean = blob_len / n_batches;
-    // (batches of 64 KiB and more: 4000 batches of 134 KiB are 2000 waves of the <2, 8 KiB> geometry — two per SIMD —
-    // and 17 windows each: 0.223 ms where <4, 4 KiB> took 0.316 and <1, 8 KiB> 0.333, round 4.  16 KiB batches: a 2 KiB
-    // window holds 7 or 8 records of the 256-byte mean, so 16 records per round — one parse round of the 16 lanes — is
-    // enough: 0.276 / 0.144 ms at 4 M / 2 M records where 32 per round took 0.282 / 0.157; <8, 2 KiB>, <4, 4 KiB, 32>
-    // measured slower: the kernel is bound by instruction issue, 95 % of the SIMDs' cycles, profiles/r04_sq_decode.txt)
-    // Batches of 64 KiB and more since the end of round 4: the same <2, 8 KiB> geometry with 64 records per round (two
-    // parse rounds per window instead of four) and the next window's blocks in flight during chain and parse
-    // (kafka_decode_coop_pf) — chosen from the emulator's counts and the budget of a round, NOT yet from a
-    // timing: set_variant 7 is the measured one, tools/first_call.sh times 7 / 11 / 12 / 13 / 14 side by side.
-    return mean < 4096 ? 5 : (mean < 65536 ? 8 : 14);
+    return mean < 8192 ? 10 : 11;
 }
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>
@@ -959,7 +957,7 @@ struct KafkaState {
     std::vector<BlobStage> stages;
     uint64_t blob_capacity = 256ull << 20;
     uint64_t inflate_limit = 0;     // kta_kafka_set_inflate_limit: 0 = default (1 GiB per group of batches)
-    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2..14 = wave geometries
+    int variant = 0;                // kta_kafka_set_variant: 0 = automatic, 1 = lane per batch, 2 / 10 / 11 = wave geometries
     int cur = 0;
     bool acquired = false;
     std::vector<hipEvent_t> ev[2];
@@ -1455,32 +1453,17 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
                        words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
                        out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
-#define KTA_DECODE_COOP_PF(G, W, R)                                                                                   \
-    hipLaunchKernelGGL((kafka_decode_coop_pf<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s, \
-                       words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
-                       out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
     switch (decode_variant_for(st->variant, n_batches, blob_len)) {
     case 1: // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
                            out->partition, out->key_len, out->val_len, out->ts_ms, out->key_off, (uint64_t)0, out->seq,
                            (uint64_t)0, d_bad, d_keyb);
         break;
-    case 2: KTA_DECODE_COOP(1, 8192u, 256u); break;   // one wave per batch
-    case 3: KTA_DECODE_COOP(4, 4096u, 64u); break;    // 16 lanes per batch, 4 KiB windows
-    case 4: KTA_DECODE_COOP(4, 2048u, 32u); break;    // 16 lanes per batch, 2 KiB windows
-    case 6: KTA_DECODE_COOP(4, 8192u, 128u); break;   // 16 lanes per batch, 8 KiB windows
-    case 7: KTA_DECODE_COOP(2, 8192u, 128u); break;   // 32 lanes per batch, 8 KiB windows: batches of 64 KiB and more
-    case 8: KTA_DECODE_COOP(4, 2048u, 16u); break;    // 16 lanes per batch, 2 KiB windows, ONE parse round per window: 16 KiB batches
-    case 9: KTA_DECODE_COOP(8, 2048u, 16u); break;    // 8 lanes per batch, 2 KiB windows: eight leaders chain side by side
-    case 10: KTA_DECODE_COOP(4, 3072u, 16u); break;   // 16 lanes per batch, 3 KiB windows: ~11 records of the 256-byte mean
-    case 11: KTA_DECODE_COOP(2, 8192u, 32u); break;   // as 7 with ONE parse round per window (an 8 KiB window holds ~31 records
-    case 12: KTA_DECODE_COOP(2, 8192u, 64u); break;   //   of the 256-byte mean) and with two: candidates for batches >= 64 KiB, untimed
-    case 13: KTA_DECODE_COOP_PF(2, 8192u, 128u); break;   // as 7 / 12 with the next window's blocks in flight during chain and
-    case 14: KTA_DECODE_COOP_PF(2, 8192u, 64u); break;    //   parse (kta_decode_coop.h: PF): candidates likewise, untimed
-    default: KTA_DECODE_COOP(8, 1024u, 16u); break;   // 8 lanes per batch, 1 KiB windows
+    case 2: KTA_DECODE_COOP(1, 8192u, 256u); break;   // one wave per batch: calls with few batches
+    case 10: KTA_DECODE_COOP(4, 3072u, 16u); break;   // 16 lanes per batch, 3 KiB windows (~11 records of the 256-byte mean), one parse round
+    default: KTA_DECODE_COOP(2, 8192u, 32u); break;   // (11) 32 lanes per batch, 8 KiB windows (~31 records), one parse round
     }
 #undef KTA_DECODE_COOP
-#undef KTA_DECODE_COOP_PF
     KK(ctx, hipGetLastError());
     if (timing) KK(ctx, hipEventRecord(b, s));
     if (n_bad_batches || n_key_bytes) {
@@ -1738,7 +1721,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 14) return KTA_ERR_INVALID;
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 2 || variant == 10 || variant == 11)) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;
 }

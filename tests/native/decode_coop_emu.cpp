@@ -17,18 +17,14 @@ namespace {
 
 namespace {
 
-template <int G, uint32_t W, uint32_t R, bool PF = false>
+template <int G, uint32_t W, uint32_t R>
 const char *run(uint32_t grid, int order, uint32_t seed, const uint4 *blocks, const kta_kafka_batch_desc *descs,
                 uint64_t n_batches, int want_keys, int32_t *part, int32_t *klen, int32_t *vlen, int64_t *ts,
                 uint32_t *koff, uint64_t *seq, uint64_t seq_base, unsigned long long *n_bad, unsigned long long *n_keyb)
 {
     return wave_emu::launch(grid, order, seed, [&] {
-        if (PF)
-            kafka_decode_coop_pf<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, (uint64_t)0, seq,
-                                          seq_base, n_bad, n_keyb);
-        else
-            kafka_decode_coop<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, (uint64_t)0, seq,
-                                       seq_base, n_bad, n_keyb);
+        kafka_decode_coop<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, (uint64_t)0, seq, seq_base,
+                                   n_bad, n_keyb);
     });
 }
 
@@ -80,8 +76,8 @@ int kta_emu_selftest_divergent(void)
     return err ? -2 : 0;
 }
 
-// lanes / window / per_round: the geometry as kta_kafka_decode_rounds_host names it (G = 64 / lanes); prefetch: the
-// kafka_decode_coop_pf form of it.  order, seed: wave_emu::launch.  poison: the byte behind the blob's end.  Returns 0, -1 for a geometry that is not instantiated
+// lanes / window / per_round: the geometry as kta_kafka_decode_rounds_host names it (G = 64 / lanes); prefetch: must be 0 (the prefetching form of the
+// kernel was deleted in round 5).  order, seed: wave_emu::launch.  poison: the byte behind the blob's end.  Returns 0, -1 for a geometry that is not instantiated
 // below, -2 when the emulator reports divergent meeting points (kta_emu_last_error).
 int kta_emu_decode_coop(uint32_t lanes, uint32_t window, uint32_t per_round, int prefetch, int order, uint32_t seed, uint8_t poison,
                         const uint8_t *blob, uint64_t blob_len, const kta_kafka_batch_desc *descs, uint64_t n_batches,
@@ -101,32 +97,19 @@ int kta_emu_decode_coop(uint32_t lanes, uint32_t window, uint32_t per_round, int
     const uint32_t grid = G ? (uint32_t)((n_batches + G - 1) / G) : 0;
     const char *err = nullptr;
     int rc = 0;
-#define GEOMETRY(g, w, r) GEOMETRY_PF(g, w, r, false)
-#define GEOMETRY_PF(g, w, r, pf)                                                                                      \
-    else if (G == (g) && window == (w) && per_round == (r) && (prefetch != 0) == (pf))                                \
-        err = run<g, w, r, pf>(grid, order, seed, blocks, descs, n_batches, wk, partition, key_len, val_len, ts_ms,       \
+#define GEOMETRY(g, w, r)                                                                                             \
+    else if (G == (g) && window == (w) && per_round == (r) && !prefetch)                                              \
+        err = run<g, w, r>(grid, order, seed, blocks, descs, n_batches, wk, partition, key_len, val_len, ts_ms,       \
                            key_off, seq, seq_base, &bad, n_key_bytes ? &keyb : nullptr)
     if (!G || 64 % lanes) rc = -1;
     GEOMETRY(1, 8192u, 256u);   // the dispatcher's geometries (kta_kafka.hip: KTA_DECODE_COOP)
-    GEOMETRY(4, 4096u, 64u);
-    GEOMETRY(4, 2048u, 32u);
-    GEOMETRY(4, 8192u, 128u);
-    GEOMETRY(2, 8192u, 128u);
-    GEOMETRY(2, 8192u, 32u);
-    GEOMETRY(2, 8192u, 64u);
-    GEOMETRY_PF(2, 8192u, 128u, true);
-    GEOMETRY_PF(2, 8192u, 64u, true);
-    GEOMETRY_PF(8, 256u, 8u, true);     // (small: almost every round decides about a prefetched window)
-    GEOMETRY_PF(16, 64u, 4u, true);
-    GEOMETRY(4, 2048u, 16u);
-    GEOMETRY(8, 2048u, 16u);
     GEOMETRY(4, 3072u, 16u);
-    GEOMETRY(8, 1024u, 16u);
+    GEOMETRY(2, 8192u, 32u);
+    GEOMETRY(8, 1024u, 16u);    // eight leaders
     GEOMETRY(8, 256u, 8u);      // small ones: a window edge in almost every record
     GEOMETRY(16, 64u, 4u);
     else rc = -1;
 #undef GEOMETRY
-#undef GEOMETRY_PF
     free(buf);
     if (err) {
         snprintf(g_error, sizeof g_error, "%s", err);

@@ -41,8 +41,7 @@ struct Geometry {
     uint32_t lanes, window, per_round;
     int prefetch;
 };
-const Geometry kGeometries[] = {{16, 2048, 16, 0}, {8, 1024, 16, 0}, {32, 8192, 128, 0}, {64, 8192, 256, 0}, {8, 256, 8, 0},
-                                {4, 64, 4, 0},     {32, 8192, 64, 1}, {8, 256, 8, 1},     {4, 64, 4, 1}};
+const Geometry kGeometries[] = {{16, 3072, 16, 0}, {8, 1024, 16, 0}, {32, 8192, 32, 0}, {64, 8192, 256, 0}, {8, 256, 8, 0}, {4, 64, 4, 0}};
 
 bool decode(const Geometry &g, const std::vector<uint8_t> &blob, const std::vector<kta_kafka_batch_desc> &descs, Columns &c,
             uint64_t *bad)

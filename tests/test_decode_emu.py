@@ -31,9 +31,6 @@ NATIVE = os.path.join(ROOT, "tests", "native")
 # every geometry tests/native/decode_coop_emu.cpp instantiates: the dispatcher's (kta_kafka.hip) and two small ones
 GEOMETRIES = sorted(set(GEOMETRY_OF_VARIANT.values()) | {(8, 1024, 16), (8, 256, 8), (4, 64, 4)})
 ORDERS = [(0, 0), (1, 0), (2, 7)]            # (lane order between meeting points, seed)
-# kafka_decode_coop_pf (the next window's blocks in flight while a round chains and parses): set_variant 13 / 14 and
-# two small geometries in which almost every round decides about a prefetched window
-PREFETCH_GEOMETRIES = [(32, 8192, 128), (32, 8192, 64), (8, 256, 8), (4, 64, 4)]
 
 
 @pytest.fixture(scope="module")
@@ -181,7 +178,7 @@ def test_kernel_source_honours_batch_status_append_time_and_record_base(emu):
     rc, descs, st = index_host(blob, 6)
     assert rc == N.KTA_OK and st.n_batches >= 12
     nb, n = int(st.n_batches), int(st.n_records)
-    plain, _ = run_kernel(emu, blob, 6, (16, 2048, 16), descs=descs, st=st)
+    plain, _ = run_kernel(emu, blob, 6, (16, 3072, 16), descs=descs, st=st)
     base, counts = [descs[i].record_base for i in range(nb)], [descs[i].n_records for i in range(nb)]
     at = n
     for i in range(nb):                                   # batch i's records now end where batch i - 1's begin
@@ -190,7 +187,7 @@ def test_kernel_source_honours_batch_status_append_time_and_record_base(emu):
     descs[3].status = 1
     descs[5].flags |= 1                       # KTA_KB_LOG_APPEND_TIME (include/kta_kafka.h)
     descs[5].max_ts_ms = 777
-    for geometry in ((16, 2048, 16), (8, 1024, 16), (32, 8192, 128), (64, 8192, 256)):
+    for geometry in ((16, 3072, 16), (8, 1024, 16), (32, 8192, 32), (64, 8192, 256)):
         cols, bad = run_kernel(emu, blob, 6, geometry, ORDERS[2], descs=descs, st=st, want_key_bytes=False)
         assert bad == 1 and cols["n_key_bytes"] == 0
         for i in range(nb):
@@ -207,69 +204,3 @@ def test_kernel_source_honours_batch_status_append_time_and_record_base(emu):
                 assert (cols["ts_ms"][mine] == 777).all()
             else:
                 assert np.array_equal(cols["ts_ms"][mine], plain["ts_ms"][was])
-
-
-@pytest.mark.parametrize("geometry", PREFETCH_GEOMETRIES)
-@pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
-                                                        (6, True, 3000)])
-def test_prefetching_kernel_source_matches_encoder_and_oracle(emu, seed, with_keys, max_records, geometry):
-    blob, expected, want = _random_case(seed, max_records)
-    host, _, _, _ = R.rounds_host(blob, 3, geometry, with_keys)
-    for order in ORDERS:
-        cols, bad = run_kernel(emu, blob, 3, geometry, order, with_keys=with_keys, prefetch=True,
-                               poison=(0xEE, 0x00, 0xFF)[order[0]])
-        assert bad == 0
-        assert_columns(cols, expected)
-        for k in ("partition", "key_len", "val_len", "ts_ms"):
-            assert np.array_equal(cols[k], want[k]), k
-        if with_keys:
-            assert np.array_equal(cols["key_off"], host["key_off"])
-        assert cols["n_key_bytes"] == host["n_key_bytes"]
-
-
-@pytest.mark.parametrize("geometry", PREFETCH_GEOMETRIES)
-def test_prefetching_kernel_source_on_awkward_and_damaged_batches(emu, geometry):
-    """Where its windows begin is the one thing the prefetching form does differently, so on sound batches it equals
-    the host statement bit for bit; in a batch that is reported, WHICH records are withheld depends on where the rounds
-    were cut: there it is held to what the host statement is held to (tests/test_decode_rounds.py) — the batches the
-    oracle reports, a delivered prefix of what the oracle delivers, the neighbours untouched."""
-    reported = 0
-    for n, blob in enumerate(_awkward_blobs()):
-        host, descs, st, host_bad = R.rounds_host(blob, 1, geometry)
-        want, ost = kafka_decode(blob, 1)
-        cols, bad = run_kernel(emu, blob, 1, geometry, ORDERS[n % 3], (0xEE, 0x00, 0xFF)[n % 3], prefetch=True)
-        assert bad == host_bad == ost.bad_batches, n
-        reported += bad
-        for i in range(st.n_batches):
-            sl = slice(descs[i].record_base, descs[i].record_base + descs[i].n_records)
-            if not (host["partition"][sl] == -1).any():
-                for k in ("partition", "key_len", "val_len", "ts_ms", "key_off"):
-                    assert np.array_equal(cols[k][sl], host[k][sl]), (n, i, k)
-                continue
-            mine, theirs = cols["partition"][sl], want["partition"][sl]
-            delivered = int((mine != -1).sum())
-            assert delivered < descs[i].n_records and delivered <= int((theirs != -1).sum()), (n, i)
-            assert (mine[:delivered] == 1).all() and (mine[delivered:] == -1).all(), (n, i)
-            for k in ("key_len", "val_len", "ts_ms"):
-                assert np.array_equal(cols[k][sl][:delivered], want[k][sl][:delivered]), (n, i, k)
-                assert (cols[k][sl][delivered:] == -1).all(), (n, i, k)
-    assert reported > 25
-
-
-def test_prefetched_window_too_early_for_a_long_header_is_not_a_truncated_batch(emu):
-    """A round without progress condemns the batch — unless its window was a prefetched one, which begins up to
-    W / 8 + 15 bytes before the round's first record: a 41-byte header (every varint padded to ten bytes) that a fresh
-    64-byte window holds does not always fit behind those.  Such a round is repeated on a fresh window (counted with
-    an instrumented build: 72 of this case's 372 rounds in the <16, 64, 4> geometry)."""
-    rng = np.random.default_rng(4)
-    recs = [(i, b"k" * int(rng.integers(0, 9)), b"v" * int(rng.integers(0, 40)), (10, 10, 10, 10, 10)) for i in range(300)]
-    raw = b"".join(R.record(r[0], r[1], r[2], r[3], offset_delta=i) for i, r in enumerate(recs))
-    blob = K.encode_batch(0, recs, 10**12, raw_records=raw)
-    want, ost = kafka_decode(blob, 1)
-    assert ost.bad_batches == 0
-    for geometry in PREFETCH_GEOMETRIES:
-        for order in ORDERS:
-            cols, bad = run_kernel(emu, blob, 1, geometry, order, prefetch=True)
-            assert bad == 0, geometry
-            for k in ("partition", "key_len", "val_len", "ts_ms"):
-                assert np.array_equal(cols[k], want[k]), (geometry, k)

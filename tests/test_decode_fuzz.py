@@ -1,7 +1,7 @@
 """Memory safety of the record decode kernel on damaged record sets: its own source (csrc/kta_decode_coop.h) over the
 lane emulator (tests/native/wave_emu.h), built with AddressSanitizer + UBSan and driven natively
 (tests/native/decode_coop_fuzz.cpp) with thousands of mutations — bytes of the records, forged record counts, batches
-cut short — in the dispatcher's geometries, two small ones and the prefetching form.  The blob and the output columns
+cut short — in the dispatcher's geometries and three small ones.  The blob and the output columns
 are heap blocks of exactly the sizes the device contract names, so a stray access aborts here where the GPU would
 fault; what is delivered is checked as well (sound batches unchanged, reported batches a prefix then -1).
 150 rounds per seed here (a minute); `decode_coop_fuzz 600 <seeds>` ran clean as well (6 600 damaged sets)."""

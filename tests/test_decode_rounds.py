@@ -16,8 +16,7 @@ from test_kafka_decode import _forged_count_blob, index_host
 
 # (lanes per batch, window bytes, records per round): the dispatcher's geometries (kta_kafka.hip) and two small ones
 # that put a window edge into almost every record
-GEOMETRIES = [(16, 2048, 16), (8, 1024, 16), (32, 8192, 128), (64, 8192, 256), (16, 4096, 64), (16, 2048, 32),
-              (16, 8192, 128), (8, 256, 8), (4, 64, 4)]
+GEOMETRIES = [(16, 3072, 16), (32, 8192, 32), (64, 8192, 256), (8, 1024, 16), (8, 256, 8), (4, 64, 4)]
 
 
 def rounds_host(blob, partition, geometry, with_keys=True):

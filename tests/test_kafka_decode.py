@@ -249,7 +249,7 @@ def _device_decode_case(seed, max_records):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11])
 @pytest.mark.parametrize("seed,with_keys,max_records", [(1, True, 40), (2, False, 40), (3, True, 700), (5, True, 300),
                                                         (6, True, 3000)])
 def test_device_decode_matches_encoder_and_oracle(seed, with_keys, max_records, variant):
@@ -273,7 +273,7 @@ def test_device_decode_reports_corrupt_batches():
     bad = K.encode_batch(10, [(0, b"a", b"b"), (1, b"c", None)], 1000, count=3)
     blob = good + bad + good
     want, ost = kafka_decode(blob, 0)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
+    for variant in (0, 1, 2, 10, 11):
         with kta.HipMetricHandler(2, now=NOW) as h:
             h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
             cols, st, nbad = _decode_on_device(h, blob, 0, True)
@@ -282,9 +282,7 @@ def test_device_decode_reports_corrupt_batches():
 
 
 # kta_kafka_set_variant -> (lanes per batch, window bytes, records per round) of kafka_decode_coop (csrc/kta_kafka.hip)
-GEOMETRY_OF_VARIANT = {2: (64, 8192, 256), 3: (16, 4096, 64), 4: (16, 2048, 32), 5: (8, 1024, 16), 6: (16, 8192, 128),
-                       7: (32, 8192, 128), 8: (16, 2048, 16), 9: (8, 2048, 16), 10: (16, 3072, 16), 11: (32, 8192, 32),
-                       12: (32, 8192, 64)}
+GEOMETRY_OF_VARIANT = {2: (64, 8192, 256), 10: (16, 3072, 16), 11: (32, 8192, 32)}
 
 
 @pytest.mark.gpu
@@ -328,7 +326,7 @@ def test_device_rounds_equal_their_host_statement_bit_for_bit():
                 for k in ("partition", "key_len", "val_len", "ts_ms", "key_off"):
                     assert np.array_equal(cols[k], want[k]), (variant, n, k)
                 assert cols["n_key_bytes"] == want["n_key_bytes"], (variant, n)
-    assert reported > 100
+    assert reported > 25 * len(GEOMETRY_OF_VARIANT)      # (27 batches of the case list are reported, per geometry)
 
 
 @pytest.mark.gpu
@@ -707,7 +705,7 @@ def test_device_inflates_streams_of_the_real_libraries():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 10])
 def test_device_decodes_snappy_batches(variant):
     rng = np.random.default_rng(33)
     blob, expected, info = random_record_set(rng, 160, max_records=120, snappy=True)

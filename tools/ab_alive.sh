@@ -2,7 +2,8 @@
 # A/B of build switches of the alive pass (kta_alive.hip) with tools/ubench_alive.hip, many variants per gpurun call
 # (a call costs about half a GPU-minute before the command starts).
 #
-#   build container:   tools/ab_alive.sh build base: l4:"-DKTA_DBG_LEVEL=4 -DKTA_DBG_PART_ONLY" b128:"-DKTA_P32_EXP_BLOG2=9 -DKTA_P32_BLOCK=32 -DKTA_DBG_PART_ONLY"
+#   build container:   tools/ab_alive.sh build base: cand:"-DSOME_SWITCH_OF_THE_CANDIDATE"      (a candidate's switch lives in the tree only while it is
+#                      being measured: round 4's were deleted with their timings kept in profiles/r04_ab_alive.txt)
 #                      -> tools/ubench_alive_ab_<tag>, one binary per "tag:flags" (timing builds: no phase counters)
 #   GPU box:           gpurun --timeout 120 -- 'AB_FULL=tools/ubench_alive_ab_base bash tools/ab_alive.sh run > gpurun_out/ab.txt 2>&1'
 #                      -> per binary: best of 4 repetitions (whole pass and per kernel) on the headline workload, and whether
@@ -28,7 +29,7 @@ if [ "${1:-}" = build ]; then
 fi
 if [ "${1:-}" = run ]; then
     # every binary on the headline workload (bit set state); the full matrix only for the binaries named in $AB_FULL
-    # (default: the first one).  Binaries built with KTA_DBG_* switches time a part of the work: their counts are wrong
+    # (default: the first one).  Binaries built with switches that time a part of the work leave the counts wrong
     # by design.
     one() {     # binary, log2 n, distinct, expected count, state
         out=$(timeout 60 "$1" "$2" "$3" "$5" 2>&1)

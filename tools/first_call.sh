@@ -10,9 +10,9 @@ mkdir -p $OUT
 cd $ROOT
 [ -n "$SKIP_PYTEST" ] || timeout 900 python -m pytest tests/test_kafka_decode.py -x -q -m gpu > $OUT/pytest_decode.txt 2>&1
 tail -3 $OUT/pytest_decode.txt
-# automatic choice (0) and the geometries around it: 5 = <8, 1 KiB, 16>, 8 = <4, 2 KiB, 16>, 9 = <8, 2 KiB, 16>,
-# 10 = <4, 3 KiB, 16>, 7 = <2, 8 KiB, 128>, 11 / 12 = <2, 8 KiB, 32 / 64>, 13 / 14 = <2, 8 KiB, 128 / 64> prefetching, 6 = <4, 8 KiB, 128>, 2 = <1, 8 KiB, 256>
-timeout 600 python tools/bench_decode.py --rpb 8,60,500 --variants 0,5,8,9,10,7,11,12,13,14,6,2 > $OUT/bench_decode.txt 2>&1
+# automatic choice (0) and the three geometries that are left (round 5: profiles/r05_decode_geometries.jsonl has the ones that lost):
+# 10 = <4, 3 KiB, 16>, 11 = <2, 8 KiB, 32>, 2 = <1, 8 KiB, 256>; ~2 / ~16 / ~134 KiB batches and ~10 KiB RECORDS in 64 KiB batches
+timeout 600 python tools/bench_decode.py --rpb 8,60,500 --variants 0,10,11,2 > $OUT/bench_decode.txt 2>&1
 tail -30 $OUT/bench_decode.txt
 bash tools/profile_round.sh r05 > $OUT/profile.log 2>&1
 tail -5 $OUT/profile.log
