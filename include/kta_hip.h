@@ -366,11 +366,11 @@ int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int aliv
  * alive-key update) and kinds 0 / 1 see only the fold: kta_kernel_time_stats returns launches[0] == 0 there. */
 int kta_set_fuse(kta_ctx *ctx, int enable);
 /* What the partitioned alive-key pass did since kta_create / kta_reset — host-side counters, nothing is waited for:
- * out[0] the slice size in force for the bit set state (batches larger than it are applied slice by slice; it drops
- * from 2^28 to 2^26 records after a batch that handed buckets to the fallback kernel), out[1] slices launched,
- * out[2] of them with both handlers in the one pass, out[3] of them whose metrics handler ran as a scan although
- * the batch began fused, out[4] buckets handed to the fallback kernel as far as sampled (the last slice of each
- * batch of >= 2^27 records, read when the NEXT batch or this call finds the copy complete), out[5] the fuse switch. */
+ * out[0] the most records one launch pair takes (larger batches are applied piece after piece), out[1] launch pairs,
+ * out[2] of them with both handlers in the one pass, out[3] of them whose metrics handler ran as a scan although the
+ * batch began fused, out[4] buckets handed to the fallback kernel (hot keys that overflow their segments; exact, slow) as
+ * far as sampled — the last launch of every bit-set-state batch of 2^24 records and more, read when the NEXT batch or this
+ * call finds the copy complete —, out[5] the fuse switch. */
 int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6]);
 
 #ifdef __cplusplus

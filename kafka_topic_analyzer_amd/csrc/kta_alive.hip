@@ -1077,6 +1077,7 @@ struct ApplyShared {
     uint32_t any_ovf;        // the side table holds something (this instalment)
     uint32_t next_seg;       // fast attempt: the next segment to hand out
     uint32_t dense;          // POOL_DENSE as thread 0 found it: ONE reading for the whole workgroup
+    uint32_t gmax[5];        // careful mode: the fullest aligned group of 1, 2, 4, 8, 16 segments (pick_group_size)
     long long w[kApplyWaves];
 };
 
@@ -1319,8 +1320,49 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     const uint32_t *region_pairs32 = reinterpret_cast<const uint32_t *>(pairs) + (uint64_t)b * W * cap;
     const uint32_t loads = BITMAP ? cap >> 8 : cap >> 7;
     const uint32_t chunks = BITMAP ? loads : (loads + kApplyUnroll - 1) / kApplyUnroll;
-    const uint32_t groups = (W + kApplyWaves - 1) / kApplyWaves;
-    const uint32_t units = groups * chunks;                                     // the same for every wave
+    // Careful mode merges one GROUP of segments — one per wave, each older than the next group's — between two
+    // checkpoints, so a group has to fit the table whatever its keys are: sixteen segments of a 2^28-record batch hold 15 k
+    // pairs, and with mostly unique keys (config 5's law on one GPU) that is more than the table and its side table
+    // take — every bucket went to kta_alive_fallback, 137 ms for the batch (round 4).  Bit set state: gs segments per
+    // group, the largest power of two whose fullest group holds at most 10 k pairs (at most 5 per set on average: the
+    // 8-way sets and the side table hold that with room to spare), found from the segment fills when the workgroup
+    // enters careful mode (pick_group_size); the waves gs ... 15 then only keep the barriers company.
+    const uint32_t groups16 = (W + kApplyWaves - 1) / kApplyWaves, units16 = groups16 * chunks;
+    uint32_t gs_c = kApplyWaves, units_c = units16;      // bit set state, careful mode: set by pick_group_size
+#define KTA_GS (BITMAP ? gs_c : (uint32_t)kApplyWaves)      /* segments of a group; units of a wave's walk (the same for every wave) */
+#define KTA_UNITS (BITMAP ? units_c : units16)
+    auto pick_group_size = [&]() __attribute__((always_inline)) {
+        if (!BITMAP) return;                             // (table state: what does not fit takes the direct path)
+        constexpr uint32_t kGroupPairs = 10240;
+        uint32_t *lvl = s_slice;                         // W words of scratch: the miss queues are empty here
+        if (threadIdx.x < 5) sh.gmax[threadIdx.x] = 0u;
+        lds_barrier();
+        for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
+            lvl[w] = s_cnt[w];
+            atomicMax(&sh.gmax[0], s_cnt[w]);
+        }
+        lds_barrier();
+        uint32_t have = W;                               // entries of the level below
+        for (uint32_t l = 1; l <= 4u; l++) {             // level l: the pairs of every aligned group of 2^l segments (W <= 1024: one per thread)
+            const uint32_t ng = (have + 1u) >> 1, g = threadIdx.x;
+            const uint32_t v = g < ng ? lvl[2u * g] + (2u * g + 1u < have ? lvl[2u * g + 1u] : 0u) : 0u;
+            lds_barrier();                               // (everybody has read the level below)
+            if (g < ng) {
+                lvl[g] = v;
+                atomicMax(&sh.gmax[l], v);
+            }
+            lds_barrier();
+            have = ng;
+        }
+        uint32_t l = 4;
+        gs_c = kApplyWaves;
+        while (gs_c > 1u && (uint32_t)__builtin_amdgcn_readfirstlane(sh.gmax[l]) > kGroupPairs) {
+            gs_c >>= 1;
+            l--;
+        }
+        units_c = ((W + gs_c - 1) / gs_c) * chunks;
+        lds_barrier();                                   // (the scratch is the miss queues' again)
+    };
     // bit set state: what pass 2 maximises per slot is (segment w, window, position in the segment) << 1 | alive; the
     // position takes ksh = ceil(log2(cap)) bits (cap >= 256, so the window's field starts above bit 8)
     const uint32_t ksh = 32u - (uint32_t)__builtin_clz(cap - 1u);
@@ -1355,10 +1397,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             seg_unit++;
         } else {
             r0 = (u % chunks) * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
-            seg = (u / chunks) * kApplyWaves + __builtin_amdgcn_readfirstlane(wave);
+            seg = (u / chunks) * KTA_GS + __builtin_amdgcn_readfirstlane(wave);
         }
         seg = __builtin_amdgcn_readfirstlane(seg);
-        const bool on = seg < W && (dynamic || u < units);
+        const bool on = seg < W && (dynamic || (u < KTA_UNITS && (!BITMAP || (uint32_t)__builtin_amdgcn_readfirstlane(wave) < gs_c)));
         const uint32_t cnt = on ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[on ? seg : 0u]) : 0u;
         if (BITMAP) {
             const uint32_t *sp = region_pairs32 + (uint64_t)(on ? seg : 0u) * cap;
@@ -1505,6 +1547,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // instalment's totals in registers, fed from the counter slot of the interval just ended (ApplyShared).
     // (Whatever the workgroup decides on comes out of LDS through readfirstlane: a value loaded per lane is divergent
     // to the compiler, and so is every loop counter of a loop that such a value leaves.)
+    if (careful) pick_group_size();
     uint32_t inst_start = 0;                            // first segment of the current instalment
     uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
     uint32_t u = 0;                                     // the unit that is merged next
@@ -1521,7 +1564,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         bool flush = false, failed = false, stop = false;
         // (fast attempt: `seg` is the segment of the unit issued LAST; segments are handed out in ascending order, so
         // once it is past the end every unit still in flight is empty or about to be merged by the trip)
-        while (!stop && (dynamic ? seg < W : u < units)) {
+        while (!stop && (dynamic ? seg < W : u < KTA_UNITS)) {
             if (!careful && __builtin_amdgcn_readfirstlane(sh.fail[0])) break;   // (fast attempt) some wave ran out of room: stop early
 #pragma unroll
             for (int s = 0; s < D; s++) {
@@ -1532,7 +1575,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 KTA_PHASE(1, 3);
                 if (careful && u % chunks == 0u) {
                     drain(par);                           // the queued misses are in before anybody looks at the table as a whole
-                    if (u < units) {
+                    if (u < KTA_UNITS) {
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
                         if (lane == 0 && claimed) atomicAdd(&sh.occ[par], claimed);
@@ -1544,6 +1587,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                         if (threadIdx.x == 0) sh.occ[(par + 2u) % 3u] = sh.ovf_n[(par + 2u) % 3u] = 0;
                         par = (par + 1u) % 3u;
                         // empty the table when the next interval, growing like the last one, would take it past kFlushAt
+                        // (measured and dropped in round 5: no forecast — merge until a group finds the table full, apply,
+                        // merge that group again: the brim-full table's long lookups cost more than the instalments saved,
+                        // 13.1 instead of 8.1 ms at 2^28 records of 100 M keys)
                         const uint32_t grew = tot_occ - last_occ;
                         last_occ = tot_occ;
                         flush = tot_occ + grew + grew / 4 > kFlushAt || tot_ovf > kOvf / 2;
@@ -1559,7 +1605,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             for (int s = 0; s + 1 < D; s++) merge(ring[s], par);
         }
         drain(par);
-        if (dynamic && !flush) u = units;                // (segments were handed out: every wave counted its own units)
+        if (dynamic && !flush) u = KTA_UNITS;              // (segments were handed out: every wave counted its own units)
         if (!failed && !flush) {                         // the last units are in: did everything fit?
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) claimed += __shfl_xor(claimed, off);
@@ -1595,13 +1641,14 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 careful = true;
                 u = 0;
                 lds_barrier();
+                pick_group_size();
                 continue;
             }
         }
         KTA_PHASE(1, 1);
         end_instalment();                                // (the one call site: the sweep is long)
-        if (u >= units) break;
-        inst_start = (u / chunks) * kApplyWaves;
+        if (u >= KTA_UNITS) break;
+        inst_start = (u / chunks) * KTA_GS;
         tot_occ = tot_ovf = last_occ = 0;
     }
     add_running(delta, running, sh.w);

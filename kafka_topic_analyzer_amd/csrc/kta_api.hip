@@ -84,14 +84,13 @@ struct kta_ctx {
     uint64_t *d_alive_stats = nullptr, *h_alive_stats = nullptr;
     hipEvent_t ev_alive_stats = nullptr;
     bool alive_stats_pending = false;
-    // bit set state: batches of mostly unique keys are applied in smaller slices (see run_device_batch)
-    uint64_t alive_slice = kta::kAlivePartitionMax;
     bool fuse_handlers = true;      // both handlers of a batch in one pass where that is possible (KTA_NO_FUSE=1: never)
     bool alive_failed_pending = false;
     int alive_backoff = 0;
-    // what the partitioned pass did since kta_create / kta_reset (kta_alive_pass_info): slices launched, of them with both
+    // what the partitioned pass did since kta_create / kta_reset (kta_alive_pass_info): launch pairs, of them with both
     // handlers in the one pass, of them with the metrics handler through the scan although the batch began fused, and the
-    // buckets the sampled slices handed to kta_alive_fallback (the word of a batch's LAST slice, read one batch late)
+    // buckets that the sampled launches (the last one of every batch of 2^24 records and more, bit set state) handed to
+    // kta_alive_fallback; the word comes back with the stream and is never waited for
     uint64_t info_slices = 0, info_fused = 0, info_scanned = 0, info_failed_buckets = 0;
     std::vector<Stage> stages;
     uint64_t batch_capacity = 0, key_bytes_capacity = 0;
@@ -222,7 +221,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
     // batch is read once, 40 B + key per record instead of 20 + 28.
     bool fuse = false;
     if (which == 3 && ctx->alive && !ctx->alive_table && !ctx->analytics && ctx->fuse_handlers) {
-        const uint64_t first = n > ctx->alive_slice ? ctx->alive_slice : n;
+        const uint64_t first = n > kta::kAlivePartitionMax ? kta::kAlivePartitionMax : n;
         const kta::AlivePartitionPlan pl0 = kta::plan_alive_partition(first, ctx->alive_wgs, ctx->cu_count, true);
         fuse = kta::alive_fuse_possible(pl0, ctx->P) && pl0.segment_wgs <= ctx->max_rows;
     }
@@ -306,20 +305,20 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                 KTA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_alive_stats, hipEventDisableTiming));
             }
             const bool report = ctx->alive_table && !ctx->alive_stats_pending;       // one report in flight at a time
-            // Bit set state: a bucket with more distinct slots than pass 2's LDS table takes is applied in instalments,
-            // as long as an instalment's segments fit the table; at 2^28 records of mostly unique keys (config 5's law
-            // on ONE GPU) they do not, and the bucket goes to kta_alive_fallback — exact, 70 times slower.  The number of
-            // buckets a batch handed over comes back with the stream (never waited for); once it was not zero, the
-            // batches that follow are applied in slices of 2^26 records: 16 segments of a bucket then hold 4 k pairs.
+            // Bit set state: a bucket with more distinct slots than pass 2's LDS table takes is applied in instalments (careful
+            // mode, groups of segments sized to fit the table: kta_alive.hip); what defeats that too — hot keys that overflow
+            // their segments into the pool, one group's segments all in one set — goes to kta_alive_fallback, exact and slow.
+            // The number of such buckets is sampled for kta_alive_pass_info.  (Round 4 applied the batches that followed one
+            // with such buckets in slices of 2^26 records; with the groups sized from the fills a whole batch of config 5's
+            // law takes 8.2 ms where four slices took 10.1, and the slicing went.)
             if (!ctx->alive_table && ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
                 ctx->alive_failed_pending = false;
                 ctx->info_failed_buckets += ctx->h_alive_stats[2];
-                if (ctx->h_alive_stats[2] != 0 && ctx->alive_slice > (1ull << 26)) ctx->alive_slice = 1ull << 26;
             }
             uint64_t first_take = 0;
             if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 4 * sizeof(uint64_t), ctx->s_compute));
             for (uint64_t at = 0; at < n;) {
-                const uint64_t left = !ctx->alive_table && n - at > ctx->alive_slice ? ctx->alive_slice : n - at;
+                const uint64_t left = n - at;
                 kta::AlivePartitionPlan pl = kta::plan_alive_partition(left, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
                 const uint64_t take = left < pl.max_records ? left : pl.max_records;
                 if (at == 0) first_take = take;
@@ -373,9 +372,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                                                           kta::alive_order_flag(ws, (int)pl.bucket_log2), written_list(ctx)));
                 at += take;
             }
-            if (!ctx->alive_table && !ctx->alive_failed_pending && first_take >= (1ull << 27) && ctx->alive_slice > (1ull << 26)) {
-                // (the last slice's word; hot keys that overflow their segments send buckets to the fallback kernel as
-                // well, whatever the size of the slice — batches that small are left as they are)
+            if (!ctx->alive_table && !ctx->alive_failed_pending && first_take >= (1ull << 24)) {
                 KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats + 2, kta::alive_failed_word(
                                                 kta::AliveWorkspace{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from}),
                                             sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->s_compute));
@@ -412,9 +409,8 @@ int reset_state(kta_ctx *ctx)
         }
         KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_running, 0, sizeof(int64_t), ctx->s_compute));
         ctx->running_valid = true;
-        // a new topic: what the old one's batches taught about slicing and backing off does not carry over (a word still
-        // on its way lands in h_alive_stats before any later copy — same stream — and is never looked at)
-        ctx->alive_slice = kta::kAlivePartitionMax;
+        // a new topic: what the old one's batches taught about backing off does not carry over (a word still on its way
+        // lands in h_alive_stats before any later copy — same stream — and is never looked at)
         ctx->alive_failed_pending = false;
         ctx->alive_stats_pending = false;
         ctx->alive_backoff = 0;
@@ -1122,9 +1118,8 @@ int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6])
     if (ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
         ctx->alive_failed_pending = false;
         ctx->info_failed_buckets += ctx->h_alive_stats[2];
-        if (ctx->h_alive_stats[2] != 0 && ctx->alive_slice > (1ull << 26)) ctx->alive_slice = 1ull << 26;
     }
-    out[0] = ctx->alive_slice;
+    out[0] = kta::kAlivePartitionMax;
     out[1] = ctx->info_slices;
     out[2] = ctx->info_fused;
     out[3] = ctx->info_scanned;
