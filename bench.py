@@ -284,8 +284,8 @@ def alive_table_report(kta, device, steps, n_records):
 def alive_hot_key_report(kta, device, n_records):
     """Adversarial shapes of the alive-key pass (bit set state): what a compacted topic with a dominant key costs.  One
     key / 40 keys over the whole batch: most records die in the partition kernel's guard (one record per hash and wave
-    instruction survives), the rest overflow their segments into the pool and the bucket is resolved by
-    kta_alive_fallback (slow, exact)."""
+    instruction survives), the rest overflow their segments into the pool (handed out in chunks, every block tagged with its
+    bucket) and the bucket is resolved by kta_alive_fallback (exact; it reads the tags and its own blocks)."""
     rows = []
     for distinct in (1, 40):
         spec, _ = kta.synth_preset("c3")
@@ -308,8 +308,8 @@ def alive_hot_key_report(kta, device, n_records):
         h.device_batch_free(b)
         h.close()
     # mostly unique keys (config 5's law: 100 M distinct, 50 % tombstones) on ONE GPU in the bit set state: a bucket holds
-    # more distinct slots than pass 2's LDS table, so it is applied in instalments — which, at this batch size, do not
-    # fit either: the first batch goes through kta_alive_fallback, and the library applies what follows in 2^26 slices
+    # ten times the distinct slots of pass 2's LDS table, so every bucket is applied in instalments (careful mode, groups of
+    # segments sized from the fills so that a group always fits: kta_alive.hip, pick_group_size)
     spec, _ = kta.synth_preset("c5")
     n5 = 15 << 24
     h = kta.HipMetricHandler(256, count_alive_keys=True, device=device)
@@ -327,9 +327,9 @@ def alive_hot_key_report(kta, device, n_records):
     h.close()
     unique = {"workload": f"c5 law (100 M distinct 16 B keys, 50 % tombstones), bit set state, {n5} records per batch, 4 batches",
               "kernel_ms_per_batch": per_launch, "records_per_s_last": n5 / (per_launch[-1] * 1e-3), **_alive_checked(res.alive_keys, "c5", 0, n5),
-              "note": "batch 1 is applied whole (buckets that fit neither the LDS table nor an instalment go to the fallback "
-                      "kernel: exact, slow); the count of such buckets comes back with the stream and the following batches are "
-                      "applied in slices of 2^26 records"}
+              "note": "every bucket restarts in careful mode and is applied in about 32 instalments (each streams the bucket's 512 KiB of "
+                      "bit set through LDS); round 4 sent all 1024 buckets of the first such batch to the fallback kernel (137 ms) and "
+                      "applied the following batches in slices of 2^26 records (9.4 ms)"}
     return {"workload": f"c3 shape with 1 / 40 distinct keys over {n_records} records (bit set state)", "rows": rows,
             "mostly_unique_keys": unique}
 

@@ -569,6 +569,7 @@ constexpr uint32_t kBlk32 = 16;                    // pairs of a block: what lea
 constexpr uint32_t kRing32 = 2 * kBlk32;           // pairs per bucket ring: two blocks
 constexpr uint32_t kBlkLanes = kBlk32 / 4;         // lanes that move a block (16 bytes each)
 constexpr uint32_t kBlkPerTrip = 64 / kBlkLanes;   // blocks a consumer wave moves at a time
+constexpr uint32_t kPoolChunk = 64;                // pool blocks a consumer wave takes with one device atomic (pool_tag_note)
 // (the block stores as non-temporal or write-through stores measured the same as plain ones: ± 0.03 ms of 1.9)
 constexpr uint32_t kGuard = 1024;                  // guard bytes (the lane that wrote last) per producer wave
 constexpr uint32_t kPair32Shift = 10;
@@ -606,11 +607,12 @@ template <int BLOG2, bool FUSE>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColumns c, uint64_t n, uint32_t tiles_per_wg,
                                                                       uint32_t *__restrict__ pairs, uint32_t *__restrict__ counts,
                                                                       uint32_t cap, unsigned long long *__restrict__ pool,
-                                                                      unsigned long long *__restrict__ pool_ctl,
+                                                                      uint64_t pool_pairs, unsigned long long *__restrict__ pool_ctl,
                                                                       uint32_t *__restrict__ pool_hist, FuseArgs fz)
 {
     constexpr uint32_t B = 1u << BLOG2;
     constexpr uint32_t RBITS = 32 - BLOG2;
+    uint32_t *pool_tags = reinterpret_cast<uint32_t *>(pool + pool_pairs);        // per pool block of 16 pairs: bucket + 1, or 0 (pool_tag_note)
     static_assert(RBITS == 32 - kPair32Shift, "a pair32 holds the hash bits below the bucket");
     static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
     extern __shared__ __attribute__((aligned(128))) uint32_t s_ring32[];           // B x kRing32 pairs
@@ -838,6 +840,14 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         constexpr uint32_t kChunks = B / (64u * kConsumers);
         const uint32_t cw = wave - (uint32_t)kProducers;
         uint32_t *list = s_list + cw * 64u;
+        // pool_tag_note.  Blocks of a full segment go to the pool, with what a pair32 leaves implicit spelled out.  The pool is
+        // handed out in CHUNKS of kPoolChunk blocks per consumer wave (one device atomic per chunk: with one per block, a
+        // batch of 40 hot keys spent 12 ms of pass 1 on 1.8 M atomics on ONE address), and every block of 16 pairs carries a
+        // tag — its bucket + 1 — so that kta_alive_fallback, which resolves a bucket, reads the tags (4 bytes per block) and
+        // only its own blocks (it read the whole pool, for every sub-range: 25 ms for those 40 keys).  Every block below the
+        // cursor gets a tag: what a wave leaves of its last chunk is tagged 0.  A bucket belongs to ONE consumer wave, whose
+        // pool positions ascend in time: among a segment's pool pairs the pool index still grows with the position.
+        uint32_t pc_next = 0, pc_end = 0;                                         // this wave's chunk, in blocks (wave-uniform)
         for (;;) {
             const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
             KTA_LDS_ORDER();
@@ -863,19 +873,37 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     KTA_LDS_ORDER();
                     const unsigned long long vm = __ballot(on && d.x != 0u && d.y != 0u && d.z != 0u && d.w != 0u);
                     const bool go = ((uint32_t)(vm >> (lane & ~(kBlkLanes - 1u))) & ((1u << kBlkLanes) - 1u)) == (1u << kBlkLanes) - 1u;   // all its pairs have arrived
+                    // the blocks of this trip whose segment is full: their places in the wave's chunk of the pool (pool_tag_note)
+                    const bool to_pool = go && (k + 1u) * kBlk32 > cap;
+                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(to_pool && piece == 0u);
+                    uint32_t pool_blk = 0;                                         // this block's place (its four lanes agree)
+                    if (pm != 0ull) {                                              // (wave-uniform)
+                        const uint32_t cnt = (uint32_t)__popcll(pm), room = pc_end - pc_next;
+                        const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << (lane & ~(kBlkLanes - 1u))) - 1ull));
+                        if (cnt > room) {                                          // what is left of the chunk, then a new one
+                            unsigned long long base = 0;
+                            if (lane == 0u) base = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kPoolChunk * kBlk32);
+                            const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base / kBlk32));
+                            pool_blk = rank < room ? pc_next + rank : nb + (rank - room);
+                            pc_next = nb + (cnt - room);
+                            pc_end = nb + kPoolChunk;
+                        } else {
+                            pool_blk = pc_next + rank;
+                            pc_next += cnt;
+                        }
+                    }
                     if (go) {
-                        if ((k + 1u) * kBlk32 <= cap) {
+                        if (!to_pool) {
                             const uint64_t at = ((uint64_t)bb * W + w) * cap + (uint64_t)k * kBlk32 + piece * 4u;
                             *reinterpret_cast<v4u *>(pairs + at) = (v4u){d.x, d.y, d.z, d.w};
-                        } else {                                                   // the segment is full: to the pool, with what a pair32 leaves implicit
-                            unsigned long long at_pool = 0;
-                            if (piece == 0u) {
-                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kBlk32);
-                                atomicAdd(&pool_hist[bb], kBlk32);
-                            }
-                            unsigned long long *dst = pool + __shfl(at_pool, (int)(lane & ~(kBlkLanes - 1u))) + piece * 4u;
+                        } else {
+                            unsigned long long *dst = pool + (uint64_t)pool_blk * kBlk32 + piece * 4u;
                             *reinterpret_cast<v2ull *>(dst) = (v2ull){pool_pair32(bb, d.x, w, RBITS), pool_pair32(bb, d.y, w, RBITS)};
                             *reinterpret_cast<v2ull *>(dst + 2) = (v2ull){pool_pair32(bb, d.z, w, RBITS), pool_pair32(bb, d.w, w, RBITS)};
+                            if (piece == 0u) {
+                                pool_tags[pool_blk] = bb + 1u;
+                                pool_hist[bb] = 1u;                                // (a flag: pass 2 leaves the bucket to the fallback kernel)
+                            }
                         }
                         *src = make_uint4(0u, 0u, 0u, 0u);
                         KTA_LDS_ORDER();
@@ -889,6 +917,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 __builtin_amdgcn_s_sleep(8);
             }
         }
+        for (uint32_t blk = pc_next + lane; blk < pc_end; blk += 64u) pool_tags[blk] = 0u;   // what is left of the last chunk holds nothing
     }
     if (FUSE) {                                        // the waves' extrema (the consumers' are the neutral elements)
         long long tmin = f_tmin, tmax = f_tmax, smin = (long long)f_smin, smax = (long long)f_smax, bad = (long long)f_bad;
@@ -945,11 +974,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                 uint32_t *dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * kBlk32;
                 for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring32[ring32_at(b, k * kBlk32 + q)];
             } else {
-                // an even number of pairs: the pool is read in 16-byte units (a zero pair is no pair)
-                unsigned long long *dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)((rem + 1u) & ~1u));
-                atomicAdd(&pool_hist[b], rem);
-                if (rem & 1u) dst[rem] = 0ull;
-                for (uint32_t q = 0; q < rem; q++) dst[q] = pool_pair32(b, s_ring32[ring32_at(b, k * kBlk32 + q)], w, RBITS);
+                // a whole pool block, padded (a zero pair is no pair); behind everything the consumers wrote (pool_tag_note)
+                const unsigned long long at = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kBlk32);
+                unsigned long long *dst = pool + at;
+                for (uint32_t q = 0; q < kBlk32; q++) dst[q] = q < rem ? pool_pair32(b, s_ring32[ring32_at(b, k * kBlk32 + q)], w, RBITS) : 0ull;
+                pool_tags[at / kBlk32] = b + 1u;
+                pool_hist[b] = 1u;
             }
         }
         counts[(uint64_t)b * W + w] = f < cap ? f : cap;
@@ -1698,7 +1728,7 @@ template <int BLOG2>
 __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32_t *__restrict__ pairs,
                                                                     const uint32_t *__restrict__ counts, uint32_t cap,
                                                                     uint32_t W, const unsigned long long *__restrict__ pool,
-                                                                    const unsigned long long *__restrict__ pool_ctl,
+                                                                    uint64_t pool_pairs, const unsigned long long *__restrict__ pool_ctl,
                                                                     const uint32_t *__restrict__ fail_from,
                                                                     uint32_t *__restrict__ bitmap,
                                                                     long long *__restrict__ running)
@@ -1712,7 +1742,42 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     if (pool_ctl[POOL_FAILED] == 0ull) return;
     const uint32_t b = blockIdx.x, from = fail_from[b];
     if (from == kNoFail) return;
-    const unsigned long long npool = pool_ctl[POOL_CURSOR];
+    // the pool in blocks of 16 pairs, each tagged with its bucket + 1 (pass 1: pool_tag_note): this bucket's blocks are found by
+    // their tags, four of which a thread has in flight
+    const uint32_t nblk = (uint32_t)(pool_ctl[POOL_CURSOR] / kBlk32);
+    const uint32_t *tags = reinterpret_cast<const uint32_t *>(pool + pool_pairs);
+    auto for_my_pool_pairs = [&](auto &&f) __attribute__((always_inline)) {      // f(pair, index in the pool)
+        // a wave looks at 4 x 64 tags at a time (the four loads in flight together) and reads the blocks that are this bucket's
+        // four at a time, sixteen lanes per block: one coalesced 128-byte read each
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        for (uint32_t b0 = wave * 256u; b0 < nblk; b0 += 256u * kApplyWaves) {
+            uint32_t t[4];
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; x++) {
+                const uint32_t blk = b0 + 64u * x + lane;
+                t[x] = tags[blk < nblk ? blk : b0];
+            }
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; x++) {
+                unsigned long long m = __builtin_amdgcn_ballot_w64(b0 + 64u * x + lane < nblk && t[x] == b + 1u);
+                while (m != 0ull) {                      // (wave-uniform) the next four of them
+                    uint32_t mine = 64u;                 // the block of this lane's group of sixteen: none
+#pragma unroll
+                    for (uint32_t g = 0; g < 4u; g++) {
+                        if (m == 0ull) break;
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        if ((lane >> 4) == g) mine = bit;
+                    }
+                    if (mine < 64u) {
+                        const unsigned long long k = (unsigned long long)(b0 + 64u * x + mine) * kBlk32 + (lane & 15u);
+                        const unsigned long long pr = pool[k];
+                        if (pr != 0ull) f(pr, k);
+                    }
+                }
+            }
+        }
+    };
     uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
     long long delta = 0;
     // What sends a bucket here is mostly a handful of hot keys (their pairs overflow the segments into the pool): its
@@ -1725,11 +1790,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
         const uint32_t *seg = pairs + ((uint64_t)b * W + w) * cap;
         for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) s_has[(seg[k] >> kPair32Shift) / kSub] = 1;
     }
-    for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
-        const unsigned long long pr = pool[k];
+    for_my_pool_pairs([&](unsigned long long pr, unsigned long long) {
         const uint32_t hh = (uint32_t)(pr >> 32);
-        if (pr != 0ull && (hh >> RBITS) == b && (((uint32_t)pr >> 9) & 1023u) >= from) s_has[(hh & ((1u << RBITS) - 1u)) / kSub] = 1;
-    }
+        if ((((uint32_t)pr >> 9) & 1023u) >= from) s_has[(hh & ((1u << RBITS) - 1u)) / kSub] = 1;
+    });
     __syncthreads();
     for (uint32_t r = 0; r < kRanges; r++) {
         if (!s_has[r]) continue;                         // (the same for every thread: read after the barrier)
@@ -1746,17 +1810,15 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
                 atomicMax(&s_max[h % kSub], (order << 1) | (p32 & 1u));
             }
         }
-        for (unsigned long long k = threadIdx.x; k < npool; k += kApplyThreads) {
-            const unsigned long long pr = pool[k];
+        for_my_pool_pairs([&](unsigned long long pr, unsigned long long k) {
             const uint32_t hh = (uint32_t)(pr >> 32), lo = (uint32_t)pr;
-            if (pr == 0ull || (hh >> RBITS) != b) continue;
             const uint32_t h = hh & ((1u << RBITS) - 1u);
-            if (h / kSub != r) continue;
+            if (h / kSub != r) return;
             const uint32_t w = (lo >> 9) & 1023u;
-            if (w < from) continue;                      // (an instalment that pass 2 finished held no pool pairs: never true)
+            if (w < from) return;                        // (an instalment that pass 2 finished held no pool pairs: never true)
             const unsigned long long order = ((unsigned long long)(w * 256u + ((lo >> 1) & 255u)) << 30) | (1ull << 29) | k;
             atomicMax(&s_max[h % kSub], (order << 1) | (lo & 1u));
-        }
+        });
         __syncthreads();
         for (uint32_t wd = threadIdx.x; wd < kSub / 32; wd += kApplyThreads) {
             uint32_t set_m = 0, clr_m = 0;
@@ -1836,7 +1898,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
             if (e != hipSuccess) return e;
             KTA_UB_MARK(0);
             hipLaunchKernelGGL((kta_alive_partition32<BLOG2, true>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
-                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist,
+                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, pl.pool_pairs, ctl, hist,
                                FuseArgs{fuse->partition, fuse->ts_ms, fuse->P, fuse->partials, fuse->row_len});
         } else {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2, false>),
@@ -1844,7 +1906,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
             if (e != hipSuccess) return e;
             KTA_UB_MARK(0);
             hipLaunchKernelGGL((kta_alive_partition32<BLOG2, false>), dim3(pl.segment_wgs), dim3(kPartThreads), lds0, s, c, n, pl.tiles_per_wg,
-                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, ctl, hist, FuseArgs{nullptr, nullptr, 0, nullptr, 0});
+                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, pl.pool_pairs, ctl, hist, FuseArgs{nullptr, nullptr, 0, nullptr, 0});
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1864,7 +1926,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, reinterpret_cast<const uint32_t *>(pp),
-                           ws.counts, pl.cap, pl.segment_wgs, pool, ctl, ws.fail_from, st.bitmap, run);
+                           ws.counts, pl.cap, pl.segment_wgs, pool, pl.pool_pairs, ctl, ws.fail_from, st.bitmap, run);
         KTA_UB_MARK(3);
         return hipGetLastError();
     }
@@ -1946,7 +2008,10 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
     pl.cap = (uint32_t)((mean + mean / 8 + 48 + 255) & ~255ull);
     pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap / (pair32 ? 2 : 1);
     pl.count_words = (uint64_t)pl.segment_wgs << pl.bucket_log2;
-    pl.pool_words = n + ((uint64_t)pl.segment_wgs << pl.bucket_log2);   // + one padding pair per segment tail
+    // the pool: at most one pair per record; + a padded block per segment tail; bit set state: + what the consumer waves
+    // leave of their last chunks (pool_tag_note), and behind the pairs one 4-byte tag per block of 16
+    pl.pool_pairs = ((n + 15) & ~15ull) + ((uint64_t)16 * pl.segment_wgs << pl.bucket_log2) + (uint64_t)kPoolChunk * kBlk32 * kConsumers * pl.segment_wgs;
+    pl.pool_words = pl.pool_pairs + (pair32 ? pl.pool_pairs / 32 + 1 : 0);
     pl.ctl_bytes = POOL_WORDS * 8 + ((size_t)4 << pl.bucket_log2) + 4;
     return pl;
 }

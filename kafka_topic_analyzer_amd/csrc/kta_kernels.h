@@ -110,7 +110,8 @@ struct AlivePartitionPlan {
     uint64_t max_records;   // records one launch pair takes (larger batches are sliced)
     uint64_t pair_words;    // u64 words of the pair workspace
     uint64_t count_words;   // u32 words of the segment-count workspace
-    uint64_t pool_words;    // u64 words of the pool (pairs whose segment was full)
+    uint64_t pool_pairs;    // pairs the pool takes (whose segment was full); bit set state: in blocks of 16, their tags behind them
+    uint64_t pool_words;    // u64 words of the pool's allocation
     uint64_t ctl_bytes;     // pool control words + pool histogram + order flag
 };
 struct AliveState {
