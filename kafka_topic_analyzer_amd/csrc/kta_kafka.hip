@@ -60,6 +60,9 @@ constexpr uint64_t kMaxBatchInflate = 512ull << 20;   // inflated size one batch
 // per wave with ONE parse round per window (an 8 KiB window holds ~31 records of the 256-byte mean).  The kernel is bound
 // by instruction issue (profiles/r04_sq_decode.txt): what wins is the geometry with the fewest rounds per byte that still
 // fills the SIMDs.  The losers' instantiations (and the prefetching form of the kernel) were deleted with their timings kept.
+// Two more were timed later in the round and not kept (another box; 2 / 8 / 16 / 32 / 134 KiB batches, ms): <2, 4 KiB, 32>
+// 0.147 / 0.136 / 0.146 / 0.153 / 0.183 and <4, 4 KiB, 16> 0.146 / 0.139 / 0.143 / 0.148 / 0.196 next to (10) 0.131 / 0.143 /
+// 0.147 / 0.159 / 0.229 and (11) 0.254 / 0.148 / 0.141 / 0.143 / 0.150: every geometry sits on the same plateau of 3.7-4.2 TB/s.
 int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 {
     if (forced) return forced;
