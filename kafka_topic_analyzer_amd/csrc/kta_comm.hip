@@ -238,6 +238,13 @@ int exchange_alive(kta_ctx *ctx, CommState *st)
         if (!any || attempt) break;
         if (send[n] != 0) listed = false;
     }
+    // (the second gather cannot carry a flag of this rank: a list that overflowed is not listed the second time, and sweeps
+    // raise none.  Should that ever change, a rank must not go on with counts that stop at the list's capacity: it would
+    // leave alive entries behind without a word — it fails instead, and kta_exchange aborts the communicator for its peers)
+    if (listed && send[n] != 0) {
+        kta_internal_set_error(ctx, "exchange: the written list still reports an overflow after the recount");
+        return KTA_ERR_INVALID;
+    }
     uint64_t send_total = 0, recv_total = 0;
     std::vector<uint64_t> send_at(n), recv_at(n);
     for (int r = 0; r < n; r++) {

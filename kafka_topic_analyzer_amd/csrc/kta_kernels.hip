@@ -1114,6 +1114,8 @@ __global__ __launch_bounds__(kWG) void kta_written_alive_count(WrittenList wl, c
 
 hipError_t launch_written_count(const WrittenList &wl, int nranks, uint64_t *counts, uint64_t *overflow, hipStream_t s)
 {
+    // (one LDS counter per owner: kta_comm.hip takes the sweeps — launch_alive_count_written_span / _export_span — for more
+    // than kMaxOwners ranks and never comes here with them)
     if (nranks > kMaxOwners) return hipErrorInvalidValue;
     // (the grid does not depend on the list's length, which only the device knows: 4 workgroups per CU walk it)
     hipLaunchKernelGGL(kta_written_count, dim3(1024), dim3(kWG), 0, s, wl, (uint32_t)nranks,
