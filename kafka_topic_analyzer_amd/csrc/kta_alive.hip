@@ -586,6 +586,41 @@ __device__ __forceinline__ unsigned long long pool_pair32(uint32_t bucket, uint3
     return ((unsigned long long)h << 32) | 0x80000000u | (w << 9) | (p32 & 0x1FFu);   // w, window, alive
 }
 
+#define KTA_LDS(T, off) (reinterpret_cast<__attribute__((address_space(3))) T *>(static_cast<uintptr_t>(off)))
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }   // (the low half of an LDS address is its offset)
+// The hot-key filter of a producer's step (see there), out of line.  guard_off: the wave's guard table (LDS byte offset); h0..h3:
+// the hashes of the lane's records of the instructions 0..3 of the tile; keyed: bit j = record j takes part.  Returns the
+// records that stay (bits 0..3) and, from bit 8, how many records of the wave were dropped (the same on every lane).
+__device__ __noinline__ uint32_t hot_filter(uint32_t guard_off, uint32_t lane, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t keyed)
+{
+    const uint32_t h[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((keyed >> j) & 1u) *KTA_LDS(uint8_t, guard_off + (h[j] & (kGuard - 1))) = (uint8_t)(lane | ((uint32_t)j << 6));
+        KTA_LDS_ORDER();
+    }
+    uint32_t last[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) last[j] = *KTA_LDS(const volatile uint8_t, guard_off + (h[j] & (kGuard - 1)));
+    KTA_LDS_ORDER();
+    uint32_t dropped = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t jl = last[j] >> 6;
+        const int at = (int)((last[j] & 63u) << 2);
+        uint32_t hh = 0;
+#pragma unroll
+        for (int j2 = j + 1; j2 < 4; j2++) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)h[j2]);
+            hh = jl == (uint32_t)j2 ? c : hh;
+        }
+        const bool gone = ((keyed >> j) & 1u) && jl > (uint32_t)j && hh == h[j];
+        dropped += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(gone));
+        keyed &= gone ? ~(1u << j) : ~0u;
+    }
+    return keyed | (dropped << 8);
+}
+
 // ---- both handlers in one pass over the batch (kafka.rs:107-109 calls every handler for every message) ----
 // With FUSE the producers also read partition and ts_ms (12 B more per record: 40 instead of 28 + 20 for two kernels) and do
 // what kta_metrics_scan does (MessageMetrics::handle_message, metric.rs:207-252), in the scan's own terms: per partition
@@ -724,6 +759,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             next_tile(tl, cols_b.win);
             load_cols32(tl, cols_b.win != 0u, cols_b);
             load_keys32(cols_a, keys_a);
+            bool hot = false;                                        // (wave-uniform) the last step dropped records: hot keys about
             auto step = [&](Cols &r, uint4 (&keys)[4], Cols &r_next, uint4 (&keys_next)[4]) __attribute__((always_inline)) {
                 uint32_t h[4];
                 if (__all(r.kl[0] == 16 && r.kl[1] == 16 && r.kl[2] == 16 && r.kl[3] == 16)) {
@@ -771,6 +807,21 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                     next_tile(tn, r.win);
                     load_cols32(tn, r.win != 0u, r);                 // r is spent: hashed
                 }
+                // ---- hot keys: a record whose hash comes again in a LATER instruction of this tile is superseded by that
+                // record — same wave, same window, a later position — and need not be inserted at all.  Only while the guard
+                // below has been dropping records (a compacted topic's instructions hold no two records of one key): the
+                // records write (instruction, lane) into the guard table in program order, read the last writer at their
+                // index back and fetch ITS hash (ds_bpermute); an equal hash from a later instruction drops the record.  What
+                // shares an index by chance is kept: the filter only ever drops what is certainly superseded.  With 40 hot
+                // keys a tile of 256 records leaves 40 pairs instead of about 130.
+                uint32_t dropped = 0;                                // (wave-uniform) records this step did not insert
+                if (hot) {                                           // (out of line: inlined, it cost the ordinary path 3 % of pass 1)
+                    const uint32_t km = (keyed[0] ? 1u : 0u) | (keyed[1] ? 2u : 0u) | (keyed[2] ? 4u : 0u) | (keyed[3] ? 8u : 0u);
+                    const uint32_t res = hot_filter(lds_offset(guard), lane, h[0], h[1], h[2], h[3], km);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) keyed[j] = (res >> j) & 1u;
+                    dropped = (uint32_t)__builtin_amdgcn_readfirstlane((int)(res >> 8));
+                }
                 // ---- the guard: among the records of one instruction, one record per hash (the newest) ----
                 uint32_t seen[4];
 #pragma unroll
@@ -793,7 +844,9 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                         todo &= ~grp;
                     }
                     ins[j] = keyed[j] && !((drop >> lane) & 1ull);
+                    dropped += (uint32_t)__popcll(drop);
                 }
+                hot = dropped >= 8u;                                 // (of 256: a tile of distinct keys drops none)
                 // ---- positions, then the pairs once their ring entries are free: straight-line, so that a lane's four
                 // LDS atomics and its four reads are in flight together ----
                 uint32_t bk[4], p[4], out[4];
@@ -1046,7 +1099,6 @@ __device__ __forceinline__ uint32_t entry_of_half(uint32_t ph) { return ((ph & 1
 // bit set reads its sub-table into registers).
 // Returns 0: merged into an entry that was there; 1: merged into an entry it claimed; 2: merged into the side table;
 // 3: the side table had no room either (the caller gives the attempt up, or takes the direct path).
-#define KTA_LDS(T, off) (reinterpret_cast<__attribute__((address_space(3))) T *>(static_cast<uintptr_t>(off)))
 __device__ __noinline__ uint32_t merge_new_slot(uint32_t lds_tag, uint32_t lds_val, uint32_t lds_ovf, uint32_t lds_ovf_n, uint32_t lds_any_ovf,
                                                uint32_t tagbits, uint32_t h, uint32_t lo)
 {
@@ -1095,7 +1147,6 @@ __device__ __noinline__ uint32_t merge_new_slot(uint32_t lds_tag, uint32_t lds_v
     }
     return 3;
 }
-__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }   // (the low half of an LDS address is its offset)
 
 struct ApplyShared {
     uint32_t pairs, claims, instalments, ovf_total;
@@ -1781,30 +1832,31 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     uint32_t *region = bitmap + ((size_t)b << (RBITS - 5));
     long long delta = 0;
     // What sends a bucket here is mostly a handful of hot keys (their pairs overflow the segments into the pool): its
-    // pairs then sit in very few of the 256 sub-ranges, and a pass reads ALL pairs of the bucket and the whole pool.
-    // One more walk first, to find the sub-ranges that hold anything (every writer writes the same 1: no atomic).
+    // pairs then sit in very few of the 256 sub-ranges, and a pass reads ALL pairs of the bucket (its segments and its pool
+    // blocks).  The first pass resolves the sub-range of the bucket's first pair — a hot key's, if there is one — and notes on
+    // the way which other sub-ranges hold anything (every writer writes the same 1: no atomic); one more pass for each of them.
+    __shared__ uint32_t s_first;
     for (uint32_t r = threadIdx.x; r < kRanges; r += kApplyThreads) s_has[r] = 0;
-    __syncthreads();
-    for (uint32_t w = from; w < W; w++) {
-        const uint32_t cnt = counts[(uint64_t)b * W + w];
-        const uint32_t *seg = pairs + ((uint64_t)b * W + w) * cap;
-        for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) s_has[(seg[k] >> kPair32Shift) / kSub] = 1;
+    for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0ull;
+    if (threadIdx.x == 0) {
+        uint32_t first = 0;
+        for (uint32_t w = from; w < W; w++)
+            if (counts[(uint64_t)b * W + w] != 0u) {
+                first = (pairs[((uint64_t)b * W + w) * cap] >> kPair32Shift) / kSub;
+                break;
+            }
+        s_first = first;
     }
-    for_my_pool_pairs([&](unsigned long long pr, unsigned long long) {
-        const uint32_t hh = (uint32_t)(pr >> 32);
-        if ((((uint32_t)pr >> 9) & 1023u) >= from) s_has[(hh & ((1u << RBITS) - 1u)) / kSub] = 1;
-    });
     __syncthreads();
-    for (uint32_t r = 0; r < kRanges; r++) {
-        if (!s_has[r]) continue;                         // (the same for every thread: read after the barrier)
-        for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0ull;
-        __syncthreads();
+    const uint32_t r_first = s_first;
+    auto walk = [&](uint32_t r, bool note) __attribute__((always_inline)) {      // the newest pair of every slot of sub-range r
         for (uint32_t w = from; w < W; w++) {
             const uint32_t cnt = counts[(uint64_t)b * W + w];
             const uint32_t *seg = pairs + ((uint64_t)b * W + w) * cap;
             for (uint32_t k = threadIdx.x; k < cnt; k += kApplyThreads) {
                 const uint32_t p32 = seg[k];
                 const uint32_t h = p32 >> kPair32Shift;
+                if (note) s_has[h / kSub] = 1;
                 if (h / kSub != r) continue;
                 const unsigned long long order = ((unsigned long long)(w * 256u + ((p32 >> 1) & 255u)) << 30) | k;
                 atomicMax(&s_max[h % kSub], (order << 1) | (p32 & 1u));
@@ -1813,18 +1865,23 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
         for_my_pool_pairs([&](unsigned long long pr, unsigned long long k) {
             const uint32_t hh = (uint32_t)(pr >> 32), lo = (uint32_t)pr;
             const uint32_t h = hh & ((1u << RBITS) - 1u);
-            if (h / kSub != r) return;
             const uint32_t w = (lo >> 9) & 1023u;
             if (w < from) return;                        // (an instalment that pass 2 finished held no pool pairs: never true)
+            if (note) s_has[h / kSub] = 1;
+            if (h / kSub != r) return;
             const unsigned long long order = ((unsigned long long)(w * 256u + ((lo >> 1) & 255u)) << 30) | (1ull << 29) | k;
             atomicMax(&s_max[h % kSub], (order << 1) | (lo & 1u));
         });
-        __syncthreads();
+    };
+    auto apply_range = [&](uint32_t r) __attribute__((always_inline)) {          // ... into the bit set; leaves s_max empty
         for (uint32_t wd = threadIdx.x; wd < kSub / 32; wd += kApplyThreads) {
             uint32_t set_m = 0, clr_m = 0;
             for (uint32_t bit = 0; bit < 32; bit++) {
                 const unsigned long long v = s_max[wd * 32 + bit];
-                if (v) (v & 1ull ? set_m : clr_m) |= 1u << bit;
+                if (v) {
+                    (v & 1ull ? set_m : clr_m) |= 1u << bit;
+                    s_max[wd * 32 + bit] = 0ull;
+                }
             }
             if (set_m | clr_m) {
                 uint32_t *word = region + (size_t)r * (kSub / 32) + wd;
@@ -1833,6 +1890,16 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
                 delta += (long long)__popc(neu) - (long long)__popc(old);
             }
         }
+    };
+    walk(r_first, true);
+    __syncthreads();
+    apply_range(r_first);
+    __syncthreads();
+    for (uint32_t r = 0; r < kRanges; r++) {
+        if (r == r_first || !s_has[r]) continue;         // (the same for every thread: s_has is not written any more)
+        walk(r, false);
+        __syncthreads();
+        apply_range(r);
         __syncthreads();
     }
     add_running(delta, running, s_w);
