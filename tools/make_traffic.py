@@ -108,10 +108,10 @@ rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false>", "kta_alive_
                "+ the written list")
 print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
-f, w = find("kafka_decode_coop<4, 2048u, 16u>", "FETCH_SIZE", True), find("kafka_decode_coop<4, 2048u, 16u>", "WRITE_SIZE", True)
+f, w = find("kafka_decode_coop<2, 8192u, 32u>", "FETCH_SIZE", True), find("kafka_decode_coop<2, 8192u, 32u>", "WRITE_SIZE", True)
 raw_log = 1075251127                          # bytes of the 4 M-record raw log bench.py's kafka_decode.roofline describes
 rd, wr = 2 * f[1] * KIB, w[1] * KIB
-out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<4, 2048u, 16u>", "records_per_launch": 4000000,
+out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<2, 8192u, 32u>", "records_per_launch": 4000000,
                             "algorithmic_bytes_per_launch": raw_log, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                             "ratio_to_algorithmic": (rd + wr) / raw_log,
