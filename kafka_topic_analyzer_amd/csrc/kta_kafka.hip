@@ -56,7 +56,7 @@ constexpr uint64_t kMaxBatchInflate = 512ull << 20;   // inflated size one batch
 //   <2, 8 KiB, 32>   (11)  0.253    0.141    0.149      128 / 64 records per round: 0.147 / 0.147 and 0.163 / 0.161;
 //                                                       with the next window prefetched into registers: 0.155 / 0.148 and 0.160 / 0.158
 //   <1, 8 KiB, 256>  (2)   0.283    0.142    0.154      <4, 8 KiB, 128>: 0.306 / 0.194 / 0.205
-// Sharing a wave between four batches pays while the batches are smaller than an 8 KiB window; from there on two batches
+// Sharing a wave between four batches pays while the batches are smaller than about 20 KiB; from there on two batches
 // per wave with ONE parse round per window (an 8 KiB window holds ~31 records of the 256-byte mean).  The kernel is bound
 // by instruction issue (profiles/r04_sq_decode.txt): what wins is the geometry with the fewest rounds per byte that still
 // fills the SIMDs.  The losers' instantiations (and the prefetching form of the kernel) were deleted with their timings kept.
@@ -68,7 +68,9 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
     if (forced) return forced;
     if (n_batches < 2048) return 2;            // few batches: one wave each
     const uint64_t mean = blob_len / n_batches;
-    return mean < 8192 ? 10 : 11;
+    // (with the chain's unaligned LDS reads — five instructions less per step — the two meet between 16 and 24 KiB: 8 KiB batches
+    // 0.132 / 0.148 ms, 16 KiB 0.136 / 0.139, 24 KiB 0.138 / 0.136, 32 KiB 0.153 / 0.136; profiles/r05_decode_geometries_3.jsonl)
+    return mean < 20480 ? 10 : 11;
 }
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>

@@ -73,6 +73,20 @@ KTA_REC_HD bool window_varlong(const uint8_t *win, uint32_t &off, uint32_t limit
     return false;
 }
 
+// The four bytes at byte offset `off` of the window.  On the device ONE LDS read at the bytes' own address (gfx950's LDS takes
+// unaligned dword reads: the compiler emits ds_read_b32 for the 4-byte copy), on the host the two dwords that hold them.
+KTA_REC_HD uint32_t window_bytes4(const uint32_t *w32, uint32_t off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t v;
+    __builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(w32) + off, 4);
+    return v;
+#else
+    const uint32_t i = off >> 2;
+    return bytes4(w32[i], w32[i + 1], off);
+#endif
+}
+
 // The leader's chain: from `cur`, follow the length prefixes while they are ordinary — one or two bytes (a record below
 // 8 KiB; a longer one does not fit a window, so the round ends with it anyway), all four bytes at `cur` inside the
 // window — and publish the record starts; at most `want` records in all (k counts them).
@@ -89,9 +103,8 @@ KTA_REC_HD bool chain(const uint32_t *w32, uint32_t limit, uint32_t want, uint32
     constexpr uint32_t LONG = 0x80000000u;           // `cur` in front of a long one: beyond every `last`
     bool go = (k < want) & (cur <= last);
     while (go) {                                     // one block, one branch: the leaders of a wave run it in step
-        const uint32_t i = cur >> 2;
         uint32_t nb, v;
-        const bool ordinary = varint2(bytes4(w32[i], w32[i + 1], cur), nb, v);
+        const bool ordinary = varint2(window_bytes4(w32, cur), nb, v);
         starts[k] = cur;                             // (k < want: inside the array; it stays only if k moves on)
         k += ordinary ? 1u : 0u;
         cur = ordinary ? cur + nb + (v >> 1) : LONG; // < 2^13 + 2 + 2^13: no overflow, whatever the bytes
@@ -132,9 +145,15 @@ KTA_REC_HD uint32_t parse_record(const uint8_t *win, uint32_t start, uint32_t re
     uint32_t off = 0;
     bool head = false;
     {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t a012[3];                            // the twelve bytes at `start`, at their own address (see window_bytes4)
+        __builtin_memcpy(a012, win + start, 12);
+        const uint32_t a0 = a012[0], a1 = a012[1], a2 = a012[2];
+#else
         const uint32_t i0 = start >> 2;
         const uint32_t d0 = w32[i0], d1 = w32[i0 + 1], d2 = w32[i0 + 2], d3 = w32[i0 + 3];
         const uint32_t a0 = bytes4(d0, d1, start), a1 = bytes4(d1, d2, start), a2 = bytes4(d2, d3, start);
+#endif
         uint32_t nbl, len;
         bool ok = varint4(a0, nbl, len) && nbl <= 3u && !(len & 1u);           // (a negative length: the long way says so)
         const uint32_t skip = 8u * ((nbl <= 3u ? nbl : 3u) + 1u);           // the length and the attributes byte: 16..32 bits
@@ -171,9 +190,8 @@ KTA_REC_HD uint32_t parse_record(const uint8_t *win, uint32_t start, uint32_t re
     const uint32_t voff = off + (r.key_len > 0 ? (uint32_t)r.key_len : 0u);   // < 2^32: off <= limit, a window
     if (voff >= rec_end) return REC_BAD;                                    // the key overruns the record
     if (voff < limit) {
-        const uint32_t i = voff >> 2;
         uint32_t nb, v;
-        if (varint4(bytes4(w32[i], w32[i + 1], voff), nb, v) && voff + nb <= limit) {
+        if (varint4(window_bytes4(w32, voff), nb, v) && voff + nb <= limit) {
             r.val_len = unzigzag32(v);
             r.after = voff + nb;
             return value_fits(r.val_len, r.after, rec_end);
