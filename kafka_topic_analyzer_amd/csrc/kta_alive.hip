@@ -1407,7 +1407,11 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // take — every bucket went to kta_alive_fallback, 137 ms for the batch (round 4).  Bit set state: gs segments per
     // group, the largest power of two whose fullest group holds at most 10 k pairs (at most 5 per set on average: the
     // 8-way sets and the side table hold that with room to spare), found from the segment fills when the workgroup
-    // enters careful mode (pick_group_size); the waves gs ... 15 then only keep the barriers company.
+    // enters careful mode (pick_group_size); the waves gs ... 15 then only keep the barriers company.  (Measured and dropped in
+    // round 5: groups of at most 4 k pairs shared by all sixteen waves, so that the table fills to its three quarters before
+    // it is emptied — 22 instead of 32 instalments on config 5's law, 7.8 instead of 8.1 ms; but with the table that full a
+    // compacted topic of 20 M keys sent 12 of its 1024 buckets to the fallback kernel, 26 instead of 7.6 ms: the forecast is
+    // only safe with room to spare.)
     const uint32_t groups16 = (W + kApplyWaves - 1) / kApplyWaves, units16 = groups16 * chunks;
     uint32_t gs_c = kApplyWaves, units_c = units16;      // bit set state, careful mode: set by pick_group_size
 #define KTA_GS (BITMAP ? gs_c : (uint32_t)kApplyWaves)      /* segments of a group; units of a wave's walk (the same for every wave) */
