@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         if (pool_hist[b] != 0u) {
             if (threadIdx.x == 0) {
                 fail_from[b] = 0u;
-                atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
+                fail_from[(1u << BLOG2) + (uint32_t)atomicAdd(&pool_ctl[POOL_FAILED], 1ull)] = b;   // (the list of such buckets: kta_alive_fallback)
             }
             return;
         }
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 if (BITMAP) {                            // handed to kta_alive_fallback from this instalment on
                     if (threadIdx.x == 0) {
                         fail_from[b] = inst_start;
-                        atomicAdd(&pool_ctl[POOL_FAILED], 1ull);
+                        fail_from[(1u << BLOG2) + (uint32_t)atomicAdd(&pool_ctl[POOL_FAILED], 1ull)] = b;
                     }
                     // (the instalments before this one ARE applied: what they changed belongs to the running count.  Round 5:
                     // this path returned without it, and a bucket that gave up after its first instalment left sum_all_alive
@@ -1785,6 +1785,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
                                                                     uint32_t W, const unsigned long long *__restrict__ pool,
                                                                     uint64_t pool_pairs, const unsigned long long *__restrict__ pool_ctl,
                                                                     const uint32_t *__restrict__ fail_from,
+                                                                    const uint32_t *__restrict__ pool_hist,
                                                                     uint32_t *__restrict__ bitmap,
                                                                     long long *__restrict__ running)
 {
@@ -1794,9 +1795,22 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     extern __shared__ __attribute__((aligned(128))) unsigned long long s_max[];   // kSub values: order << 1 | alive
     __shared__ long long s_w[kApplyWaves];
     __shared__ uint8_t s_has[kRanges];                   // the sub-ranges that hold a pair at all
-    if (pool_ctl[POOL_FAILED] == 0ull) return;
-    const uint32_t b = blockIdx.x, from = fail_from[b];
-    if (from == kNoFail) return;
+    // One workgroup per bucket is launched; the buckets to resolve are few (pass 2 lists them behind fail_from's B words), so
+    // they share the workgroups: each gets B / (their number) of them, 32 at most.  A bucket with pool pairs is a hot-key
+    // bucket — its pairs sit in one or a few sub-ranges — and ONE of its workgroups resolves it; a bucket without, one that
+    // careful mode gave up, holds pairs in all 256 sub-ranges, a pass over all its pairs for each: its workgroups share the
+    // sub-ranges (twelve such buckets took 20 ms with one workgroup each while 244 CUs idled).
+    const uint32_t nfail = (uint32_t)pool_ctl[POOL_FAILED];
+    if (nfail == 0u) return;
+    constexpr uint32_t B = 1u << BLOG2;
+    uint32_t share = B / (nfail < B ? nfail : B);
+    share = share > 32u ? 32u : share;
+    const uint32_t which = blockIdx.x / share, part = blockIdx.x % share;
+    if (which >= nfail) return;
+    const uint32_t b = fail_from[B + which], from = fail_from[b];
+    if (from == kNoFail) return;                         // (never: the list holds the buckets that were given up)
+    const uint32_t nparts = pool_hist[b] != 0u ? 1u : share;
+    if (part >= nparts) return;
     // the pool in blocks of 16 pairs, each tagged with its bucket + 1 (pass 1: pool_tag_note): this bucket's blocks are found by
     // their tags, four of which a thread has in flight
     const uint32_t nblk = (uint32_t)(pool_ctl[POOL_CURSOR] / kBlk32);
@@ -1897,10 +1911,14 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     };
     walk(r_first, true);
     __syncthreads();
-    apply_range(r_first);
+    if (r_first % nparts == part) {
+        apply_range(r_first);
+    } else {                                             // (another workgroup's: only the notes were wanted)
+        for (uint32_t e = threadIdx.x; e < kSub; e += kApplyThreads) s_max[e] = 0ull;
+    }
     __syncthreads();
     for (uint32_t r = 0; r < kRanges; r++) {
-        if (r == r_first || !s_has[r]) continue;         // (the same for every thread: s_has is not written any more)
+        if (r == r_first || !s_has[r] || r % nparts != part) continue;   // (the same for every thread: s_has is not written any more)
         walk(r, false);
         __syncthreads();
         apply_range(r);
@@ -1997,7 +2015,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, reinterpret_cast<const uint32_t *>(pp),
-                           ws.counts, pl.cap, pl.segment_wgs, pool, pl.pool_pairs, ctl, ws.fail_from, st.bitmap, run);
+                           ws.counts, pl.cap, pl.segment_wgs, pool, pl.pool_pairs, ctl, ws.fail_from, hist, st.bitmap, run);
         KTA_UB_MARK(3);
         return hipGetLastError();
     }

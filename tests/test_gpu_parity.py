@@ -516,6 +516,46 @@ def test_adversarial_alive_shapes_at_scale(hc, ht, state, shape, log2n):
     assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
 
 
+def test_bucket_given_up_in_careful_mode_is_resolved_exactly(hc):
+    """A bucket WITHOUT pool pairs that pass 2 gives up in careful mode — not a hot key's bucket (those overflow their segments
+    into the pool), but one whose table overflows: 2 000 keys whose hashes fall into ONE slice of 128 sets of one bucket
+    (2^18 consecutive slots; a slice holds 128 x 8 entries + 128 in its side table), all of them in the first sixteenth of the
+    batch, i.e. in the first group of segments, among random keys.  The fast attempt fails, careful mode's first group
+    fails, and kta_alive_fallback resolves the bucket from its first segment on, its workgroups sharing the 256 sub-ranges
+    (the library's counter says that exactly one bucket went there).  Count and every bit against the oracle; twice, the
+    second batch on top of what the first left (/root/reference/src/metric.rs:289-304: the order decides)."""
+    n = 1 << 24
+    rng = np.random.default_rng(4242)
+    want_prefix = (0x155 << 4) | 7                       # hash >> 18: bucket 0x155, slice 7
+    special = np.zeros((0, 16), np.uint8)
+    while len(special) < 2000:
+        cand = rng.integers(0, 256, size=(4_000_000, 16), dtype=np.uint8)
+        special = np.concatenate([special, cand[(_fnv32_np(cand) >> 18) == want_prefix]])
+    special = special[:2000]
+    assert fnv32(special[0].tobytes()) >> 18 == want_prefix
+    pool_keys = rng.integers(0, 256, size=(1 << 20, 16), dtype=np.uint8)        # the ordinary keys
+    keys = pool_keys[rng.integers(0, len(pool_keys), size=n)]
+    where = rng.choice(n // 16 - 1000, size=4000, replace=False)                 # every special key twice, in the first group's records
+    keys[where] = special[np.arange(4000) % 2000]
+    cols = {"partition": rng.integers(0, 64, size=n).astype(np.int32), "key_len": np.full(n, 16, np.int32),
+            "val_len": np.where(rng.random(n) < 0.4, -1, 100).astype(np.int32),
+            "ts_ms": np.full(n, 1_600_000_000_000, np.int64), "key_off": (np.arange(n, dtype=np.uint64) * 16).astype(np.uint32),
+            "key_bytes": keys.reshape(-1), "n_key_bytes": 16 * n}
+    o = Oracle(NOW, True)
+    hc.reset()
+    b, nb = hc.upload_batch(cols, with_keys=True)
+    for k in range(2):
+        o.run_soa(cols)
+        hc.submit_device(b, nb, k * nb, which=2)
+        hc.sync()
+    info = hc.alive_pass_info()
+    res, _ = hc.finish()
+    hc.device_batch_free(b)
+    assert info["failed_buckets"] == 2, info             # one bucket, in either batch
+    assert res.alive_keys == o.alive_keys()
+    assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+
+
 def test_max_partitions_uses_large_dynamic_lds():
     P = 4096  # 96 KiB of LDS partials per workgroup
     rng = np.random.default_rng(41)
