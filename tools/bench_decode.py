@@ -29,13 +29,14 @@ ap.add_argument("--rpb", default="8,60,500", help="records per batch: 8 ~2 KiB, 
 ap.add_argument("--variants", default="0")
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--lib", default="")
+ap.add_argument("--val-mean", type=int, default=0, help="mean value length of the records (0: the c4 law's 208 B); e.g. 10240 with --rpb 6 --records 100000: records of ~10 KiB, whose 3-byte length prefixes the chain leaves to the byte loop")
 args = ap.parse_args()
 
 libs = [l for l in args.lib.split(",") if l]
 if len(libs) > 1:
     for l in libs:
         argv = [sys.executable, os.path.abspath(__file__), "--records", str(args.records), "--rpb", args.rpb,
-                "--variants", args.variants, "--reps", str(args.reps), "--lib", l]
+                "--variants", args.variants, "--reps", str(args.reps), "--lib", l, "--val-mean", str(args.val_mean)]
         subprocess.run(argv, check=False)
     sys.exit(0)
 
@@ -47,6 +48,9 @@ import kafka_topic_analyzer_amd as kta  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 lib = N.load()
 spec, _ = kta.synth_preset("c4")
+if args.val_mean:
+    spec.val_mean = args.val_mean
+    spec.val_cap = max(int(spec.val_cap), 8 * args.val_mean)
 n = args.records
 ref = kta.synth_fill_host(spec, 0, min(n, 1 << 18))
 h = kta.HipMetricHandler(256)
@@ -82,7 +86,7 @@ for rpb in [int(x) for x in args.rpb.split(",")]:
         h.set_timing(False)
         cols = h.download_batch(out, len(ref["partition"]))
         ok = all(np.array_equal(cols[k], ref[k]) for k in ("key_len", "val_len", "ts_ms"))
-        print(json.dumps({"lib": os.path.basename(N.LIB_PATH), "records_per_batch": rpb, "variant": variant,
+        print(json.dumps({"lib": os.path.basename(N.LIB_PATH), "records_per_batch": rpb, "variant": variant, "val_mean": int(spec.val_mean),
                           "batches": int(st.n_batches), "raw_log_bytes": int(ln.value), "kernel_ms": round(a[1], 4),
                           "launches": int(c[1]), "GBps": round(ln.value / (a[1] * 1e-3) / 1e9, 1),
                           "frac": round(ln.value / (a[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "columns_ok": bool(ok)}),
