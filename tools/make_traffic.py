@@ -108,15 +108,21 @@ rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false>", "kta_alive_
                "+ the written list")
 print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
-f, w = find("kafka_decode_coop<2, 8192u, 32u>", "FETCH_SIZE", True), find("kafka_decode_coop<2, 8192u, 32u>", "WRITE_SIZE", True)
+# the 4 M-record launch of ~16 KiB batches: 66 667 batches x 16 lanes -> grid 1 066 688; batches below 20 KiB take <4, 3 KiB, 16>
+# (kta_kafka.hip: pick_geometry) — the row is found by that grid size, whichever geometry served it
+DECODE_GRID = 1066688
+hits = sorted({k for (k, c) in rows if "kafka_decode_coop<" in k and "grid=%d" % DECODE_GRID in k})
+assert len(hits) == 1, hits
+decode_kernel = re.search(r"kafka_decode_coop<[^>]*>", hits[0]).group(0)
+f, w = rows[(hits[0], "FETCH_SIZE")], rows[(hits[0], "WRITE_SIZE")]
 raw_log = 1075251127                          # bytes of the 4 M-record raw log bench.py's kafka_decode.roofline describes
 rd, wr = 2 * f[1] * KIB, w[1] * KIB
-out["kafka_decode_coop"] = {"kernel": "kafka_decode_coop<2, 8192u, 32u>", "records_per_launch": 4000000,
+out["kafka_decode_coop"] = {"kernel": decode_kernel, "records_per_launch": 4000000,
                             "algorithmic_bytes_per_launch": raw_log, "FETCH_SIZE_kib_avg": f[1], "WRITE_SIZE_kib_avg": w[1],
                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                             "ratio_to_algorithmic": (rd + wr) / raw_log,
-                            "note": "rows are per launch size (the summary carries grid sizes): the largest grid = the 4 M-record / "
-                                    "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them" % f[0],
+                            "note": "rows are per launch size (the summary carries grid sizes): grid %d = the 4 M-record / "
+                                    "1.075 GB launches bench.py's kafka_decode.roofline describes, %d of them" % (DECODE_GRID, f[0]),
                             **src("kafka_topic_analyzer_amd/csrc/kta_kafka.hip+kafka_topic_analyzer_amd/csrc/kta_decode_coop.h+"
                                   "kafka_topic_analyzer_amd/csrc/kta_records.h")}
 print("decode: read %.3f GB + wrote %.3f GB vs raw log %.3f GB" % (rd / 1e9, wr / 1e9, raw_log / 1e9), file=sys.stderr)
