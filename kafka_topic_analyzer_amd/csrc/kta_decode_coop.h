@@ -50,6 +50,49 @@ __device__ __forceinline__ void pin(uint4 &v)
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
+// ---- experiment switches (template parameter X of the kernel; X = 0 is the product) ----------------------------
+// Timed side by side through kta_kafka_set_variant(100 + X / 200 + X) in a build with -DKTA_DECODE_EXPERIMENTS
+// (tools/build_variant.sh); the product build instantiates X = 0 only.
+#ifdef KTA_DEC_STATS
+unsigned long long kta_dec_stats[4];   // (emulator only) rounds, rounds on prefetched blocks, prefetches not taken
+#endif
+enum : uint32_t {
+    DX_NT_LOAD = 1,      // window loads non-temporal (the log is read once)
+    DX_ALIGN128 = 2,     // window bases on 128-byte lines instead of 16-byte blocks
+    DX_NT_STORE = 4,     // column stores non-temporal
+    DX_LOAD_ONLY = 8,    // ablation: windows streamed through LDS, nothing else (columns are not written)
+    DX_NO_STORE = 16,    // ablation: everything but the column stores
+    DX_NO_PARSE = 32,    // ablation: loads and chain only
+    DX_PF_EARLY = 64,    // the blocks behind the window are sent for before the chain (in registers while the round runs)
+    DX_PF_LATE = 128,    // the next window is sent for when the chain knows where it begins, before the parse
+    DX_LOAD_1K = 256     // a load instruction of the wave reads 1 KiB of ONE window (all 64 lanes), not 256 bytes of each of four
+};
+#ifndef KTA_READLANE   // (tests/native/wave_emu.h: a meeting point)
+#define KTA_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
+#endif
+
+template <bool NT>
+__device__ __forceinline__ uint4 load_block(const uint8_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+#endif
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+template <bool NT, class T>
+__device__ __forceinline__ void store_col(T *p, T v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+
 // ---- wave-cooperative decode: G batches per wave ---------------------------------------------------
 // The lane-per-batch walk (kafka_decode, kta_kafka.hip) is latency bound (one dependent HBM round trip per varint) and has
 // only as many active lanes as there are batches.  Here a group of L = 64/G lanes owns one batch:
@@ -74,7 +117,7 @@ __device__ __forceinline__ void pin(uint4 &v)
 #ifndef KTA_WAVES_PER_EU   // (tests/native/wave_emu.h defines it away: a host compiler does not parse the attribute)
 #define KTA_WAVES_PER_EU(least, most) __attribute__((amdgpu_waves_per_eu(least, most)))
 #endif
-template <int G, uint32_t W, uint32_t R>   // batches per wave, window bytes, records per round of a group
+template <int G, uint32_t W, uint32_t R, uint32_t X = 0>   // batches per wave, window bytes, records per round of a group, experiment switches
 __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                    uint64_t n_batches, int want_keys, int32_t *part,
                                                    int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
@@ -86,6 +129,12 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
     constexpr uint32_t NLOAD = W / (L * 16);      // staged 16-byte loads per lane and window
     constexpr uint32_t NT = R / L;                // parse rounds per window
     static_assert(W % (L * 16) == 0 && R % L == 0, "window geometry");
+    constexpr bool NTL = (X & DX_NT_LOAD) != 0, NTS = (X & DX_NT_STORE) != 0;
+    constexpr bool PFE = (X & DX_PF_EARLY) != 0, PFL = (X & DX_PF_LATE) != 0, PF = PFE || PFL;
+    constexpr uint64_t AMASK = (X & DX_ALIGN128) ? 127ull : 15ull;   // a window begins on a block / on a line
+    constexpr bool C1K = (X & DX_LOAD_1K) != 0;
+    static_assert(!C1K || (W % 1024 == 0 && !PF), "1 KiB loads: whole KiB windows, no prefetch");
+    static_assert(!(PFE && PFL) && W % 128 == 0 || !(X & (DX_ALIGN128 | DX_PF_EARLY | DX_PF_LATE)), "experiment switches");
     __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the register paths read whole dwords up to 16 bytes ahead
     __shared__ uint32_t s_start[G][R + 1];        // record starts relative to the window base; [found]: where the last one ends
     __shared__ uint64_t s_next[G];                // absolute position after the last chained record
@@ -109,34 +158,101 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
         bad = d.status != 0;                              // failed check.crcs or inflate: the batch is not delivered
     }
     bool run = !bad && j < total;                         // uniform inside a group
+    // (PF) the blocks sent for during the last round, the base of the window they belong to (none: ~0), and how far into them a
+    // round may begin (early form: they lie behind the window, the next record begins somewhere in them)
+    constexpr uint32_t OV = W >= 256 ? (W / 4) & ~127u : 16u;
+    uint4 ahead[PF ? NLOAD : 1];
+#pragma unroll
+    for (uint32_t u = 0; u < (PF ? NLOAD : 1); u++) ahead[u] = make_uint4(0, 0, 0, 0);   // (uninitialised, the array stays in scratch)
+    uint64_t pf_base = ~0ull;
     while (__any(run)) {
         uint64_t wbase = 0;
         uint32_t limit = 0, end_rel = 0;                  // valid bytes in the window; the batch's end seen from its base
         bool to_the_end = false;                          // the window reaches the end of the batch
+        bool fetched = false;                             // (PF) the window is the one the last round sent for
+        uint32_t c1k_bytes = 16;                          // (C1K) this group's window as the whole wave loads it: base and bytes
+        uint64_t c1k_base = 0;
         if (run && pos >= end) { bad = true; run = false; }
         if (run) {
-            wbase = pos & ~15ull;
+            wbase = pos & ~AMASK;
+            if (PFE) {
+                fetched = pf_base <= wbase && wbase - pf_base <= OV;
+                if (fetched) wbase = pf_base;
+            }
+            if (PFL) fetched = pf_base == wbase;
+#ifdef KTA_DEC_STATS
+            if (sub == 0) { kta_dec_stats[0]++; kta_dec_stats[1] += fetched; kta_dec_stats[2] += pf_base != ~0ull && !fetched; }
+#endif
             const uint64_t span = ((end + 15) & ~15ull) - wbase, rest = end - wbase;
             const uint32_t wbytes = span < W ? (uint32_t)span : W;         // a multiple of 16, at least 16
             to_the_end = rest <= wbytes;
             limit = to_the_end ? (uint32_t)rest : wbytes;
             end_rel = rest < 0xF0000000ull ? (uint32_t)rest : 0xF0000000u;
-            // all loads of the window are in flight together; a lane behind the batch's last block loads that block
-            // again and stores it where its own would go — bytes at and behind `limit`, which decide nothing
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + wbase;
+            if (C1K) {
+                c1k_base = wbase; c1k_bytes = wbytes;
+            } else if (!fetched) {
+                // all loads of the window are in flight together; a lane behind the batch's last block loads that block
+                // again and stores it where its own would go — bytes at and behind `limit`, which decide nothing
+                const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + wbase;
+                uint4 stage[NLOAD];
+#pragma unroll
+                for (uint32_t u = 0; u < NLOAD; u++) {
+                    const uint32_t o = (sub + u * L) * 16;
+                    stage[u] = load_block<NTL>(src + (o < wbytes - 16 ? o : wbytes - 16));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = stage[u];
+            } else if (PF) {                              // (its own registers and stores: no copies between the two ways)
+#pragma unroll
+                for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = ahead[u];
+            }
+            if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
+        }
+        if (C1K) {
+            // every lane takes part in every group's window: W / 1024 instructions of 1 KiB each per group (a group that does not
+            // run reads the blob's first block into its own window)
+            constexpr uint32_t PER = W / 1024;
             uint4 stage[NLOAD];
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) {
-                const uint32_t o = (sub + u * L) * 16;
-                stage[u] = *reinterpret_cast<const uint4 *>(src + (o < wbytes - 16 ? o : wbytes - 16));
+                const uint32_t gg = u / PER, c = u % PER;
+                const uint64_t gb = (uint64_t)KTA_READLANE((uint32_t)c1k_base, gg * L) | ((uint64_t)KTA_READLANE((uint32_t)(c1k_base >> 32), gg * L) << 32);
+                const uint32_t gbytes = KTA_READLANE(c1k_bytes, gg * L);
+                const uint32_t o = (c * 64 + lane) * 16;
+                stage[u] = load_block<NTL>(reinterpret_cast<const uint8_t *>(blocks) + gb + (o < gbytes - 16 ? o : gbytes - 16));
             }
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
 #pragma unroll
-            for (uint32_t u = 0; u < NLOAD; u++) s_win[g][sub + u * L] = stage[u];
-            if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
+            for (uint32_t u = 0; u < NLOAD; u++) s_win[u / PER][(u % PER) * 64 + lane] = stage[u];
         }
         __syncthreads();
+        if (X & DX_LOAD_ONLY) {                           // ablation: the window is in LDS; on to the next one
+            if (run) {
+                kb += s_win[g][sub].x;
+                pos = wbase + limit;
+                run = !to_the_end;
+            }
+            __syncthreads();
+            continue;
+        }
+        if (PFE) {
+            // Every lane issues the loads, wanted or not (a group that is done or at its batch's end reads the blob's
+            // first block): loads under a condition would merge with the old registers through copies, and a copy
+            // waits for its load.
+            const bool want = run && !to_the_end;         // (the window is full: W bytes, and the batch goes on behind it)
+            pf_base = want ? wbase + W : ~0ull;
+            const uint64_t from = want ? pf_base : 0ull, span = want ? ((end + 15) & ~15ull) - pf_base : 16ull;
+            const uint32_t wbytes = span < W ? (uint32_t)span : W;             // as the round that takes them computes it
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + from;
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) {
+                const uint32_t o = (sub + u * L) * 16;
+                ahead[u] = load_block<NTL>(src + (o < wbytes - 16 ? o : wbytes - 16));
+            }
+        }
         if (run && sub == 0) {                                                 // chain the length prefixes
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
             const uint32_t want = total - j < R ? total - j : R;
@@ -162,10 +278,25 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             s_next[g] = next;
         }
         __syncthreads();
+        if (PFL) {
+            // The chain has said where the next window begins (unless a record of this round turns out incomplete: then the
+            // blocks are not taken).  Every lane issues the loads, wanted or not, as above.
+            const uint64_t next = run ? s_next[g] : end;
+            const bool want = run && next < end && j + s_found[g] < total;
+            pf_base = want ? next & ~AMASK : ~0ull;
+            const uint64_t from = want ? pf_base : 0ull, span = want ? ((end + 15) & ~15ull) - pf_base : 16ull;
+            const uint32_t wbytes = span < W ? (uint32_t)span : W;
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(blocks) + from;
+#pragma unroll
+            for (uint32_t u = 0; u < NLOAD; u++) {
+                const uint32_t o = (sub + u * L) * 16;
+                ahead[u] = load_block<NTL>(src + (o < wbytes - 16 ? o : wbytes - 16));
+            }
+        }
         uint32_t my_kl[NT];
 #pragma unroll
         for (uint32_t t = 0; t < NT; t++) my_kl[t] = 0;
-        if (run) {
+        if (run && !(X & DX_NO_PARSE)) {
             const uint32_t found = s_found[g];
             const uint32_t key_base = (uint32_t)(wbase - blob_base);           // key offsets are 32 bits wide
 #pragma unroll
@@ -184,22 +315,31 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
                 if (verdict == rec::REC_INCOMPLETE) { atomicMin(&s_first_incomplete[g], k); continue; }
                 if (verdict != rec::REC_OK) { s_bad[g] = 1; continue; }
                 const uint64_t i = record_base + j + k;
-                part[i] = partition;
-                klen[i] = (int32_t)r.key_len;
-                vlen[i] = (int32_t)r.val_len;
-                ts[i] = ts_base + (r.ts_delta & ts_mask);
-                if (seq) seq[i] = seq_base + i;
-                if (want_keys) koff[i] = r.key_len > 0 ? key_base + r.key : 0u;
+                if (X & DX_NO_STORE) {                                         // ablation: the parse stays alive through kb
+                    my_kl[t] = (uint32_t)r.key_len + (uint32_t)r.val_len + (uint32_t)r.ts_delta + r.key;
+                    continue;
+                }
+                store_col<NTS>(&part[i], partition);
+                store_col<NTS>(&klen[i], (int32_t)r.key_len);
+                store_col<NTS>(&vlen[i], (int32_t)r.val_len);
+                store_col<NTS>(&ts[i], (int64_t)(ts_base + (r.ts_delta & ts_mask)));
+                if (seq) store_col<NTS>(&seq[i], (uint64_t)(seq_base + i));
+                if (want_keys) store_col<NTS>(&koff[i], r.key_len > 0 ? key_base + r.key : 0u);
                 my_kl[t] = r.key_len > 0 ? (uint32_t)r.key_len : 0u;
             }
+        }
+        if (X & DX_NO_PARSE) {
+            if (run) my_kl[0] = s_start[g][sub < R ? sub : 0];
         }
         __syncthreads();
         if (run) {
             const uint32_t found = s_found[g], first_inc = s_first_incomplete[g];
             const uint32_t done = first_inc < found ? first_inc : found;
-            if (s_bad[g] || done == 0) {                                       // done == 0: no progress, truncated batch
+            if (s_bad[g] || (done == 0 && !(PFE && fetched))) {                // done == 0: no progress, truncated batch
                 bad = true;
                 run = false;
+            } else if (PFE && done == 0) {
+                pf_base = ~0ull;            // (PF) the window began too far before this record: the next one begins at it
             } else {
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++)
@@ -210,6 +350,10 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             }
         }
         __syncthreads();
+    }
+    if (X & (DX_LOAD_ONLY | DX_NO_STORE | DX_NO_PARSE)) {   // ablations: what they computed is "used", the columns stay as they were
+        if (kb == 0x123456789ABCull) part[0] = 1;
+        return;
     }
     if (bad) {
         for (uint32_t r = j + sub; r < total; r += L) {
@@ -227,13 +371,13 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
     }
 }
 
-template <int G, uint32_t W, uint32_t R>
+template <int G, uint32_t W, uint32_t R, uint32_t X = 0>
 __global__ __launch_bounds__(64) KTA_WAVES_PER_EU(G * W <= 8192 ? 5 : 1, 8) void kafka_decode_coop(const uint4 *blocks, const kta_kafka_batch_desc *descs,
                                                         uint64_t n_batches, int want_keys, int32_t *part,
                                                         int32_t *klen, int32_t *vlen, int64_t *ts, uint32_t *koff,
                                                         uint64_t blob_base, uint64_t *seq, uint64_t seq_base,
                                                         unsigned long long *n_bad, unsigned long long *n_keyb)
 {
-    decode_coop_rounds<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, blob_base, seq, seq_base,
+    decode_coop_rounds<G, W, R, X>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, blob_base, seq, seq_base,
                                        n_bad, n_keyb);
 }

@@ -1458,6 +1458,22 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
                        words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
                        out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
+#ifdef KTA_DECODE_EXPERIMENTS   // 1000 + X: <4, 3 KiB, 16> with the switches X; 2000 + X: <2, 8 KiB, 32> (kta_decode_coop.h: DX_*)
+#define KTA_DECODE_COOP_X(G, W, R, X)                                                                                 \
+    hipLaunchKernelGGL((kafka_decode_coop<G, W, R, X>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s, \
+                       words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
+                       out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
+#define KTA_X_CASES(X) case 1000 + (X): KTA_DECODE_COOP_X(4, 3072u, 16u, X); break; case 2000 + (X): KTA_DECODE_COOP_X(2, 8192u, 32u, X); break;
+    if (st->variant >= 1000) {
+        switch (st->variant) {
+        KTA_X_CASES(0) KTA_X_CASES(1) KTA_X_CASES(2) KTA_X_CASES(3) KTA_X_CASES(4) KTA_X_CASES(5) KTA_X_CASES(7)
+        KTA_X_CASES(8) KTA_X_CASES(9) KTA_X_CASES(16) KTA_X_CASES(32)
+        KTA_X_CASES(64) KTA_X_CASES(65) KTA_X_CASES(69) KTA_X_CASES(128) KTA_X_CASES(129) KTA_X_CASES(133) KTA_X_CASES(135)
+        KTA_X_CASES(256) KTA_X_CASES(257) KTA_X_CASES(259) KTA_X_CASES(263)
+        default: return KTA_ERR_INVALID;
+        }
+    } else
+#endif
     switch (decode_variant_for(st->variant, n_batches, blob_len)) {
     case 1: // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
@@ -1726,6 +1742,9 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
+#ifdef KTA_DECODE_EXPERIMENTS
+    if (ctx && variant >= 1000 && variant < 3000) { state_of(ctx)->variant = variant; return KTA_OK; }
+#endif
     if (!ctx || !(variant == 0 || variant == 1 || variant == 2 || variant == 10 || variant == 11)) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;

@@ -45,7 +45,7 @@ struct Dim3 {
     uint32_t x, y, z;
 };
 
-enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3 };
+enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3, READLANE = 4 };
 
 struct Lane {
     ucontext_t ctx;
@@ -102,6 +102,13 @@ template <class T> inline T shfl_xor(T v, int mask, int site)
     T r;
     memcpy(&r, &state().current->out, sizeof(T));
     return r;
+}
+
+// v_readlane: every lane takes lane `src`'s value (src is the same for all of them)
+inline uint32_t readlane(uint32_t v, uint32_t src, int site)
+{
+    park(READLANE, site, v, src);
+    return (uint32_t)state().current->out;
 }
 
 inline void lane_entry()
@@ -170,6 +177,11 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
                 uint64_t r = 0;
                 for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done) r |= s.lanes[l].in;
                 for (uint32_t l = 0; l < kLanes; l++) s.lanes[l].out = r;
+            } else if (what == READLANE) {
+                uint32_t src = 0;
+                for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done) { src = s.lanes[l].operand; break; }
+                const Lane &from = s.lanes[src % kLanes];
+                for (uint32_t l = 0; l < kLanes; l++) s.lanes[l].out = from.done ? 0 : from.in;
             } else if (what == SHFL_XOR) {
                 for (uint32_t l = 0; l < kLanes; l++) {
                     const Lane &from = s.lanes[(l ^ s.lanes[l].operand) % kLanes];
@@ -188,6 +200,7 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
 #define __syncthreads() wave_emu::barrier(__LINE__)
 #define __any(p) wave_emu::any((p), __LINE__)
 #define __shfl_xor(v, m) wave_emu::shfl_xor((v), (m), __LINE__)
+#define KTA_READLANE(v, l) wave_emu::readlane((uint32_t)(v), (l), __LINE__)
 
 // one OS thread: the atomics are plain operations
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)

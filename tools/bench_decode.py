@@ -29,6 +29,7 @@ ap.add_argument("--rpb", default="8,60,500", help="records per batch: 8 ~2 KiB, 
 ap.add_argument("--variants", default="0")
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--lib", default="")
+ap.add_argument("--sweeps", type=int, default=1, help="repeat the sweep over the variants this many times (A B C A B C: drift between variants shows)")
 ap.add_argument("--val-mean", type=int, default=0, help="mean value length of the records (0: the c4 law's 208 B); e.g. 10240 with --rpb 6 --records 100000: records of ~10 KiB, whose 3-byte length prefixes the chain leaves to the byte loop")
 args = ap.parse_args()
 
@@ -36,7 +37,8 @@ libs = [l for l in args.lib.split(",") if l]
 if len(libs) > 1:
     for l in libs:
         argv = [sys.executable, os.path.abspath(__file__), "--records", str(args.records), "--rpb", args.rpb,
-                "--variants", args.variants, "--reps", str(args.reps), "--lib", l, "--val-mean", str(args.val_mean)]
+                "--variants", args.variants, "--reps", str(args.reps), "--lib", l, "--val-mean", str(args.val_mean),
+                "--sweeps", str(args.sweeps)]
         subprocess.run(argv, check=False)
     sys.exit(0)
 
@@ -56,9 +58,12 @@ ref = kta.synth_fill_host(spec, 0, min(n, 1 << 18))
 h = kta.HipMetricHandler(256)
 for rpb in [int(x) for x in args.rpb.split(",")]:
     ln = C.c_uint64()
-    lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n, rpb, None, 0, C.byref(ln))
-    buf = np.zeros(ln.value + 64, np.uint8)
-    lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n, rpb, buf.ctypes.data, ln.value, C.byref(ln))
+    room = n * (int(spec.val_mean) + 256) * 2 + (1 << 20)          # one pass: room to spare (untouched pages cost nothing)
+    buf = np.zeros(room, np.uint8)
+    lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n, rpb, buf.ctypes.data, room - 64, C.byref(ln))
+    if ln.value > room - 64:                                         # (the law's tail was longer: size it, then fill)
+        buf = np.zeros(ln.value + 64, np.uint8)
+        lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n, rpb, buf.ctypes.data, ln.value, C.byref(ln))
     cap = n // rpb + 2
     descs = (N.KtaKafkaBatchDesc * cap)()
     st = N.KtaKafkaIndexStats()
@@ -67,7 +72,7 @@ for rpb in [int(x) for x in args.rpb.split(",")]:
     blob = h.device_batch_alloc((ln.value + 3) // 4 + 32)
     h._check(lib.kta_copy_to_device(h._ctx, blob.partition, buf.ctypes.data, (ln.value + 63) // 64 * 64))
     out = h.device_batch_alloc(n, 16)
-    for variant in [int(v) for v in args.variants.split(",")]:
+    for variant in [int(v) for v in args.variants.split(",")] * args.sweeps:
         h._check(lib.kta_kafka_set_variant(h._ctx, variant))
         a, c = (C.c_float * 2)(), (C.c_uint64 * 2)()
 
