@@ -65,7 +65,9 @@ enum : uint32_t {
     DX_NO_PARSE = 32,    // ablation: loads and chain only
     DX_PF_EARLY = 64,    // the blocks behind the window are sent for before the chain (in registers while the round runs)
     DX_PF_LATE = 128,    // the next window is sent for when the chain knows where it begins, before the parse
-    DX_LOAD_1K = 256     // a load instruction of the wave reads 1 KiB of ONE window (all 64 lanes), not 256 bytes of each of four
+    DX_LOAD_1K = 256,    // a load instruction of the wave reads 1 KiB of ONE window (all 64 lanes), not 256 bytes of each of four
+    DX_STAGE = 512,      // the columns leave in whole aligned blocks of L records (a lane keeps the record of its slot until the block is full)
+    DX_DEFER = 1024      // a round's columns are stored behind the NEXT round's window loads (a whole round to complete before anything waits on vmcnt)
 };
 #ifndef KTA_READLANE   // (tests/native/wave_emu.h: a meeting point)
 #define KTA_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
@@ -134,7 +136,11 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
     constexpr uint64_t AMASK = (X & DX_ALIGN128) ? 127ull : 15ull;   // a window begins on a block / on a line
     constexpr bool C1K = (X & DX_LOAD_1K) != 0;
     static_assert(!C1K || (W % 1024 == 0 && !PF), "1 KiB loads: whole KiB windows, no prefetch");
-    static_assert(!(PFE && PFL) && W % 128 == 0 || !(X & (DX_ALIGN128 | DX_PF_EARLY | DX_PF_LATE)), "experiment switches");
+    constexpr bool STAGE = (X & DX_STAGE) != 0;
+    static_assert(!STAGE || NT == 1, "staged columns: one record per lane and round");
+    constexpr bool DEFER = (X & DX_DEFER) != 0;
+    static_assert(!DEFER || (NT == 1 && !STAGE), "deferred columns: one record per lane and round");
+    static_assert((!(PFE && PFL) && W % 128 == 0) || !(X & (DX_ALIGN128 | DX_PF_EARLY | DX_PF_LATE)), "experiment switches");
     __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the register paths read whole dwords up to 16 bytes ahead
     __shared__ uint32_t s_start[G][R + 1];        // record starts relative to the window base; [found]: where the last one ends
     __shared__ uint64_t s_next[G];                // absolute position after the last chained record
@@ -165,6 +171,14 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
 #pragma unroll
     for (uint32_t u = 0; u < (PF ? NLOAD : 1); u++) ahead[u] = make_uint4(0, 0, 0, 0);   // (uninitialised, the array stays in scratch)
     uint64_t pf_base = ~0ull;
+    // (STAGE) lane `sub` owns slot `sub` of the group's current block of L records (record indices blk .. blk + L - 1, blk a multiple
+    // of L): the record it keeps for it, the one it parsed this round
+    int32_t c_kl = 0, c_vl = 0, f_kl = 0, f_vl = 0;
+    int64_t c_ts = 0, f_ts = 0;
+    uint32_t c_ko = 0, f_ko = 0;
+    bool have = false;
+    bool f_ok = false, pend = false;                      // (DEFER) this round's record parsed; last round's record waits to be stored
+    uint64_t p_i = 0;
     while (__any(run)) {
         uint64_t wbase = 0;
         uint32_t limit = 0, end_rel = 0;                  // valid bytes in the window; the batch's end seen from its base
@@ -210,6 +224,17 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             }
             if (sub == 0) { s_bad[g] = 0; s_first_incomplete[g] = R; }
         }
+        if (DEFER && !C1K) {
+            if (pend) {
+                store_col<NTS>(&part[p_i], partition);
+                store_col<NTS>(&klen[p_i], c_kl);
+                store_col<NTS>(&vlen[p_i], c_vl);
+                store_col<NTS>(&ts[p_i], c_ts);
+                if (seq) store_col<NTS>(&seq[p_i], (uint64_t)(seq_base + p_i));
+                if (want_keys) store_col<NTS>(&koff[p_i], c_ko);
+            }
+            pend = false;
+        }
         if (C1K) {
             // every lane takes part in every group's window: W / 1024 instructions of 1 KiB each per group (a group that does not
             // run reads the blob's first block into its own window)
@@ -227,6 +252,17 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             for (uint32_t u = 0; u < NLOAD; u++) pin(stage[u]);
 #pragma unroll
             for (uint32_t u = 0; u < NLOAD; u++) s_win[u / PER][(u % PER) * 64 + lane] = stage[u];
+            if (DEFER) {
+                if (pend) {
+                    store_col<NTS>(&part[p_i], partition);
+                    store_col<NTS>(&klen[p_i], c_kl);
+                    store_col<NTS>(&vlen[p_i], c_vl);
+                    store_col<NTS>(&ts[p_i], c_ts);
+                    if (seq) store_col<NTS>(&seq[p_i], (uint64_t)(seq_base + p_i));
+                    if (want_keys) store_col<NTS>(&koff[p_i], c_ko);
+                }
+                pend = false;
+            }
         }
         __syncthreads();
         if (X & DX_LOAD_ONLY) {                           // ablation: the window is in LDS; on to the next one
@@ -296,6 +332,7 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
         uint32_t my_kl[NT];
 #pragma unroll
         for (uint32_t t = 0; t < NT; t++) my_kl[t] = 0;
+        f_ok = false;
         if (run && !(X & DX_NO_PARSE)) {
             const uint32_t found = s_found[g];
             const uint32_t key_base = (uint32_t)(wbase - blob_base);           // key offsets are 32 bits wide
@@ -319,6 +356,13 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
                     my_kl[t] = (uint32_t)r.key_len + (uint32_t)r.val_len + (uint32_t)r.ts_delta + r.key;
                     continue;
                 }
+                if (DEFER) f_ok = true;
+                if (STAGE || DEFER) {
+                    f_kl = (int32_t)r.key_len; f_vl = (int32_t)r.val_len; f_ts = ts_base + (r.ts_delta & ts_mask);
+                    f_ko = r.key_len > 0 ? key_base + r.key : 0u;
+                    my_kl[t] = r.key_len > 0 ? (uint32_t)r.key_len : 0u;
+                    continue;
+                }
                 store_col<NTS>(&part[i], partition);
                 store_col<NTS>(&klen[i], (int32_t)r.key_len);
                 store_col<NTS>(&vlen[i], (int32_t)r.val_len);
@@ -332,6 +376,8 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             if (run) my_kl[0] = s_start[g][sub < R ? sub : 0];
         }
         __syncthreads();
+        const uint64_t i0 = record_base + j;              // (STAGE) the index of this round's first record
+        uint32_t dn = 0;                                  // (STAGE) the records this round delivers
         if (run) {
             const uint32_t found = s_found[g], first_inc = s_first_incomplete[g];
             const uint32_t done = first_inc < found ? first_inc : found;
@@ -344,12 +390,56 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++)
                     if (sub + L * t < done) kb += my_kl[t];
+                dn = done;
                 j += done;
                 pos = done < found ? wbase + s_start[g][done] : s_next[g];     // records >= done are redone
                 run = j < total;
             }
         }
+        if (DEFER) {
+            pend = f_ok && sub < dn;
+            p_i = i0 + sub;
+            c_kl = f_kl; c_vl = f_vl; c_ts = f_ts; c_ko = f_ko;
+        }
+        if (STAGE) {
+            // The round's records k = 0 .. dn - 1 (lane k parsed record k) go to the slots c, c + 1, ... of the current block and on
+            // into the next one: slot `sub` takes record (sub - c) mod L.  A block that fills up leaves as ONE aligned store per
+            // column (L records: 64 bytes of a 4-byte column with sixteen lanes per batch); what belongs to the next block is kept.
+            const uint32_t c = (uint32_t)i0 & (L - 1u), k_src = (sub - c) & (L - 1u), from = g * L + k_src;
+            const int32_t n_kl = __shfl(f_kl, from), n_vl = __shfl(f_vl, from);
+            const int64_t n_ts = __shfl(f_ts, from);
+            const uint32_t n_ko = __shfl(f_ko, from);
+            const bool got = k_src < dn, into_cur = sub >= c;
+            if (c + dn >= L) {                            // (uniform inside a group) the current block is complete
+                const bool valid = into_cur ? true : have;
+                const uint64_t i = (i0 & ~(uint64_t)(L - 1u)) + sub;
+                if (valid) {
+                    store_col<NTS>(&part[i], partition);
+                    store_col<NTS>(&klen[i], into_cur ? n_kl : c_kl);
+                    store_col<NTS>(&vlen[i], into_cur ? n_vl : c_vl);
+                    store_col<NTS>(&ts[i], into_cur ? n_ts : c_ts);
+                    if (seq) store_col<NTS>(&seq[i], (uint64_t)(seq_base + i));
+                    if (want_keys) store_col<NTS>(&koff[i], into_cur ? n_ko : c_ko);
+                }
+                have = !into_cur && got;
+                c_kl = n_kl; c_vl = n_vl; c_ts = n_ts; c_ko = n_ko;            // (meaningful where `have`)
+            } else if (into_cur && got) {
+                have = true;
+                c_kl = n_kl; c_vl = n_vl; c_ts = n_ts; c_ko = n_ko;
+            }
+        }
         __syncthreads();
+    }
+    if (DEFER && pend) {                                  // the last round's records
+        part[p_i] = partition; klen[p_i] = c_kl; vlen[p_i] = c_vl; ts[p_i] = c_ts;
+        if (seq) seq[p_i] = seq_base + p_i;
+        if (want_keys) koff[p_i] = c_ko;
+    }
+    if (STAGE && have) {                                  // what is left of the batch's last block
+        const uint64_t i = ((record_base + j) & ~(uint64_t)(L - 1u)) + sub;
+        part[i] = partition; klen[i] = c_kl; vlen[i] = c_vl; ts[i] = c_ts;
+        if (seq) seq[i] = seq_base + i;
+        if (want_keys) koff[i] = c_ko;
     }
     if (X & (DX_LOAD_ONLY | DX_NO_STORE | DX_NO_PARSE)) {   // ablations: what they computed is "used", the columns stay as they were
         if (kb == 0x123456789ABCull) part[0] = 1;

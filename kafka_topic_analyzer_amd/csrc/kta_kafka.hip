@@ -1470,6 +1470,8 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KTA_X_CASES(8) KTA_X_CASES(9) KTA_X_CASES(16) KTA_X_CASES(32)
         KTA_X_CASES(64) KTA_X_CASES(65) KTA_X_CASES(69) KTA_X_CASES(128) KTA_X_CASES(129) KTA_X_CASES(133) KTA_X_CASES(135)
         KTA_X_CASES(256) KTA_X_CASES(257) KTA_X_CASES(259) KTA_X_CASES(263)
+        KTA_X_CASES(19) KTA_X_CASES(267) KTA_X_CASES(512) KTA_X_CASES(513) KTA_X_CASES(515) KTA_X_CASES(519) KTA_X_CASES(771) KTA_X_CASES(643)
+        KTA_X_CASES(1024) KTA_X_CASES(1027) KTA_X_CASES(1283) KTA_X_CASES(1287)
         default: return KTA_ERR_INVALID;
         }
     } else
@@ -1743,7 +1745,7 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
 #ifdef KTA_DECODE_EXPERIMENTS
-    if (ctx && variant >= 1000 && variant < 3000) { state_of(ctx)->variant = variant; return KTA_OK; }
+    if (ctx && variant >= 1000 && variant < 4000) { state_of(ctx)->variant = variant; return KTA_OK; }
 #endif
     if (!ctx || !(variant == 0 || variant == 1 || variant == 2 || variant == 10 || variant == 11)) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
