@@ -187,8 +187,8 @@ uint32_t kta_crc32c_host(const uint8_t *bytes, uint64_t len);
 /* Decode kernel choice of this context: 0 = automatic (default: by the number of batches in the call and their mean
  * size), 1 = one lane per batch (kept for comparison; also selects the lane-per-batch inflate kernels of all four
  * codecs instead of the wave-cooperative / two-stage ones), 2 = one wave per batch with 8 KiB LDS windows (calls with
- * fewer than 2048 batches), 10 = four batches per wave, 3 KiB windows, 16 records per round (batches below 20 KiB),
- * 11 = two batches per wave, 8 KiB windows, 32 records per round (batches of 20 KiB and more).  Any other value:
+ * fewer than 2048 batches), 10 = four batches per wave, 3 KiB windows, 16 records per round (batches below 28 KiB),
+ * 11 = two batches per wave, 8 KiB windows, 32 records per round (batches of 28 KiB and more).  Any other value:
  * KTA_ERR_INVALID (3 ... 9 and 12 ... 14 were geometries that lost the side-by-side timing of round 5 and were deleted:
  * profiles/r05_decode_geometries.jsonl). */
 int kta_kafka_set_variant(kta_ctx *ctx, int variant);

@@ -56,21 +56,20 @@ constexpr uint64_t kMaxBatchInflate = 512ull << 20;   // inflated size one batch
 //   <2, 8 KiB, 32>   (11)  0.253    0.141    0.149      128 / 64 records per round: 0.147 / 0.147 and 0.163 / 0.161;
 //                                                       with the next window prefetched into registers: 0.155 / 0.148 and 0.160 / 0.158
 //   <1, 8 KiB, 256>  (2)   0.283    0.142    0.154      <4, 8 KiB, 128>: 0.306 / 0.194 / 0.205
-// Sharing a wave between four batches pays while the batches are smaller than about 20 KiB; from there on two batches
-// per wave with ONE parse round per window (an 8 KiB window holds ~31 records of the 256-byte mean).  The kernel is bound
-// by instruction issue (profiles/r04_sq_decode.txt): what wins is the geometry with the fewest rounds per byte that still
-// fills the SIMDs.  The losers' instantiations (and the prefetching form of the kernel) were deleted with their timings kept.
-// Two more were timed later in the round and not kept (another box; 2 / 8 / 16 / 32 / 134 KiB batches, ms): <2, 4 KiB, 32>
-// 0.147 / 0.136 / 0.146 / 0.153 / 0.183 and <4, 4 KiB, 16> 0.146 / 0.139 / 0.143 / 0.148 / 0.196 next to (10) 0.131 / 0.143 /
-// 0.147 / 0.159 / 0.229 and (11) 0.254 / 0.148 / 0.141 / 0.143 / 0.150: every geometry sits on the same plateau of 3.7-4.2 TB/s.
+// Every geometry sat on one plateau of 3.7-4.2 TB/s, and the round's last calls found out why by switching parts of the kernel off
+// (profiles/r05_decode_switches.jsonl): the time is the windows' way through LDS (6.0-6.7 TB/s on its own) plus the column stores;
+// chain and parse hide behind other waves' loads.  What moved it: non-temporal window loads on 128-byte bases and a KiB of one
+// window per load instruction (kta_decode_coop.h) — <4, 3 KiB, 16> 0.137 -> 0.120 ms at 16 KiB batches (4 M records: 0.248 -> 0.217,
+// 0.282 -> 0.235 on a slower box), <2, 8 KiB, 32> 0.139 -> 0.136; 134 KiB batches 0.141 -> 0.137.  With it four batches per wave
+// pay up to about 30 KiB batches (8 KiB batches 0.124 / 0.146 ms, 16 KiB 0.125 / 0.138, 32 KiB 0.138 / 0.136; few large batches are
+// bound by the serial chain of a batch: 134 KiB 0.23 / 0.137).  The losers' instantiations, the prefetching forms, the staged and the
+// deferred column stores were deleted with their timings kept.
 int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 {
     if (forced) return forced;
     if (n_batches < 2048) return 2;            // few batches: one wave each
     const uint64_t mean = blob_len / n_batches;
-    // (with the chain's unaligned LDS reads — five instructions less per step — the two meet between 16 and 24 KiB: 8 KiB batches
-    // 0.132 / 0.148 ms, 16 KiB 0.136 / 0.139, 24 KiB 0.138 / 0.136, 32 KiB 0.153 / 0.136; profiles/r05_decode_geometries_3.jsonl)
-    return mean < 20480 ? 10 : 11;
+    return mean < 28672 ? 10 : 11;
 }
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>
@@ -1261,7 +1260,7 @@ int kta_kafka_decode_rounds_host(const uint8_t *blob, uint64_t blob_len, const k
         bool bad = d.status != 0, run = !bad && j < total;
         while (run) {
             if (pos >= end) { bad = true; break; }
-            const uint64_t wbase = pos & ~15ull;
+            const uint64_t wbase = rec::window_base(pos, W);
             const uint64_t span = ((end + 15) & ~15ull) - wbase, rest = end - wbase;
             const uint32_t wbytes = span < W ? (uint32_t)span : W;
             const bool to_the_end = rest <= wbytes;
@@ -1458,24 +1457,6 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     hipLaunchKernelGGL((kafka_decode_coop<G, W, R>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s,  \
                        words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
                        out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
-#ifdef KTA_DECODE_EXPERIMENTS   // 1000 + X: <4, 3 KiB, 16> with the switches X; 2000 + X: <2, 8 KiB, 32> (kta_decode_coop.h: DX_*)
-#define KTA_DECODE_COOP_X(G, W, R, X)                                                                                 \
-    hipLaunchKernelGGL((kafka_decode_coop<G, W, R, X>), dim3((uint32_t)((n_batches + (G) - 1) / (G))), dim3(64), 0, s, \
-                       words, st->d_descs, n_batches, wk, out->partition, out->key_len, out->val_len, out->ts_ms,     \
-                       out->key_off, (uint64_t)0, out->seq, (uint64_t)0, d_bad, d_keyb)
-#define KTA_X_CASES(X) case 1000 + (X): KTA_DECODE_COOP_X(4, 3072u, 16u, X); break; case 2000 + (X): KTA_DECODE_COOP_X(2, 8192u, 32u, X); break;
-    if (st->variant >= 1000) {
-        switch (st->variant) {
-        KTA_X_CASES(0) KTA_X_CASES(1) KTA_X_CASES(2) KTA_X_CASES(3) KTA_X_CASES(4) KTA_X_CASES(5) KTA_X_CASES(7)
-        KTA_X_CASES(8) KTA_X_CASES(9) KTA_X_CASES(16) KTA_X_CASES(32)
-        KTA_X_CASES(64) KTA_X_CASES(65) KTA_X_CASES(69) KTA_X_CASES(128) KTA_X_CASES(129) KTA_X_CASES(133) KTA_X_CASES(135)
-        KTA_X_CASES(256) KTA_X_CASES(257) KTA_X_CASES(259) KTA_X_CASES(263)
-        KTA_X_CASES(19) KTA_X_CASES(267) KTA_X_CASES(512) KTA_X_CASES(513) KTA_X_CASES(515) KTA_X_CASES(519) KTA_X_CASES(771) KTA_X_CASES(643)
-        KTA_X_CASES(1024) KTA_X_CASES(1027) KTA_X_CASES(1283) KTA_X_CASES(1287)
-        default: return KTA_ERR_INVALID;
-        }
-    } else
-#endif
     switch (decode_variant_for(st->variant, n_batches, blob_len)) {
     case 1: // one lane per batch (kept for comparison)
         hipLaunchKernelGGL(kafka_decode, dim3(grid), dim3(kLanesPerBlock), 0, s, words, st->d_descs, n_batches, wk,
@@ -1744,9 +1725,6 @@ int kta_kafka_crc_errors(kta_ctx *ctx, uint64_t *n)
 
 int kta_kafka_set_variant(kta_ctx *ctx, int variant)
 {
-#ifdef KTA_DECODE_EXPERIMENTS
-    if (ctx && variant >= 1000 && variant < 4000) { state_of(ctx)->variant = variant; return KTA_OK; }
-#endif
     if (!ctx || !(variant == 0 || variant == 1 || variant == 2 || variant == 10 || variant == 11)) return KTA_ERR_INVALID;
     state_of(ctx)->variant = variant;
     return KTA_OK;

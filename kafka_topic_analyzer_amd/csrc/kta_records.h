@@ -23,6 +23,11 @@
 namespace kta {
 namespace rec {
 
+// Where a window of W bytes that has to hold the byte at `pos` begins: on a 128-byte line for the windows the dispatcher uses
+// (the loads are non-temporal — the log is read once — and a window that begins inside a line would fetch that line twice), on a
+// 16-byte block for the small windows of the tests.  Host statement and kernel agree on it, so they agree on the rounds.
+KTA_REC_HD uint64_t window_base(uint64_t pos, uint32_t W) { return pos & ~(W >= 1024u ? 127ull : 15ull); }
+
 // The four bytes at byte offset (sh & 3) of the dword pair lo, hi.
 KTA_REC_HD uint32_t bytes4(uint32_t lo, uint32_t hi, uint32_t sh)
 {

@@ -17,13 +17,13 @@ namespace {
 
 namespace {
 
-template <int G, uint32_t W, uint32_t R, uint32_t X = 0>
+template <int G, uint32_t W, uint32_t R>
 const char *run(uint32_t grid, int order, uint32_t seed, const uint4 *blocks, const kta_kafka_batch_desc *descs,
                 uint64_t n_batches, int want_keys, int32_t *part, int32_t *klen, int32_t *vlen, int64_t *ts,
                 uint32_t *koff, uint64_t *seq, uint64_t seq_base, unsigned long long *n_bad, unsigned long long *n_keyb)
 {
     return wave_emu::launch(grid, order, seed, [&] {
-        kafka_decode_coop<G, W, R, X>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, (uint64_t)0, seq, seq_base,
+        kafka_decode_coop<G, W, R>(blocks, descs, n_batches, want_keys, part, klen, vlen, ts, koff, (uint64_t)0, seq, seq_base,
                                    n_bad, n_keyb);
     });
 }
@@ -61,9 +61,6 @@ void divergent_kernel()
 extern "C" {
 
 const char *kta_emu_last_error(void) { return g_error; }
-#ifdef KTA_DEC_STATS
-unsigned long long *kta_emu_stats(void) { return kta_dec_stats; }
-#endif
 
 int kta_emu_selftest_handover(int order, uint32_t seed, int with_barrier, uint32_t grid, uint32_t *out)
 {
@@ -111,25 +108,6 @@ int kta_emu_decode_coop(uint32_t lanes, uint32_t window, uint32_t per_round, int
     GEOMETRY(8, 1024u, 16u);    // eight leaders
     GEOMETRY(8, 256u, 8u);      // small ones: a window edge in almost every record
     GEOMETRY(16, 64u, 4u);
-#define GEOMETRY_X(g, w, r, x)                                                                                        \
-    else if (G == (g) && window == (w) && per_round == (r) && prefetch == (x))                                        \
-        err = run<g, w, r, x>(grid, order, seed, blocks, descs, n_batches, wk, partition, key_len, val_len, ts_ms,    \
-                              key_off, seq, seq_base, &bad, n_key_bytes ? &keyb : nullptr)
-    // the experiment switches (kta_decode_coop.h: DX_*), `prefetch` carries them
-    GEOMETRY_X(4, 3072u, 16u, 2);  GEOMETRY_X(2, 8192u, 32u, 2);  GEOMETRY_X(8, 256u, 8u, 2);  GEOMETRY_X(8, 1024u, 16u, 2);
-    GEOMETRY_X(4, 3072u, 16u, 64); GEOMETRY_X(2, 8192u, 32u, 64); GEOMETRY_X(8, 256u, 8u, 64); GEOMETRY_X(8, 1024u, 16u, 64);
-    GEOMETRY_X(4, 3072u, 16u, 128); GEOMETRY_X(2, 8192u, 32u, 128); GEOMETRY_X(8, 256u, 8u, 128); GEOMETRY_X(8, 1024u, 16u, 128);
-    GEOMETRY_X(4, 3072u, 16u, 130); GEOMETRY_X(2, 8192u, 32u, 130); GEOMETRY_X(8, 256u, 8u, 130); GEOMETRY_X(8, 1024u, 16u, 130);
-    GEOMETRY_X(4, 3072u, 16u, 66); GEOMETRY_X(2, 8192u, 32u, 66); GEOMETRY_X(8, 256u, 8u, 66); GEOMETRY_X(8, 1024u, 16u, 66);
-    GEOMETRY_X(4, 3072u, 16u, 256); GEOMETRY_X(2, 8192u, 32u, 256); GEOMETRY_X(8, 1024u, 16u, 256);
-    GEOMETRY_X(4, 3072u, 16u, 258); GEOMETRY_X(2, 8192u, 32u, 258); GEOMETRY_X(8, 1024u, 16u, 258);
-    GEOMETRY_X(4, 3072u, 16u, 512); GEOMETRY_X(2, 8192u, 32u, 512); GEOMETRY_X(8, 256u, 8u, 512); GEOMETRY_X(16, 64u, 4u, 512);
-    GEOMETRY_X(4, 3072u, 16u, 514); GEOMETRY_X(2, 8192u, 32u, 514); GEOMETRY_X(8, 256u, 8u, 514);
-    GEOMETRY_X(4, 3072u, 16u, 770); GEOMETRY_X(2, 8192u, 32u, 770);
-    GEOMETRY_X(4, 3072u, 16u, 642); GEOMETRY_X(2, 8192u, 32u, 642); GEOMETRY_X(8, 256u, 8u, 642);
-    GEOMETRY_X(4, 3072u, 16u, 1024); GEOMETRY_X(2, 8192u, 32u, 1024); GEOMETRY_X(8, 256u, 8u, 1024); GEOMETRY_X(16, 64u, 4u, 1024);
-    GEOMETRY_X(4, 3072u, 16u, 1282); GEOMETRY_X(2, 8192u, 32u, 1282);
-#undef GEOMETRY_X
     else rc = -1;
 #undef GEOMETRY
     free(buf);

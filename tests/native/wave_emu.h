@@ -3,7 +3,7 @@
 // restatement of it.  Not part of the product: nothing under kafka_topic_analyzer_amd/ includes this file.
 //
 // The 64 lanes of a workgroup are fibers (ucontext) on one OS thread.  A lane runs until it reaches a meeting point —
-// __syncthreads(), __any(), __shfl_xor() — and parks there; when every live lane is parked the scheduler checks that
+// __syncthreads(), __any(), __shfl_xor(), KTA_READLANE() — and parks there; when every live lane is parked the scheduler checks that
 // they all wait at the SAME call site (the source line: a barrier under divergent control flow is reported, not
 // emulated), exchanges the values and releases them.  Between two meeting points the lanes run one after the other in
 // an order the test chooses — ascending, descending or a fresh pseudo-random permutation per phase — so code that
@@ -45,7 +45,7 @@ struct Dim3 {
     uint32_t x, y, z;
 };
 
-enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3, READLANE = 4, SHFL_IDX = 5 };
+enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3, READLANE = 4 };
 
 struct Lane {
     ucontext_t ctx;
@@ -99,18 +99,6 @@ template <class T> inline T shfl_xor(T v, int mask, int site)
     uint64_t bits = 0;
     memcpy(&bits, &v, sizeof(T));
     park(SHFL_XOR, site, bits, (uint32_t)mask);
-    T r;
-    memcpy(&r, &state().current->out, sizeof(T));
-    return r;
-}
-
-// ds_bpermute: every lane takes the value of the lane it names
-template <class T> inline T shfl_idx(T v, uint32_t src, int site)
-{
-    static_assert(sizeof(T) <= 8, "shfl: at most 64 bits");
-    uint64_t bits = 0;
-    memcpy(&bits, &v, sizeof(T));
-    park(SHFL_IDX, site, bits, src);
     T r;
     memcpy(&r, &state().current->out, sizeof(T));
     return r;
@@ -189,11 +177,6 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
                 uint64_t r = 0;
                 for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done) r |= s.lanes[l].in;
                 for (uint32_t l = 0; l < kLanes; l++) s.lanes[l].out = r;
-            } else if (what == SHFL_IDX) {
-                for (uint32_t l = 0; l < kLanes; l++) {
-                    const Lane &from = s.lanes[s.lanes[l].operand % kLanes];
-                    s.lanes[l].out = from.done ? 0 : from.in;
-                }
             } else if (what == READLANE) {
                 uint32_t src = 0;
                 for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done) { src = s.lanes[l].operand; break; }
@@ -217,7 +200,6 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
 #define __syncthreads() wave_emu::barrier(__LINE__)
 #define __any(p) wave_emu::any((p), __LINE__)
 #define __shfl_xor(v, m) wave_emu::shfl_xor((v), (m), __LINE__)
-#define __shfl(v, l) wave_emu::shfl_idx((v), (uint32_t)(l), __LINE__)
 #define KTA_READLANE(v, l) wave_emu::readlane((uint32_t)(v), (l), __LINE__)
 
 // one OS thread: the atomics are plain operations

@@ -108,7 +108,7 @@ rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false>", "kta_alive_
                "+ the written list")
 print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
-# the 4 M-record launch of ~16 KiB batches: 66 667 batches x 16 lanes -> grid 1 066 688; batches below 20 KiB take <4, 3 KiB, 16>
+# the 4 M-record launch of ~16 KiB batches: 66 667 batches x 16 lanes -> grid 1 066 688; batches below 28 KiB take <4, 3 KiB, 16>
 # (kta_kafka.hip: pick_geometry) — the row is found by that grid size, whichever geometry served it
 DECODE_GRID = 1066688
 hits = sorted({k for (k, c) in rows if "kafka_decode_coop<" in k and "grid=%d" % DECODE_GRID in k})
