@@ -89,10 +89,8 @@ __device__ __forceinline__ uint4 load_block(const uint8_t *p)
 // <4, 3 KiB, 16>): streaming the windows through LDS alone 0.161-0.179 ms (6.0-6.7 TB/s: the floor), the chain adds nothing
 // (hidden behind other waves' loads), the parse 0.01 ms, the column stores 0.04-0.08 ms; 20 instructions per record in all,
 // an instruction every eighth cycle of a SIMD — the kernel waits for memory, it is not bound by issue any more.
-// Register budget: the geometries the dispatcher picks for batches below 64 KiB (<4, 2 KiB, 16>, <8, 1 KiB, 16>) compile to
-// 100 / 102 VGPRs without a hint — four waves per SIMD where their LDS (8.6 / 9.0 KiB per workgroup) admits 4.75 — and to
-// 96 with it: no spills, the same instruction counts (the kernel measured in round 4 had 89).  The geometries with more
-// than 8 KiB of windows per wave do not fit five waves and are compiled without the hint.
+// Occupancy: the windows' LDS bounds it (<4, 3 KiB, 16>: 12.4 KiB per wave, twelve waves per CU at 108 registers; <2, 8 KiB, 32>:
+// 16.3 KiB, nine waves at 130); <1, 8 KiB, 256> (8 KiB of windows) is held to 96 registers by the hint below: five waves per SIMD.
 #ifndef KTA_WAVES_PER_EU   // (tests/native/wave_emu.h defines it away: a host compiler does not parse the attribute)
 #define KTA_WAVES_PER_EU(least, most) __attribute__((amdgpu_waves_per_eu(least, most)))
 #endif
