@@ -235,12 +235,14 @@ def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras
     return out, both
 
 
-def alive_table_report(kta, device, steps, n_records):
-    """The alive-key pass as a rank of a partition-sharded -c run executes it: the sequence-numbered table (32 GiB),
-    batches with a seq column (the global consumption index of every record), config 3's key law — 10 M distinct keys,
-    what one of eight ranks of config 5 sees (key-affine partitions: 12.5 M).  Every step is a NEW batch of the topic
-    (records and sequence numbers that follow the last one's): resubmitting a batch would find its own entries in the
-    table and write nothing."""
+def alive_table_report(kta, device, steps, n_records, extras=True):
+    """What a rank of a partition-sharded -c run executes: the sequence-numbered table (32 GiB), batches with a seq column
+    (the global consumption index of every record), config 3's key law — 10 M distinct keys, about what one of eight ranks of
+    config 5 sees (key-affine partitions: 12.5 M).  Every step is a NEW batch of the topic (records and sequence numbers that
+    follow the last one's): resubmitting a batch would find its own entries in the table and write nothing.  Three contexts over
+    the same resident batches: the alive-key pass alone (which = 2), both handlers as the library runs them — ONE pass,
+    kta_alive_partition48<seq, fused> (which = 3) — and, with kta_set_fuse(ctx, 0), as two (kta_metrics_scan, then the pass).
+    Returns (alive_pass_table, both_handlers_table)."""
     spec, _ = kta.synth_preset("c3")
     h = kta.HipMetricHandler(64, count_alive_keys=True, device=device, alive_table=True)
     batches = []
@@ -248,37 +250,77 @@ def alive_table_report(kta, device, steps, n_records):
         b = h.device_batch_alloc(n_records, n_records * 16, with_seq=True)
         kb = h.synth_fill_device(spec, k * n_records, n_records, b)
         batches.append(b)
-    h.submit_device(batches[0], n_records, 0, which=2)          # warm-up: the first batch also writes 10 M new slots
-    h.sync()
-    h.kernel_time_stats()
-    h.set_timing(True)
-    t0 = time.perf_counter()
-    for k in range(steps):
-        h.submit_device(batches[k + 1], n_records, 0, which=2)
-    h.sync()
-    wall = time.perf_counter() - t0
-    avg_ms, cnt = h.kernel_time_stats()
-    h.set_timing(False)
+
+    def run(hh, which):
+        hh.submit_device(batches[0], n_records, 0, which=which)   # warm-up: the first batch also writes 10 M new slots
+        hh.sync()
+        hh.kernel_time_stats()
+        hh.set_timing(True)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            hh.submit_device(batches[k + 1], n_records, 0, which=which)
+        hh.sync()
+        wall = time.perf_counter() - t0
+        avg, cnt = hh.kernel_time_stats()
+        hh.set_timing(False)
+        return wall, [a if c else 0.0 for a, c in zip(avg, cnt)], cnt
+
+    wall, avg_ms, cnt = run(h, 2)
     res, _ = h.finish()
     # (a sharded rank's batches carry the global consumption index of every record: + 8 B per record, SURVEY §8e — read
-    # by pass 1, which checks that the column ascends inside the batch, and for the survivors)
+    # by pass 1, whose consumer waves check that the column ascends inside the batch, and for the survivors)
     algo = (4 + 4 + 4 + 8) * n_records + kb
-    rep = {"workload": f"c3 law, table state, seq column: {steps} consecutive batches of {n_records} records, 16 B keys, 10M distinct, "
-                       "10% tombstones (the partitioned pass: kta_alive_partition + kta_alive_apply<table>)",
+    what = f"c3 law, table state, seq column: {steps} consecutive batches of {n_records} records, 16 B keys, 10M distinct, 10% tombstones"
+    rep = {"workload": what + " (the partitioned pass: kta_alive_partition48<seq> + kta_alive_apply<table>)",
            "value": n_records * steps / wall, "unit": "records/s", "ms_per_step": wall / steps * 1e3,
            **_alive_checked(res.alive_keys, "c3", 0, n_records * (steps + 1)),
-           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition + kta_alive_apply (table state)",
+           "roofline": {"bound": "hbm", "kernel": "kta_alive_partition48 + kta_alive_apply (table state)",
                         "achieved": algo / (avg_ms[2] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (avg_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo,
                         "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
-                        "traffic": _traffic(["kta_alive_partition", "kta_alive_apply_table"], n_records),
+                        "traffic": _traffic(["kta_alive_partition48", "kta_alive_apply_table"], n_records),
                         "traffic_source": TRAFFIC_SOURCE,
                         "note": "algorithmic bytes = alive_pass's 12 B + key per record + the 8-byte seq column of a sharded "
-                                "rank's batches (SURVEY 8e): 36 B per record with 16-byte keys"}}
+                                "rank's batches (SURVEY 8e): 36 B per record with 16-byte keys; 6-byte pairs since round 6"}}
+    # ---- both handlers: 20 + 12 - 8 + 8 (seq) + key = 48 B per record with 16-byte keys, read once by the fused pass
+    h3 = kta.HipMetricHandler(64, count_alive_keys=True, device=device, alive_table=True)
+    wall3, avg3, cnt3 = run(h3, 3)
+    r3, c3 = h3.finish()
+    info3 = h3.alive_pass_info()
+    h3.close()
+    assert r3.alive_keys == res.alive_keys and info3["fused"] == steps + 1, "the fused table pass did not run, or disagrees"
+    two = None
+    if extras:
+        h2 = kta.HipMetricHandler(64, count_alive_keys=True, device=device, alive_table=True)
+        h2.set_fuse(False)
+        wall2, avg2, cnt2 = run(h2, 3)
+        r2, c2 = h2.finish()
+        h2.close()
+        assert r2.alive_keys == r3.alive_keys and (c2 == c3).all(), "the fused pass and the two passes disagree (table state)"
+        two = {"value": n_records * steps / wall2, "kernel_ms": avg2[0] + avg2[1] + avg2[2], "scan_ms": avg2[0],
+               "fold_ms": avg2[1], "alive_ms": avg2[2]}
+    algo3 = (20 + 12 - 8 + 8) * n_records + kb
+    both_ms = avg3[0] + avg3[1] + avg3[2]
+    both = {"workload": what + "; MessageMetrics + LogCompactionInMemoryMetrics per record (which=3): a sharded -c rank's step",
+            "value": n_records * steps / wall3, "unit": "records/s", "ms_per_step": wall3 / steps * 1e3,
+            "alive_keys": int(r3.alive_keys), "alive_keys_checked": rep["alive_keys_checked"],
+            "roofline": {"bound": "hbm", "kernel": "kta_alive_partition48<seq, fused> + kta_fold_partials + kta_alive_apply (table state)",
+                         "achieved": algo3 / (both_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo3 / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo3,
+                         "kernel_ms": both_ms, "scan_launches": int(cnt3[0]), "launches": int(cnt3[2]),
+                         "traffic": _traffic(["kta_alive_partition48_fused", "kta_alive_apply_table"], n_records),
+                         "traffic_source": TRAFFIC_SOURCE,
+                         "note": "algorithmic bytes = the union of the two handlers' columns + the seq column (48 B per record with "
+                                 "16-byte keys), which the fused pass reads once; kernel_ms = HIP events around partition (with the "
+                                 "metrics handler's sums) + fold + apply + the pool's direct path"},
+            "two_passes": None if two is None else dict(
+                two, frac=algo3 / (two["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                note="kta_set_fuse(ctx, 0): kta_metrics_scan + kta_fold_partials, then the alive-key pass (56 B per record touched: "
+                     "key_len and val_len twice)")}
     for b in batches:
         h.device_batch_free(b)
     h.close()
-    return rep
+    return rep, both
 
 
 def alive_hot_key_report(kta, device, n_records):
@@ -814,7 +856,8 @@ def main():
             line["alive_pass"], line["both_handlers"] = alive_pass_report(kta, local_rank, max(3, args.steps // 5), 2,
                                                                           args.alive_records, args.cpu_seconds,
                                                                           extras=not args.no_alive_extras)
-            line["alive_pass_table"] = alive_table_report(kta, local_rank, 5, args.alive_records)
+            line["alive_pass_table"], line["both_handlers_table"] = alive_table_report(kta, local_rank, 5, args.alive_records,
+                                                                                       extras=not args.no_alive_extras)
             if not args.no_alive_extras:
                 line["alive_pass_hot_key"] = alive_hot_key_report(kta, local_rank, 1 << 26)
         if world == 1 and not args.no_decode and not c5:

@@ -225,314 +225,14 @@ constexpr int kPartThreads = 1024;                 // one workgroup per CU: the 
 constexpr int kPartWaves = kPartThreads / 64;
 constexpr int kConsumers = 4;                      // waves that move completed blocks from the rings to memory (one per SIMD)
 constexpr int kProducers = kPartWaves - kConsumers; // waves that stream, hash and insert
-constexpr uint32_t kTile = 256;                    // records of one wave step: four consecutive records per lane
-constexpr uint32_t kRing = 16;                     // pairs per bucket ring: two 64-byte blocks
+constexpr uint32_t kTile = 256;                    // records of one wave step: instruction j of it takes the records 64 j + lane
 static_assert(kConsumers >= 1 && kConsumers <= 8 && kProducers >= 1, "waves of the partition workgroup");
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
 
-struct TileCols {
-    int4 kl, vl;
-    uint4 ko;
-    unsigned long long sq[5];                      // SEQ: the sequence numbers of the lane's four records and of the one behind them
-    uint32_t sq_ok;                                // SEQ: bit j: records j and j + 1 both exist (their order is to be checked)
-};
-struct TileKeys {
-    uint4 k[4];                                    // the 16 bytes at each key's offset
-};
-
-// Unconditional loads (the index is clamped into the batch, the result masked): a load under a lane predicate
-// becomes a branch, and the compiler then waits with vmcnt(0) wherever the value is used — which would also
-// wait for every prefetch issued in between.  The columns are 16-byte aligned and tiles start at multiples
-// of four records, so the last, partial group of four is read inside its own aligned 16 bytes.
-// The first `skip` (0..3) positions lie before the batch: the three columns were aligned down by that many records.
-template <bool SEQ>
-__device__ __forceinline__ void load_cols(const AliveColumns &c, uint64_t n, uint32_t skip, uint64_t tile, bool tile_ok, TileCols &r)
-{
-    const uint64_t base = tile * kTile + (uint64_t)(threadIdx.x & 63u) * 4u;
-    const uint64_t last = (n - 1) & ~3ull;
-    const uint64_t bc = tile_ok && base < last ? base : last;
-    r.kl = *reinterpret_cast<const int4 *>(c.key_len + bc);
-    r.vl = *reinterpret_cast<const int4 *>(c.val_len + bc);
-    r.ko = *reinterpret_cast<const uint4 *>(c.key_off + bc);
-    const bool in0 = tile_ok && base < n && base >= skip, in1 = tile_ok && base + 1 < n && base + 1 >= skip,
-               in2 = tile_ok && base + 2 < n && base + 2 >= skip, in3 = tile_ok && base + 3 < n;
-    r.kl.x = in0 ? r.kl.x : -1;                    // key None: ignored (metric.rs:302)
-    r.kl.y = in1 ? r.kl.y : -1;
-    r.kl.z = in2 ? r.kl.z : -1;
-    r.kl.w = in3 ? r.kl.w : -1;
-    if (SEQ) {
-        // the seq column is NOT aligned down with the others: record `base + j` of the aligned columns is seq[base + j - skip].
-        // Five values, clamped into the column (what is clamped is masked): the order of neighbours is checked here, in
-        // the kernel that reads the batch anyway, instead of by a kernel of its own that read the whole column first
-        // (0.52 ms of a 3.8 ms pass at 15 x 2^24 records).
-        const uint64_t nrec = n - skip;               // records of the batch
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const uint64_t i = base + (uint64_t)j;
-            r.sq[j] = c.seq[i >= skip && i - skip < nrec ? i - skip : 0u];
-        }
-        const bool in4 = tile_ok && base + 4 < n;
-        r.sq_ok = (in0 && in1 ? 1u : 0u) | (in1 && in2 ? 2u : 0u) | (in2 && in3 ? 4u : 0u) | (in3 && in4 ? 8u : 0u);
-    }
-}
-
-// The first 16 bytes at every key's offset, whatever the key's length: the bytes past a shorter key are
-// loaded and ignored (key_bytes is readable for 16 bytes past its last key: kta_hip.h).
-__device__ __forceinline__ void load_keys(const AliveColumns &c, const TileCols &r, TileKeys &k)
-{
-    // unconditional as well: a keyless record loads the blob's first 16 bytes
-    __builtin_memcpy(&k.k[0], c.key_bytes + (r.kl.x > 0 ? r.ko.x : 0u), 16);
-    __builtin_memcpy(&k.k[1], c.key_bytes + (r.kl.y > 0 ? r.ko.y : 0u), 16);
-    __builtin_memcpy(&k.k[2], c.key_bytes + (r.kl.z > 0 ? r.ko.z : 0u), 16);
-    __builtin_memcpy(&k.k[3], c.key_bytes + (r.kl.w > 0 ? r.ko.w : 0u), 16);
-}
-
-// LDS address (in pairs) of position p of bucket b's ring.  A ring is one 128-byte row, so without a twist every
-// bucket's position k would sit in the same two banks; rows are rotated by 2 * (b & 7) pairs (an even rotation
-// keeps the 16-byte pieces of a block aligned).
-__device__ __forceinline__ uint32_t ring_at(uint32_t b, uint32_t p)
-{
-    return b * kRing + ((p + 2u * (b & 7u)) & (kRing - 1));
-}
-
 // pool control words (device memory, zeroed before every launch pair)
 enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS = 3 };
-
-// pair = h << 32 | (batch-local index + 1) << 1 | alive       (index < 2^31 - 1: the low word of a pair is never zero)
-//
-// Per bucket in LDS: a ring of 16 pairs (two blocks of 8 = 64 bytes) and two counters — `pos`, the positions handed
-// out, and `out`, the pairs written out to memory (a multiple of 8).  Position p belongs to block p >> 3 and may be
-// written once p - out < 16: the ring entry's previous tenant has left.  An entry is zero from the moment it leaves
-// until its next tenant arrives.
-//
-// The workgroup's waves have two jobs (round 4; before, every wave did both and spent more instructions and LDS
-// round trips on the hand-over — arrival counts, a queue of completed blocks, stores staged around the prefetches
-// because loads and stores share one in-order counter — than on the records):
-//   producers  stream the columns and keys, hash, and per record: one returning LDS atomic (its position), one
-//              read (`out`, requested together with the atomic), one 8-byte write.  Nothing else: no store ever
-//              enters their vmcnt, and which block is complete is not their business.
-//   consumers  (one per SIMD) sweep the counters of their buckets: a block all of whose positions are handed out
-//              (pos >> 3 > out >> 3) and all of whose entries are non-zero leaves — four lanes per block, one aligned
-//              64-byte store — its entries are zeroed, `out` advances by 8.  They never load from memory.
-// Whoever holds a position in the oldest unwritten block of a bucket never waits (p - out < 8), so that block
-// completes and leaves: no deadlock, wherever its writers sit.
-// SEQ: the batch carries a seq column, which has to ascend inside the batch for pass 2 (it orders a batch's records by
-// their index): the producers check it on the way and raise *order_flag, which pass 2 and what runs in its stead read.
-template <int BLOG2, bool SEQ>
-__global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns c, uint64_t n, uint32_t skip, uint32_t tiles_per_wg,
-                                                                    unsigned long long *__restrict__ pairs,
-                                                                    uint32_t *__restrict__ counts, uint32_t cap,
-                                                                    unsigned long long *__restrict__ pool,
-                                                                    unsigned long long *__restrict__ pool_ctl,
-                                                                    uint32_t *__restrict__ pool_hist, uint32_t *__restrict__ order_flag)
-{
-    constexpr uint32_t B = 1u << BLOG2;
-    static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
-    KTA_PHASE_BEGIN;
-    extern __shared__ __attribute__((aligned(128))) unsigned long long s_ring[];   // B x kRing pairs
-    uint2 *s_ctl = reinterpret_cast<uint2 *>(s_ring + (size_t)B * kRing);          // per bucket: x = pos, y = out
-    uint32_t *s_list = reinterpret_cast<uint32_t *>(s_ctl + B);                    // kConsumers x 64: the chunk's ready blocks
-    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done, [1] next tile of the walk
-    {
-        ulonglong2 *z = reinterpret_cast<ulonglong2 *>(s_ring);
-        for (uint32_t e = threadIdx.x; e < B * kRing / 2u; e += kPartThreads) z[e] = make_ulonglong2(0ull, 0ull);
-        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) s_ctl[b] = make_uint2(0u, 0u);
-        if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
-    }
-    __syncthreads();
-    const uint32_t W = gridDim.x, w = blockIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t ntiles = (n + kTile - 1) / kTile;
-    const uint64_t first = (uint64_t)w * tiles_per_wg;
-    const uint64_t end = first + tiles_per_wg < ntiles ? first + tiles_per_wg : ntiles;
-    const uint64_t span = end > first ? end - first : 0u;
-
-    if (wave < (uint32_t)kProducers) {
-        // ---------------------------------------------- producer ----------------------------------------------
-        // Two-stage prefetch: the columns run two steps ahead of the hash, the key bytes (whose addresses come
-        // from the columns) one step ahead — no load waits for another inside a step.  Two register sets
-        // alternate (the loop is unrolled by two): copying "next" into "current" at the end of a step would
-        // make the wave wait for the prefetch at the very place it was issued.
-        // The workgroup's range is walked from a start that differs from workgroup to workgroup (and around): the
-        // ranges lie a power of two apart, and in step all workgroups would ask the same few memory channels.
-        // Tiles are handed out by a counter: the waves of a SIMD that also runs a consumer get fewer.
-        const uint64_t rot = span > 64u ? ((uint64_t)w * 37u * kPartWaves) % span : 0u;
-        auto at = [&](uint64_t i) __attribute__((always_inline)) -> uint64_t {   // i-th tile of this workgroup's walk
-            const uint64_t r = i + rot;
-            return first + (r < span ? r : r - span);
-        };
-        auto grab = [&]() __attribute__((always_inline)) -> uint64_t {           // the next tile of the walk (wave-uniform)
-            uint32_t g = 0;
-            if (lane == 0) g = lds_add(&s_misc[1], 1u);
-            return (uint64_t)__builtin_amdgcn_readfirstlane(g);
-        };
-        uint64_t t_a = grab(), t_b = grab();              // walk indices of the tiles in the two register sets
-        if (t_a < span) {
-            TileCols cols_a, cols_b;
-            TileKeys keys_a, keys_b;
-            load_cols<SEQ>(c, n, skip, at(t_a), true, cols_a);
-            load_cols<SEQ>(c, n, skip, at(t_b < span ? t_b : t_a), t_b < span, cols_b);
-            bool disorder = false;                            // SEQ: a record whose sequence number is not below its successor's
-            load_keys(c, cols_a, keys_a);
-            // one step: hash the tile in (r, keys) — walk index t — and insert its pairs; request the key bytes of the
-            // next tile (its columns were requested a step ago) and the columns of the tile after that, into r
-            auto step = [&](TileCols &r, TileKeys &keys, uint64_t &t, TileCols &r_next, TileKeys &keys_next) __attribute__((always_inline)) {
-                const int32_t kl[4] = {r.kl.x, r.kl.y, r.kl.z, r.kl.w}, vl[4] = {r.vl.x, r.vl.y, r.vl.z, r.vl.w};
-                const uint32_t ko[4] = {r.ko.x, r.ko.y, r.ko.z, r.ko.w};
-                uint32_t h[4];
-                unsigned long long pr[4];
-                bool keyed[4];
-                const uint64_t i0 = at(t) * kTile + (uint64_t)lane * 4u - skip;   // the batch-local index of the lane's first record
-                const uint64_t t_new = grab();                                    // (its latency hides behind the hashing)
-                // keys of one length are the common case (ids, UUIDs, fixed-width numbers): when every key of the tile
-                // has 16 bytes the wave takes the straight-line chain, without a branch per key
-                if (__all(kl[0] == 16 && kl[1] == 16 && kl[2] == 16 && kl[3] == 16)) {
-                    fnv_16x4(h, keys.k);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        h[j] = kl[j] > 0 ? fnv32_prefetched(keys.k[j], c.key_bytes + ko[j], (uint32_t)kl[j]) : kFnvInit;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    keyed[j] = kl[j] >= 0;
-                    pr[j] = ((unsigned long long)h[j] << 32) | ((unsigned long long)(i0 + j + 1) << 1) | (vl[j] >= 0 ? 1ull : 0ull);
-                }
-                if (SEQ) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) disorder |= ((r.sq_ok >> j) & 1u) && r.sq[j] >= r.sq[j + 1];
-                }
-                KTA_PHASE(0, 0);   // waiting for the step's loads + hashing
-                load_keys(c, r_next, keys_next);                       // their columns were requested a step ago
-                t = t_new;
-                load_cols<SEQ>(c, n, skip, at(t < span ? t : 0u), t < span, r);   // r is spent: hashed
-                // Straight-line, so that a lane's four LDS atomics and its four reads are in flight together.
-                uint32_t bk[4], p[4], out[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) bk[j] = h[j] >> (32 - BLOG2);
-#pragma unroll
-                for (int j = 0; j < 4; j++) p[j] = keyed[j] ? lds_add(&s_ctl[bk[j]].x, 1u) : 0u;
-#pragma unroll
-                for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                KTA_LDS_ORDER();
-                uint32_t pending = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (keyed[j]) {
-                        // (`out` may have been read before the position was handed out: it only grows, so an old
-                        // reading errs on the side of waiting)
-                        if (p[j] - out[j] < kRing) s_ring[ring_at(bk[j], p[j])] = pr[j];
-                        else pending |= 1u << j;
-                    }
-                }
-                KTA_PHASE(0, 1);   // positions + inserts
-                // Rare: sixteen arrivals of one bucket since its last block left.  The consumers write the oldest
-                // block out as soon as it is complete, and whoever holds a position in it never waits.
-                while (__any(pending != 0u)) {
-                    __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (!((pending >> j) & 1u)) continue;
-                        const uint32_t o = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (p[j] - o >= kRing) continue;
-                        KTA_LDS_ORDER();
-                        s_ring[ring_at(bk[j], p[j])] = pr[j];
-                        pending &= ~(1u << j);
-                    }
-                }
-                KTA_PHASE(0, 4);   // waiting for a ring half
-            };
-            for (;;) {
-                step(cols_a, keys_a, t_a, cols_b, keys_b);
-                if (t_b >= span) break;
-                step(cols_b, keys_b, t_b, cols_a, keys_a);
-                if (t_a >= span) break;
-            }
-            if (SEQ && __any(disorder) && lane == 0) atomicOr(order_flag, 1u);
-        }
-        KTA_LDS_ORDER();
-        if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
-    } else {
-        // ---------------------------------------------- consumer ----------------------------------------------
-        constexpr uint32_t kChunks = B / (64u * kConsumers);
-        const uint32_t cw = wave - (uint32_t)kProducers;
-        uint32_t *list = s_list + cw * 64u;
-        for (;;) {
-            const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
-            KTA_LDS_ORDER();
-            bool any_ready = false;                                               // wave-uniform
-            for (uint32_t ch = 0; ch < kChunks; ch++) {
-                const uint32_t b = (cw * kChunks + ch) * 64u + lane;
-                const unsigned long long ctl = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&s_ctl[b]), __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t pos = (uint32_t)ctl, out = (uint32_t)(ctl >> 32);
-                const bool ready = (pos >> 3) > (out >> 3);                        // every position of block out >> 3 is handed out
-                const unsigned long long m = __ballot(ready);
-                if (m == 0ull) continue;
-                any_ready = true;
-                const uint32_t nready = (uint32_t)__popcll(m);
-                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | ((out >> 3) << BLOG2);
-                KTA_LDS_ORDER();
-                for (uint32_t g0 = 0; g0 < nready; g0 += 16u) {                    // sixteen blocks at a time, four lanes per block
-                    const uint32_t e = g0 + (lane >> 2), piece = lane & 3u;
-                    const bool on = e < nready;
-                    const uint32_t ent = list[on ? e : 0u];
-                    const uint32_t bb = ent & (B - 1), k = ent >> BLOG2;           // bucket, block number
-                    ulonglong2 *src = reinterpret_cast<ulonglong2 *>(s_ring + ring_at(bb, k * 8u + piece * 2u));
-                    const ulonglong2 d = *src;
-                    KTA_LDS_ORDER();
-                    const unsigned long long vm = __ballot(on && (uint32_t)d.x != 0u && (uint32_t)d.y != 0u);
-                    const bool go = ((uint32_t)(vm >> (lane & ~3u)) & 15u) == 15u;  // all eight pairs have arrived
-                    if (go) {
-                        // ONE 16-byte store per lane, its address selected (stores in both arms of a branch were split into
-                        // two 8-byte stores each, one hoisted past the join)
-                        unsigned long long *dst;
-                        if ((k + 1u) * 8u <= cap) {
-                            dst = pairs + ((uint64_t)bb * W + w) * cap + (uint64_t)k * 8u;
-                        } else {                                                   // the segment is full: to the pool
-                            unsigned long long at_pool = 0;
-                            if (piece == 0u) {
-                                at_pool = atomicAdd(&pool_ctl[POOL_CURSOR], 8ull);
-                                atomicAdd(&pool_hist[bb], 8u);
-                            }
-                            dst = pool + __shfl(at_pool, (int)(lane & ~3u));
-                        }
-                        *reinterpret_cast<v2ull *>(dst + piece * 2u) = (v2ull){d.x, d.y};
-                        *src = make_ulonglong2(0ull, 0ull);
-                        KTA_LDS_ORDER();
-                        if (piece == 0u) lds_add(&s_ctl[bb].y, 8u);               // after the zeroes (program order)
-                    }
-                }
-                KTA_LDS_ORDER();
-            }
-            if (!any_ready) {
-                if (done == (uint32_t)kProducers) break;                          // nothing left that is complete
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-    }
-    __syncthreads();
-    // the last, partial block of every segment, and the segment fills for pass 2
-    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
-        const uint32_t f = s_ctl[b].x, k = f >> 3, rem = f & 7u;
-        if (rem) {
-            unsigned long long *dst;
-            if ((k + 1u) * 8u <= cap) {
-                dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * 8u;
-            } else {
-                // an even number of pairs: the pool's blocks are addressed in 16-byte units (a zero pair is no pair)
-                dst = pool + atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)((rem + 1u) & ~1u));
-                atomicAdd(&pool_hist[b], rem);
-                if (rem & 1u) dst[rem] = 0ull;
-            }
-            for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring[ring_at(b, k * 8u + q)];
-        }
-        counts[(uint64_t)b * W + w] = f < cap ? f : cap;
-    }
-    KTA_PHASE(0, 7);
-}
 
 // ------------------------------------------------------------------------------------------------------
 // pass 1, bit set state: the same partition with 4-byte pairs whose order is implicit
@@ -564,6 +264,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition(AliveColumns
 // Hot keys — which used to fill their bucket's ring and stall the workgroup — mostly die in the guard.
 // The stream is read once: non-temporal loads (measured against plain ones: the same time, within the noise).
 #define KTA_P32_LOAD(p) __builtin_nontemporal_load(p)
+// ... at a 32-bit byte offset from a base that lives in scalar registers
+template <typename T>
+__device__ __forceinline__ T ld_nt(const T *base, uint32_t byte_off)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off));
+}
 typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));   // 16 key bytes at any address (unaligned access mode)
 constexpr uint32_t kBlk32 = 16;                    // pairs of a block: what leaves the ring in one piece (64 bytes)
 constexpr uint32_t kRing32 = 2 * kBlk32;           // pairs per bucket ring: two blocks
@@ -624,19 +330,69 @@ __device__ __noinline__ uint32_t hot_filter(uint32_t guard_off, uint32_t lane, u
 // ---- both handlers in one pass over the batch (kafka.rs:107-109 calls every handler for every message) ----
 // With FUSE the producers also read partition and ts_ms (12 B more per record: 40 instead of 28 + 20 for two kernels) and do
 // what kta_metrics_scan does (MessageMetrics::handle_message, metric.rs:207-252), in the scan's own terms: per partition
-// three LDS words — A += 1 | tombstone << 21 | key None << 42, K += key length, V += value length (no replicas: the
-// rings leave 6 KiB) — and the global extrema in registers.  The workgroup writes one row of the scan's partial
+// three LDS words — A += 1 | tombstone << 21 | key None << 42, K += key length, V += value length, replicated by lane as far
+// as 12 KiB go (fuse_replicas_log2) — and the global extrema in registers.  The workgroup writes one row of the scan's partial
 // workspace, which kta_fold_partials folds as it folds the scan's.  A workgroup takes less than 2^21 records (the
 // host checks), so the 21-bit counts cannot overflow.
 struct FuseArgs {
     const int32_t *partition;
     const int64_t *ts_ms;
     uint32_t P;                  // <= kFuseMaxP
+    uint32_t rep_log2;           // replicas of a partition's sums in LDS: (P << rep_log2) <= kFuseSlots (fuse_replicas)
     uint64_t *partials;          // rows of row_len words, one per workgroup
     uint32_t row_len;
 };
 constexpr uint32_t kFuseMaxP = 256;
+constexpr uint32_t kFuseSlots = 512;    // partition x replica slots of three 8-byte sums: 12 KiB
+// A wave instruction's 64 records that share a partition serialise on its three sums (64 partitions: four or five records
+// deep on average, and rounds 4-5 paid for it: the fused form cost 0.54 ms of a 2.3 ms pass on config 3's 64 partitions) — so
+// the sums are replicated by lane, like the scan's (kta_kernels.hip): slot = partition << rep_log2 | lane & (replicas - 1).
+inline uint32_t fuse_replicas_log2(uint32_t P)
+{
+    uint32_t r = 0;
+    while (r < 4u && ((P ? P : 1u) << (r + 1u)) <= kFuseSlots) r++;
+    return r;
+}
 constexpr uint32_t kFuseCntBits = 21;   // (the scan's packing: kta_kernels.hip)
+
+// FUSE, after the workgroup's last barrier: its row of the scan's partial workspace (kta_fold_partials) from the sums in
+// s_acc and the waves' extrema in s_red ([kPartWaves][5]: min / max timestamp, min / max size, bad-partition records).
+__device__ __forceinline__ void fuse_write_row(const FuseArgs &fz, uint32_t w, const unsigned long long *s_acc, const long long *s_red)
+{
+    uint64_t *row = fz.partials + (uint64_t)w * fz.row_len;
+    constexpr unsigned long long kMask = (1ull << kFuseCntBits) - 1ull;
+    for (uint32_t p = threadIdx.x; p < fz.P; p += kPartThreads) {
+        uint64_t t[5] = {0, 0, 0, 0, 0};
+        for (uint32_t r = 0; r < (1u << fz.rep_log2); r++) {
+            const unsigned long long *sl = s_acc + 3u * ((p << fz.rep_log2) | r);
+            const unsigned long long a = sl[0];
+            t[0] += a & kMask, t[1] += (a >> kFuseCntBits) & kMask, t[2] += (a >> (2 * kFuseCntBits)) & kMask;
+            t[3] += sl[1], t[4] += sl[2];
+        }
+        uint64_t *o = row + (uint64_t)p * kScanCols;
+        o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = t[3], o[4] = t[4];
+    }
+    if (threadIdx.x == 0) {
+        long long tmin = LLONG_MAX, tmax = LLONG_MIN, smin = 0xFFFFFFFFll, smax = 0, bad = 0;
+        for (uint32_t v = 0; v < (uint32_t)kPartWaves; v++) {
+            const long long *o = s_red + v * 5u;
+            tmin = o[0] < tmin ? o[0] : tmin;
+            tmax = o[1] > tmax ? o[1] : tmax;
+            smin = o[2] < smin ? o[2] : smin;
+            smax = o[3] > smax ? o[3] : smax;
+            bad += o[4];
+        }
+        uint64_t *g = row + (uint64_t)fz.P * kScanCols;
+        g[SG_TMIN] = (uint64_t)tmin;
+        g[SG_TMAX] = (uint64_t)tmax;
+        g[SG_SMIN] = smin == 0xFFFFFFFFll ? (uint64_t)LLONG_MAX : (uint64_t)smin;     // (no record with a payload: as the scan says it)
+        g[SG_SMAX] = (uint64_t)smax;
+        g[SG_BAD] = (uint64_t)bad;
+        g[SG_NREC] = 0;
+        g[6] = 0;
+        g[7] = 0;
+    }
+}
 
 template <int BLOG2, bool FUSE>
 __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColumns c, uint64_t n, uint32_t tiles_per_wg,
@@ -657,7 +413,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
     uint32_t *s_list = reinterpret_cast<uint32_t *>(s_guard + (size_t)kProducers * kGuard);   // kConsumers x 64
     uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done (20 words)
     unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_misc + 20);      // FUSE: A, K, V per partition
-    long long *s_red = reinterpret_cast<long long *>(s_acc + 3 * kFuseMaxP);              // FUSE: [kPartWaves][5] extrema of the waves
+    long long *s_red = reinterpret_cast<long long *>(s_acc + 3 * kFuseSlots);             // FUSE: [kPartWaves][5] extrema of the waves
     {
         uint4 *z = reinterpret_cast<uint4 *>(s_ring32);
         for (uint32_t e = threadIdx.x; e < B * kRing32 / 4u; e += kPartThreads) z[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -667,7 +423,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         }
         if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
         if (FUSE)
-            for (uint32_t e = threadIdx.x; e < 3 * kFuseMaxP; e += kPartThreads) s_acc[e] = 0ull;
+            for (uint32_t e = threadIdx.x; e < 3 * kFuseSlots; e += kPartThreads) s_acc[e] = 0ull;
     }
     // FUSE: the lane's share of the global extrema (metric.rs:56-72) and of the records outside [0, P)
     long long f_tmin = LLONG_MAX, f_tmax = LLONG_MIN;
@@ -786,7 +542,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
                                 f_smin = min(f_smin, ks + vs);
                                 f_smax = max(f_smax, ks + vs);
                             }
-                            unsigned long long *a = s_acc + 3u * (uint32_t)r.pt[j];
+                            unsigned long long *a = s_acc + 3u * (((uint32_t)r.pt[j] << fz.rep_log2) | (lane & ((1u << fz.rep_log2) - 1u)));
                             atomicAdd(a, 1ull | ((unsigned long long)tomb << kFuseCntBits) | ((unsigned long long)knull << (2 * kFuseCntBits)));
                             atomicAdd(a + 1, (unsigned long long)ks);
                             atomicAdd(a + 2, (unsigned long long)vs);
@@ -989,36 +745,7 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         }
     }
     __syncthreads();
-    if (FUSE) {                                        // this workgroup's row of the scan's partial workspace (kta_fold_partials)
-        uint64_t *row = fz.partials + (uint64_t)w * fz.row_len;
-        constexpr unsigned long long kMask = (1ull << kFuseCntBits) - 1ull;
-        for (uint32_t p = threadIdx.x; p < fz.P; p += kPartThreads) {
-            const unsigned long long a = s_acc[3u * p];
-            uint64_t *o = row + (uint64_t)p * kScanCols;
-            o[0] = a & kMask, o[1] = (a >> kFuseCntBits) & kMask, o[2] = (a >> (2 * kFuseCntBits)) & kMask;
-            o[3] = s_acc[3u * p + 1u], o[4] = s_acc[3u * p + 2u];
-        }
-        if (threadIdx.x == 0) {
-            long long tmin = LLONG_MAX, tmax = LLONG_MIN, smin = 0xFFFFFFFFll, smax = 0, bad = 0;
-            for (uint32_t v = 0; v < (uint32_t)kPartWaves; v++) {
-                const long long *o = s_red + v * 5u;
-                tmin = o[0] < tmin ? o[0] : tmin;
-                tmax = o[1] > tmax ? o[1] : tmax;
-                smin = o[2] < smin ? o[2] : smin;
-                smax = o[3] > smax ? o[3] : smax;
-                bad += o[4];
-            }
-            uint64_t *g = row + (uint64_t)fz.P * kScanCols;
-            g[SG_TMIN] = (uint64_t)tmin;
-            g[SG_TMAX] = (uint64_t)tmax;
-            g[SG_SMIN] = smin == 0xFFFFFFFFll ? (uint64_t)LLONG_MAX : (uint64_t)smin;     // (no record with a payload: as the scan says it)
-            g[SG_SMAX] = (uint64_t)smax;
-            g[SG_BAD] = (uint64_t)bad;
-            g[SG_NREC] = 0;
-            g[6] = 0;
-            g[7] = 0;
-        }
-    }
+    if (FUSE) fuse_write_row(fz, w, s_acc, s_red);
     // the last, partial block of every segment, and the segment fills for pass 2
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         const uint32_t f = s_pos[b], k = f / kBlk32, rem = f % kBlk32;
@@ -1036,6 +763,429 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
             }
         }
         counts[(uint64_t)b * W + w] = f < cap ? f : cap;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pass 1, table state: 6-byte pairs with the order spelled out
+// ------------------------------------------------------------------------------------------------------
+// The table keeps ((global sequence number + 1) << 1) | alive per slot, so pass 2 needs a survivor's place in the batch
+// (its sequence number is base_seq + index, or seq[index]).  Rounds 1-5 spelled the whole batch-local index out: 8-byte
+// pairs, 2 GB written and read again per 2^28 records — and the kernel read its columns 16 bytes per lane, four
+// consecutive records each, with a register budget (119 of 128) that left no room for the metrics handler.  Now:
+//
+//   * the stream, the window walk and the FUSE arm are kta_alive_partition32's (4-byte column loads, lane j of an
+//     instruction = one record; both handlers of kafka.rs:107-109 in the one pass for a sharded rank as well);
+//   * pair48 = slot in the bucket (22 bits), alive, and the record's index INSIDE THE WORKGROUP'S RANGE (22 bits: a
+//     workgroup takes at most 2^22 records, the plan sees to it) — the workgroup is the pair's segment, so the batch-local
+//     index is segment x range + index.  The order of two pairs of one slot is their index: no windows, no guard;
+//   * a pair is three 16-bit words, each with bit 15 set:
+//         word 0 = index bits 0..14        word 1 = slot bits 0..14        word 2 = slot bits 15..21 | alive << 7 | index bits 15..21 << 8
+//     Bit 15 says "arrived": a ring word is zero from the moment its block leaves until its next tenant writes it, and the
+//     three words of a pair are three LDS writes;
+//   * a segment is a DENSE stream of 6-byte pairs.  A bucket's ring is 128 bytes = two 64-byte blocks = 21 1/3 pairs: the
+//     words of position p are the ring's words (3 p + i) mod 64, so a pair may straddle two blocks (and the ring's end).
+//     A block leaves — one aligned 64-byte store, as ever — when every position that reaches into it is handed out and
+//     all its 32 words have arrived; `out` counts the BYTES written out, and position p may be written once
+//     6 p + 6 - out <= 128 (every ring word it takes has been zeroed: the consumer zeroes a block before it advances `out`);
+//   * a position at or behind the segment's capacity never enters the ring: the producer writes the pair, in the pool's
+//     8-byte form with the batch-local index spelled out, straight to the pool (kta_alive_pool_direct takes it from there:
+//     pre-read + atomicMax, commutative).  The pool is handed out to the producer waves in chunks (one device atomic per
+//     chunk; what a wave leaves of its last chunk is zeroed: a zero pair is no pair).
+// SEQ: the batch carries a seq column, which has to ascend inside the batch for pass 2 (it orders a batch's records by their
+// index): the producers read it next to the other columns and raise *order_flag, which pass 2 and what runs in its stead read.
+constexpr uint32_t kRingW48 = 64;                  // 16-bit words of a bucket's ring: two 64-byte blocks
+constexpr uint32_t kBlkW48 = 32;                   // words of a block
+constexpr uint32_t kIdxBits48 = 22;                // index inside the workgroup's range
+constexpr uint32_t kPoolChunk48 = 2048;            // pool pairs a producer wave takes with one device atomic
+
+__device__ __forceinline__ uint32_t ring48_at(uint32_t b, uint32_t word)   // (rows rotated by whole 16-byte pieces)
+{
+    return b * kRingW48 + ((word + 8u * (b & 7u)) & (kRingW48 - 1));
+}
+
+template <int BLOG2, bool SEQ, bool FUSE>
+__global__ __launch_bounds__(kPartThreads) void kta_alive_partition48(AliveColumns c, uint64_t n, uint32_t tiles_per_wg,
+                                                                      unsigned short *__restrict__ pairs, uint32_t *__restrict__ counts,
+                                                                      uint32_t cap, unsigned long long *__restrict__ pool,
+                                                                      unsigned long long *__restrict__ pool_ctl,
+                                                                      uint32_t *__restrict__ order_flag, FuseArgs fz)
+{
+    constexpr uint32_t B = 1u << BLOG2;
+    constexpr uint32_t RBITS = 32 - BLOG2;
+    static_assert(RBITS == 22, "a pair48 holds 22 hash bits below the bucket");
+    static_assert(B % (64u * kConsumers) == 0, "a consumer's buckets are whole lanes-of-64 chunks");
+    extern __shared__ __attribute__((aligned(128))) unsigned short s_ring48[];    // B x kRingW48 words
+    uint2 *s_ctl = reinterpret_cast<uint2 *>(s_ring48 + (size_t)B * kRingW48);     // per bucket: x = positions handed out, y = bytes written out
+    uint32_t *s_list = reinterpret_cast<uint32_t *>(s_ctl + B);                    // kConsumers x 64: the chunk's ready blocks
+    uint32_t *s_misc = s_list + kConsumers * 64;                                   // [0] producers that are done, [1] next window (4 words)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_misc + 4);       // FUSE: A, K, V per partition
+    long long *s_red = reinterpret_cast<long long *>(s_acc + 3 * kFuseSlots);             // FUSE: [kPartWaves][5] extrema of the waves
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_ring48);
+        for (uint32_t e = threadIdx.x; e < B * kRingW48 / 8u; e += kPartThreads) z[e] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) s_ctl[b] = make_uint2(0u, 0u);
+        if (threadIdx.x < 2) s_misc[threadIdx.x] = 0u;
+        if (FUSE)
+            for (uint32_t e = threadIdx.x; e < 3 * kFuseSlots; e += kPartThreads) s_acc[e] = 0ull;
+    }
+    // FUSE: the lane's share of the global extrema (metric.rs:56-72) and of the records outside [0, P)
+    long long f_tmin = LLONG_MAX, f_tmax = LLONG_MIN;
+    uint32_t f_smin = 0xFFFFFFFFu, f_smax = 0u, f_bad = 0u;   // (0xFFFFFFFF is no size: both lengths are below 2^31)
+    __syncthreads();
+    const uint32_t W = gridDim.x, w = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t ntiles = (n + kTile - 1) / kTile;
+    const uint64_t first = (uint64_t)w * tiles_per_wg;
+    const uint64_t end = first + tiles_per_wg < ntiles ? first + tiles_per_wg : ntiles;
+    unsigned short *seg_base = pairs + (uint64_t)w * cap * 3u;                     // + bucket * W * cap * 3: the segment's words
+
+    if (wave < (uint32_t)kProducers) {
+        // ---------------------------------------------- producer ----------------------------------------------
+        // The batch has at most 2^28 records (kAlivePartitionMax), so every column offset fits 32 bits: the loads take the
+        // column's base from scalar registers and a 32-bit byte offset per lane (a 64-bit index per lane costs two
+        // registers and two additions per load).
+        struct Cols {                                      // two sets: requested two steps ahead
+            int32_t kl[4], vl[4];
+            uint32_t ko[4];
+            uint32_t on;                                   // a tile (wave-uniform); 0: none
+            uint32_t at;                                   // the batch-local index of the tile's first record
+        };
+        const uint32_t nn = (uint32_t)n, first_rec = (uint32_t)(first * kTile);
+        auto load_cols48 = [&](uint64_t tile, bool ok, Cols &r) __attribute__((always_inline)) {
+            r.at = ok ? (uint32_t)(tile * kTile) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = r.at + 64u * (uint32_t)j + lane;
+                const bool in = ok && i < nn;
+                const uint32_t ic = (in ? i : nn - 1u) * 4u;
+                r.kl[j] = ld_nt(c.key_len, ic);
+                r.vl[j] = ld_nt(c.val_len, ic);
+                r.ko[j] = ld_nt(c.key_off, ic);
+                r.kl[j] = in ? r.kl[j] : -1;               // key None: ignored (metric.rs:302)
+                if (FUSE) r.vl[j] = in ? r.vl[j] : 0;
+            }
+        };
+        auto load_keys48 = [&](const Cols &r, uint4 (&k)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v4u_any kk = KTA_P32_LOAD(reinterpret_cast<const v4u_any *>(c.key_bytes + (r.kl[j] > 0 ? r.ko[j] : 0u)));
+                k[j] = make_uint4(kk.x, kk.y, kk.z, kk.w);
+            }
+        };
+        // What only the head of a tile's step reads — FUSE: partition (-2: no record) and timestamp — lives in ONE register
+        // set, requested with the tile's key bytes (a step ahead) and spent before the next tile's are requested.
+        int32_t x_pt[FUSE ? 4 : 1];
+        long long x_ts[FUSE ? 4 : 1];
+        auto load_extra48 = [&](const Cols &r) __attribute__((always_inline)) {
+            if (FUSE) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = r.at + 64u * (uint32_t)j + lane;
+                    const bool in = r.on != 0u && i < nn;
+                    const uint32_t ic = in ? i : nn - 1u;
+                    x_pt[j] = ld_nt(fz.partition, ic * 4u);
+                    x_ts[j] = ld_nt(fz.ts_ms, ic * 8u);
+                    x_pt[j] = in ? x_pt[j] : -2;           // no record here (a record's bad id stays what it is)
+                }
+            }
+        };
+        // the walk: kta_alive_partition32's — windows of consecutive tiles taken from a counter, from a start that differs from
+        // workgroup to workgroup (here a window is only the unit of work: the pairs carry their index)
+        const uint64_t span = end > first ? end - first : 0u;
+        const uint32_t wtiles = (uint32_t)((span + 254u) / 255u);                 // tiles per window
+        const uint32_t nwin = wtiles ? (uint32_t)((span + wtiles - 1u) / wtiles) : 0u;
+        const uint32_t woff = nwin ? (w * 37u) % nwin : 0u;
+        uint64_t cur_tile = 0, cur_stop = 0;                                     // the walk's cursor (wave-uniform)
+        uint32_t cur_on = 0;
+        auto next_tile = [&](uint64_t &tile, uint32_t &on) __attribute__((always_inline)) {   // on = 0: the range is used up
+            if (cur_tile + 1 < cur_stop) {
+                cur_tile++;
+            } else {
+                uint32_t g = 0;
+                if (lane == 0) g = lds_add(&s_misc[1], 1u);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g < nwin) {
+                    const uint32_t cw = g + woff < nwin ? g + woff : g + woff - nwin;
+                    cur_tile = first + (uint64_t)cw * wtiles;
+                    cur_stop = cur_tile + wtiles < end ? cur_tile + wtiles : end;
+                    cur_on = 1u;
+                } else {
+                    cur_on = 0u;
+                    cur_stop = 0u;
+                    cur_tile = 0u;
+                }
+            }
+            tile = cur_tile;
+            on = cur_on;
+        };
+        uint32_t pc_next = 0, pc_end = 0;                  // this wave's chunk of the pool, in pairs (wave-uniform)
+        {
+            Cols cols_a, cols_b;
+            uint4 keys_a[4], keys_b[4];
+            uint64_t tl;
+            next_tile(tl, cols_a.on);
+            load_cols48(tl, cols_a.on != 0u, cols_a);
+            next_tile(tl, cols_b.on);
+            load_cols48(tl, cols_b.on != 0u, cols_b);
+            load_keys48(cols_a, keys_a);
+            load_extra48(cols_a);
+            auto step = [&](Cols &r, uint4 (&keys)[4], Cols &r_next, uint4 (&keys_next)[4]) __attribute__((always_inline)) {
+                uint32_t h[4];
+                if (__all(r.kl[0] == 16 && r.kl[1] == 16 && r.kl[2] == 16 && r.kl[3] == 16)) {
+                    fnv_16x4(h, keys);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        h[j] = r.kl[j] > 0 ? fnv32_prefetched(keys[j], c.key_bytes + r.ko[j], (uint32_t)r.kl[j]) : kFnvInit;
+                }
+                if (FUSE) {
+                    // MessageMetrics::handle_message (metric.rs:207-252) for the tile's records, keyed or not
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool there = x_pt[j] != -2;
+                        const bool ok = there && (uint32_t)x_pt[j] < fz.P;                 // (unsigned: negative ids are out as well)
+                        const uint32_t tomb = (uint32_t)r.vl[j] >> 31, knull = (uint32_t)r.kl[j] >> 31;   // payload None / key None (metric.rs:227-244)
+                        const uint32_t ks = knull ? 0u : (uint32_t)r.kl[j], vs = tomb ? 0u : (uint32_t)r.vl[j];
+                        const long long t = x_ts[j] == -1ll ? 0ll : x_ts[j];               // to_millis() None -> unwrap_or(0) (metric.rs:209)
+                        f_bad += there && !ok ? 1u : 0u;
+                        if (ok) {
+                            f_tmin = t < f_tmin ? t : f_tmin;
+                            f_tmax = t > f_tmax ? t : f_tmax;
+                            if (!tomb) {                                                   // metric.rs:249-251
+                                f_smin = min(f_smin, ks + vs);
+                                f_smax = max(f_smax, ks + vs);
+                            }
+                            unsigned long long *a = s_acc + 3u * (((uint32_t)x_pt[j] << fz.rep_log2) | (lane & ((1u << fz.rep_log2) - 1u)));
+                            atomicAdd(a, 1ull | ((unsigned long long)tomb << kFuseCntBits) | ((unsigned long long)knull << (2 * kFuseCntBits)));
+                            atomicAdd(a + 1, (unsigned long long)ks);
+                            atomicAdd(a + 2, (unsigned long long)vs);
+                        }
+                    }
+                }
+                // what the inserts need of the tile, in few registers (the columns' are about to be requested again)
+                const uint32_t at = r.at - first_rec + lane;         // the index, inside the workgroup's range, of the lane's first record
+                uint32_t alive_m = 0, ins_m = 0;                     // bit j: record j has a payload / a key
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    alive_m |= (r.vl[j] >= 0 ? 1u : 0u) << j;
+                    ins_m |= (r.kl[j] >= 0 ? 1u : 0u) << j;
+                }
+                load_keys48(r_next, keys_next);                      // their columns were requested a step ago
+                load_extra48(r_next);
+                {
+                    uint64_t tn;
+                    next_tile(tn, r.on);
+                    load_cols48(tn, r.on != 0u, r);                  // r is spent: hashed
+                }
+                // ---- positions, then the pairs once their ring words are free: straight-line, so that a lane's four
+                // LDS atomics and its four reads are in flight together ----
+                uint32_t bk[4], p[4], out[4];
+                bool ins[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    bk[j] = h[j] >> RBITS;
+                    ins[j] = (ins_m >> j) & 1u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = ins[j] ? lds_add(&s_ctl[bk[j]].x, 1u) : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) out[j] = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                KTA_LDS_ORDER();
+                auto put = [&](int j) __attribute__((always_inline)) {   // the pair's three words
+                    const uint32_t q = 3u * p[j], idx = at + 64u * (uint32_t)j, slot = h[j] & ((1u << RBITS) - 1u);
+                    s_ring48[ring48_at(bk[j], q)] = (unsigned short)(0x8000u | (idx & 0x7FFFu));
+                    s_ring48[ring48_at(bk[j], q + 1u)] = (unsigned short)(0x8000u | (slot & 0x7FFFu));
+                    s_ring48[ring48_at(bk[j], q + 2u)] = (unsigned short)(0x8000u | (slot >> 15) | (((alive_m >> j) & 1u) << 7) | ((idx >> 15) << 8));
+                };
+                uint32_t pending = 0, over = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (ins[j]) {
+                        // (`out` may have been read before the position was handed out: it only grows, so an old
+                        // reading errs on the side of waiting)
+                        if (p[j] >= cap) over |= 1u << j;
+                        else if (6u * p[j] + 6u - out[j] <= 2u * kRingW48) put(j);
+                        else pending |= 1u << j;
+                    }
+                }
+                while (__any(pending != 0u)) {                        // rare: 21 arrivals of one bucket since its last block left
+                    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!((pending >> j) & 1u)) continue;
+                        const uint32_t o = __hip_atomic_load(&s_ctl[bk[j]].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (6u * p[j] + 6u - o > 2u * kRingW48) continue;
+                        KTA_LDS_ORDER();
+                        put(j);
+                        pending &= ~(1u << j);
+                    }
+                }
+                // ---- rare: pairs whose segment is full go to the pool, spelled out (hot keys, or a bucket 8 sigma over its share)
+                if (__any(over != 0u)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool o = (over >> j) & 1u;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(o);
+                        if (m == 0ull) continue;                     // (wave-uniform)
+                        const uint32_t cnt = (uint32_t)__popcll(m), room = pc_end - pc_next;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        uint32_t at_pool;
+                        if (cnt > room) {                            // what is left of the chunk, then a new one
+                            unsigned long long nb = 0;
+                            if (lane == 0u) nb = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kPoolChunk48);
+                            const uint32_t nb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                            at_pool = rank < room ? pc_next + rank : nb0 + (rank - room);
+                            pc_next = nb0 + (cnt - room);
+                            pc_end = nb0 + kPoolChunk48;
+                        } else {
+                            at_pool = pc_next + rank;
+                            pc_next += cnt;
+                        }
+                        // the pool's form of a pair: hash << 32 | (batch-local index + 1) << 1 | alive
+                        if (o) pool[at_pool] = ((unsigned long long)h[j] << 32) | (((unsigned long long)first_rec + at + 64u * (uint32_t)j + 1ull) << 1) | ((alive_m >> j) & 1u);
+                    }
+                }
+            };
+            while (cols_a.on != 0u) {
+                step(cols_a, keys_a, cols_b, keys_b);
+                if (cols_b.on == 0u) break;
+                step(cols_b, keys_b, cols_a, keys_a);
+            }
+        }
+        for (uint32_t k = pc_next + lane; k < pc_end; k += 64u) pool[k] = 0ull;   // what is left of the last chunk holds nothing
+        KTA_LDS_ORDER();
+        if (lane == 0) lds_add(&s_misc[0], 1u);            // (LDS operations of a wave are performed in order: its pairs are in)
+    } else {
+        // ---------------------------------------------- consumer ----------------------------------------------
+        constexpr uint32_t kChunks = B / (64u * kConsumers);
+        const uint32_t cw = wave - (uint32_t)kProducers;
+        uint32_t *list = s_list + cw * 64u;
+        // SEQ: the consumer waves, which have registers and time to spare (a block of a bucket completes every 19 us, a sweep
+        // takes a fraction of one), also read the workgroup's range of the seq column — a quarter each, kSeqRows rows of 64
+        // records per sweep, requested before the sweep and looked at before the next one: every pair of neighbours of the
+        // column has to ascend.  Lane l of row t holds record 64 t + l (one instruction per 512 bytes: every line is asked
+        // for once — non-temporal loads of overlapping pieces fetched their lines again and again); its successor is the
+        // next lane's, the next row's first, or — the last row's last — the record behind the rows (which may be the next
+        // quarter's, or the next workgroup's, first).  Every index is clamped into the column, what is clamped is masked, all
+        // loads are unconditional.  (In the producers the column cost ten registers that the fused form does not have.)
+        const uint32_t nn = (uint32_t)n;                   // (at most 2^28 records: kAlivePartitionMax)
+        constexpr uint32_t kSeqRows = 24;                  // (12 KiB on the way per consumer wave; 8, 24 and 40 rows measured the same)
+        const uint32_t q_tiles = (uint32_t)((end > first ? end - first : 0u) + kConsumers - 1u) / kConsumers;
+        const uint32_t sq_lo = ((uint32_t)first + cw * q_tiles) * kTile;                       // the quarter's first record
+        const uint32_t sq_stop_t = (uint32_t)first + (cw + 1u) * q_tiles < (uint32_t)end ? (uint32_t)first + (cw + 1u) * q_tiles : (uint32_t)end;
+        const uint32_t sq_stop = sq_stop_t * kTile < nn ? sq_stop_t * kTile : nn;              // (the quarter's end, inside the batch)
+        // The quarter in chunks of kSeqRows rows, each complete in itself (it reads its own successor), from a chunk that
+        // differs from wave to wave, and around: the quarters lie a power of two apart, and in step all 1024 consumer waves of
+        // the chip would ask the same few memory channels at every moment (measured: 2.8 instead of 2.3 ms for the pass).
+        const uint32_t sq_chunks = sq_lo < sq_stop ? (sq_stop - sq_lo + 64u * kSeqRows - 1u) / (64u * kSeqRows) : 0u;
+        const uint32_t sq_rot = sq_chunks ? ((w * (uint32_t)kConsumers + cw) * 37u) % sq_chunks : 0u;
+        uint32_t sq_k = 0;                                 // chunks requested so far
+        unsigned long long sq[SEQ ? kSeqRows : 1], sq_edge = 0;
+        uint32_t sq_base = 0;                              // the rows in the registers begin at this record ...
+        bool sq_have = false;                              // ... if there are any (wave-uniform)
+        bool disorder = false;
+        for (;;) {
+            const uint32_t done = __hip_atomic_load(&s_misc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // BEFORE the sweep
+            KTA_LDS_ORDER();
+            if (SEQ) {
+                if (sq_have) {
+#pragma unroll
+                    for (uint32_t t = 0; t < kSeqRows; t++) {
+                        const unsigned long long mine = sq[t];
+                        unsigned long long next = __shfl_down(mine, 1);
+                        const unsigned long long row0 = t + 1 < kSeqRows
+                            ? ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sq[t + 1 < kSeqRows ? t + 1 : t] >> 32), 0) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sq[t + 1 < kSeqRows ? t + 1 : t], 0)
+                            : sq_edge;
+                        next = lane == 63u ? row0 : next;
+                        const uint32_t i = sq_base + 64u * t + lane;                           // this record; i + 1: its successor
+                        disorder |= i < sq_stop && i + 1u < nn && mine >= next;
+                    }
+                }
+                sq_have = sq_k < sq_chunks;
+                {
+                    const uint32_t ck = sq_k + sq_rot < sq_chunks ? sq_k + sq_rot : sq_k + sq_rot - sq_chunks;
+                    sq_base = sq_have ? sq_lo + ck * (64u * kSeqRows) : 0u;
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < kSeqRows; t++) {
+                    const uint32_t i = sq_base + 64u * t + lane;
+                    sq[t] = ld_nt(reinterpret_cast<const unsigned long long *>(c.seq), (i < nn ? i : nn - 1u) * 8u);
+                }
+                {
+                    const uint32_t i = sq_base + 64u * kSeqRows;
+                    sq_edge = ld_nt(reinterpret_cast<const unsigned long long *>(c.seq), (i < nn ? i : nn - 1u) * 8u);
+                }
+                sq_k += sq_have ? 1u : 0u;
+            }
+            bool any_ready = false;                                               // wave-uniform
+            for (uint32_t ch = 0; ch < kChunks; ch++) {
+                const uint32_t b = (cw * kChunks + ch) * 64u + lane;
+                const unsigned long long ctl = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&s_ctl[b]), __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t pos = (uint32_t)ctl, out = (uint32_t)(ctl >> 32);
+                const uint32_t lim = pos < cap ? pos : cap;                        // (what lies behind the capacity went to the pool)
+                const bool ready = 6u * lim - out >= 2u * kBlkW48;                 // every position that reaches into block out / 64 is handed out
+                const unsigned long long m = __ballot(ready);
+                if (m == 0ull) continue;
+                any_ready = true;
+                const uint32_t nready = (uint32_t)__popcll(m);
+                if (ready) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b | ((out >> 6) << BLOG2);
+                KTA_LDS_ORDER();
+                for (uint32_t g0 = 0; g0 < nready; g0 += 16u) {                    // sixteen blocks at a time, four lanes per block
+                    const uint32_t e = g0 + (lane >> 2), piece = lane & 3u;
+                    const bool on = e < nready;
+                    const uint32_t ent = list[on ? e : 0u];
+                    const uint32_t bb = ent & (B - 1), k = ent >> BLOG2;           // bucket, block number
+                    uint4 *src = reinterpret_cast<uint4 *>(s_ring48 + ring48_at(bb, (k & 1u) * kBlkW48 + piece * 8u));
+                    const uint4 d = *src;
+                    KTA_LDS_ORDER();
+                    const unsigned long long vm = __ballot(on && ((d.x & d.y & d.z & d.w) & 0x80008000u) == 0x80008000u);
+                    const bool go = ((uint32_t)(vm >> (lane & ~3u)) & 15u) == 15u;  // all its 32 words have arrived
+                    if (go) {
+                        unsigned short *dst = seg_base + (uint64_t)bb * W * cap * 3u + (uint64_t)k * kBlkW48 + piece * 8u;
+                        *reinterpret_cast<v4u *>(dst) = (v4u){d.x, d.y, d.z, d.w};
+                        *src = make_uint4(0u, 0u, 0u, 0u);
+                        KTA_LDS_ORDER();
+                        if (piece == 0u) s_ctl[bb].y = (k + 1u) * 64u;            // after the zeroes (program order); its only writer
+                    }
+                }
+                KTA_LDS_ORDER();
+            }
+            if (!any_ready) {
+                if (done == (uint32_t)kProducers && (!SEQ || !sq_have)) break;   // nothing left that is complete (SEQ: or unread)
+                if (done != (uint32_t)kProducers) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (SEQ && __any(disorder) && lane == 0) atomicOr(order_flag, 1u);
+    }
+    if (FUSE) {                                        // the waves' extrema (the consumers' are the neutral elements)
+        long long tmin = f_tmin, tmax = f_tmax, smin = (long long)f_smin, smax = (long long)f_smax, bad = (long long)f_bad;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long a = __shfl_xor(tmin, off), b2 = __shfl_xor(tmax, off), c2 = __shfl_xor(smin, off), d2 = __shfl_xor(smax, off);
+            bad += __shfl_xor(bad, off);
+            tmin = a < tmin ? a : tmin;
+            tmax = b2 > tmax ? b2 : tmax;
+            smin = c2 < smin ? c2 : smin;
+            smax = d2 > smax ? d2 : smax;
+        }
+        if (lane == 0) {
+            long long *o = s_red + wave * 5u;
+            o[0] = tmin, o[1] = tmax, o[2] = smin, o[3] = smax, o[4] = bad;
+        }
+    }
+    __syncthreads();
+    if (FUSE) fuse_write_row(fz, w, s_acc, s_red);
+    // the last, partial block of every segment, and the segment fills for pass 2
+    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+        const uint32_t pos = s_ctl[b].x, out = s_ctl[b].y;
+        const uint32_t lim = pos < cap ? pos : cap;
+        const uint32_t remw = (6u * lim - out) / 2u;                               // words still in the ring: less than a block
+        unsigned short *dst = seg_base + (uint64_t)b * W * cap * 3u + out / 2u;
+        for (uint32_t q = 0; q < remw; q++) dst[q] = s_ring48[ring48_at(b, out / 2u + q)];
+        counts[(uint64_t)b * W + w] = lim;
     }
 }
 
@@ -1167,7 +1317,7 @@ struct ApplyShared {
 template <int BLOG2, bool BITMAP>
 __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned long long *__restrict__ pairs,
                                                                  const uint32_t *__restrict__ counts, uint32_t cap,
-                                                                 uint32_t W, uint64_t base_seq,
+                                                                 uint32_t W, uint32_t range, uint64_t base_seq,
                                                                  const uint64_t *__restrict__ seq_col,
                                                                  unsigned long long *__restrict__ table,
                                                                  uint32_t *__restrict__ bitmap,
@@ -1351,31 +1501,63 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             // (3) the workgroup is its region's only writer during this kernel (its own direct-path atomics
             // are complete: barrier), so read / compare / write needs no RMW atomic.  Loads and stores are
             // agent-scope so that they see, and are seen by, the atomics of the direct path and other kernels.
-            for (uint32_t e0 = 0; e0 < kEntries; e0 += 4 * kApplyThreads) {
-                uint32_t tg[4], lo[4], slot[4];
-                unsigned long long v[4], old[4];
+            // Four entries per thread at a time (eight spill), and every load of them UNCONDITIONAL (an entry without a tag reads its set's
+            // first slot and record 0's sequence number, and changes nothing): under `if (tag)` each load was a branch of its own
+            // with a full wait behind it — 32 memory round trips one after the other per instalment, 123 of pass 2's 280 us per
+            // bucket (round 6's phase counters).  The new slots of a round are appended to the written list with ONE device
+            // atomic per wave.
+            constexpr int U = 4;
+            for (uint32_t e0 = 0; e0 < kEntries; e0 += U * kApplyThreads) {
+                uint32_t tg[U], lo[U], slot[U];
+                unsigned long long sv[U], old[U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const uint32_t e = e0 + (uint32_t)u * kApplyThreads + threadIdx.x;      // a tag by its half-word position ...
                     const uint32_t ev = (e & ~7u) | entry_of_half(e & 7u);                    // ... and its value
                     tg[u] = s_tag[e];
                     lo[u] = s_val[ev];
                     s_tag[e] = 0;
                     s_val[ev] = 0u;
-                    slot[u] = (b << RBITS) | ((e >> 3) << TAGBITS) | (tg[u] - 1u);
+                    slot[u] = (b << RBITS) | ((e >> 3) << TAGBITS) | (tg[u] ? tg[u] - 1u : 0u);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    v[u] = tg[u] ? global_val(lo[u]) : 0ull;
-                    old[u] = tg[u] ? __hip_atomic_load(&table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                for (int u = 0; u < U; u++) {
+                    const uint64_t idx = tg[u] ? (uint64_t)(lo[u] >> 1) - 1u : 0u;
+                    sv[u] = seq_col ? seq_col[idx] : base_seq + idx;
+                    old[u] = __hip_atomic_load(&table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                bool fresh[U];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (tg[u] && v[u] > old[u]) {
-                        __hip_atomic_store(&table[slot[u]], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        note_new_slot(wl, old[u] == 0ull, slot[u]);
-                        delta += (long long)(v[u] & 1ull) - (long long)(old[u] & 1ull);
+                for (int u = 0; u < U; u++) {
+                    const unsigned long long v = ((unsigned long long)(sv[u] + 1) << 1) | (lo[u] & 1u);
+                    const bool upd = tg[u] && v > old[u];
+                    fresh[u] = upd && old[u] == 0ull;
+                    if (upd) {
+                        __hip_atomic_store(&table[slot[u]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        delta += (long long)(v & 1ull) - (long long)(old[u] & 1ull);
                     }
+                }
+                if (wl.slots) {                          // (uniform control flow from here: every lane takes part in the ballots)
+                    unsigned long long m[U];
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        m[u] = __builtin_amdgcn_ballot_w64(fresh[u]);
+                        total += (uint32_t)__popcll(m[u]);
+                    }
+                    if (total) {                         // (wave-uniform)
+                        unsigned long long base = 0;
+                        if (lane == 0u) base = atomicAdd(wl.n, (unsigned long long)total);
+                        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const unsigned long long at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+                            if (fresh[u] && at < wl.cap) wl.slots[at] = slot[u];
+                            base += (uint32_t)__popcll(m[u]);
+                        }
+                    }
+                }
             }
             lds_barrier();
             for (uint32_t k = threadIdx.x; k < novf; k += kApplyThreads) {
@@ -1394,13 +1576,14 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         lds_barrier();
     };
 
-    // A wave reads its segments in units of 256 pairs, masked by the segment's fill: table state — two 16-byte loads
-    // per lane of 8-byte pairs (cap is a multiple of 128); bit set state — ONE 16-byte load per lane, its four 4-byte
-    // pairs (cap is a multiple of 256).  kApplyDepth - 1 units are in flight while one is merged.
-    const unsigned long long *region_pairs = pairs + (uint64_t)b * W * cap;
+    // A wave reads its segments in units of 256 pairs (cap is a multiple of 256), four per lane, masked by the segment's
+    // fill: bit set state — ONE 16-byte load per lane, its four 4-byte pairs; table state — the lane's 24 bytes of the
+    // dense stream of 6-byte pairs, a 16-byte and an 8-byte load (kta_alive_partition48).  kApplyDepth - 1 (table state:
+    // one) units are in flight while one is merged.
+    const uint8_t *region_pairs48 = reinterpret_cast<const uint8_t *>(pairs) + (uint64_t)b * W * cap * 6u;
     const uint32_t *region_pairs32 = reinterpret_cast<const uint32_t *>(pairs) + (uint64_t)b * W * cap;
-    const uint32_t loads = BITMAP ? cap >> 8 : cap >> 7;
-    const uint32_t chunks = BITMAP ? loads : (loads + kApplyUnroll - 1) / kApplyUnroll;
+    const uint32_t loads = cap >> 8;
+    const uint32_t chunks = loads;
     // Careful mode merges one GROUP of segments — one per wave, each older than the next group's — between two
     // checkpoints, so a group has to fit the table whatever its keys are: sixteen segments of a 2^28-record batch hold 15 k
     // pairs, and with mostly unique keys (config 5's law on one GPU) that is more than the table and its side table
@@ -1452,9 +1635,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // position takes ksh = ceil(log2(cap)) bits (cap >= 256, so the window's field starts above bit 8)
     const uint32_t ksh = 32u - (uint32_t)__builtin_clz(cap - 1u);
     struct Unit {
-        ulonglong2 q[kApplyUnroll];
-        uint32_t nv[kApplyUnroll];   // valid pairs of each load: 0, 1 or 2 (bit set state: [0] = 0..4, [1] = the value of the
-                                     // lane's first pair without its window and alive bit)
+        ulonglong2 q[kApplyUnroll];  // bit set state: q[0] = four pair32; table state: q[0], q[1].x = four pair48
+        uint32_t nv[kApplyUnroll];   // [0] = the lane's valid pairs, 0..4; [1] = bit set state: the value of the lane's first pair
+                                     // without its window and alive bit; table state: the batch-local index of the segment's range
     };
     // Which segment a unit reads: in careful mode wave v takes the segments v, v + 16, ... (every group of 16 is
     // older than the next); in the fast attempt the order does not matter and the waves take whatever segment is
@@ -1478,10 +1661,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 if (seg_units == 0u) seg_units = 1u;
                 seg_unit = 0;
             }
-            r0 = seg_unit * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
+            r0 = seg_unit;
             seg_unit++;
         } else {
-            r0 = (u % chunks) * (BITMAP ? 1u : (uint32_t)kApplyUnroll);
+            r0 = u % chunks;
             seg = (u / chunks) * KTA_GS + __builtin_amdgcn_readfirstlane(wave);
         }
         seg = __builtin_amdgcn_readfirstlane(seg);
@@ -1500,12 +1683,18 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             un.q[0] = make_ulonglong2(four.x, four.y);
             return;
         }
-        const unsigned long long *sp = region_pairs + (uint64_t)(on ? seg : 0u) * cap;
-#pragma unroll
-        for (int x = 0; x < kApplyUnroll; x++) {
-            const uint32_t k = ((r0 + (uint32_t)x) << 7) + 2u * lane;
-            un.nv[x] = (r0 + (uint32_t)x) < loads && k < cnt ? (cnt - k >= 2u ? 2u : 1u) : 0u;
-            un.q[x] = *reinterpret_cast<const ulonglong2 *>(sp + (un.nv[x] ? k : 2u * lane));   // unconditional, as above
+        {
+            const uint8_t *sp = region_pairs48 + (uint64_t)(on ? seg : 0u) * cap * 6u;
+            const uint32_t k = (r0 << 8) + 4u * lane;
+            un.nv[0] = r0 < loads && k < cnt ? (cnt - k >= 4u ? 4u : cnt - k) : 0u;
+            un.nv[1] = (on ? seg : 0u) * range;
+            const uint8_t *at = sp + (uint64_t)(un.nv[0] ? k : 4u * lane) * 6u;     // unconditional, as above (8-byte aligned: 24 bytes per lane)
+            typedef unsigned long long ull_a8 __attribute__((ext_vector_type(2), aligned(8)));
+            // (ordinary loads: the two instructions ask for the same lines, and a non-temporal load's line does not wait in the
+            // cache for the second one)
+            const ull_a8 lo = *reinterpret_cast<const ull_a8 *>(at);
+            un.q[0] = make_ulonglong2(lo.x, lo.y);
+            un.q[1] = make_ulonglong2(*reinterpret_cast<const unsigned long long *>(at + 16), 0ull);
         }
     };
     uint32_t claimed = 0;
@@ -1547,82 +1736,57 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
         KTA_LDS_ORDER();
     };
-    // Merge the unit `un`: four pairs per lane, their four lookups in flight together.
-    //   bit set state: a lookup is the set's 16 tag bytes — read unconditionally, any word addresses a set —, a hit one
-    //     LDS max; the misses of the unit go to the wave's queue, which always has room for a unit's 256 (it is emptied
-    //     down to less than 64 after every unit: whole waves of 64 lanes walk the long way, never the few of one unit).
-    //   table state: misses collect over several units and are handled when the queue is half full; a miss that
-    //     finds the queue full waits in its register until the queue has been handled.
+    // Merge the unit `un`: four pairs per lane, their four lookups in flight together (one form for both states since round 6:
+    // the table state's used to collect misses over several units and make a miss that found the queue full wait).
     auto merge = [&](const Unit &un, uint32_t par) __attribute__((always_inline)) {
         static_assert(kApplyUnroll == 2 && kMissQueue >= 5 * 64, "a unit's misses fit the queue behind what drain_full leaves");
         mq = __builtin_amdgcn_readfirstlane(mq);         // (wave-uniform by construction: see issue)
+        // the lane's four pairs as (slot in the bucket, value to maximise)
+        uint32_t hr[4], val[4];
         if (BITMAP) {
             const uint32_t w32[4] = {(uint32_t)un.q[0].x, (uint32_t)(un.q[0].x >> 32), (uint32_t)un.q[0].y, (uint32_t)(un.q[0].y >> 32)};
-            uint4 t[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) t[i] = *reinterpret_cast<const uint4 *>(s_tag + (w32[i] >> (kPair32Shift + TAGBITS)) * 8u);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t w = w32[i];
                 // value = (segment, window, position) << 1 | alive: the window and the alive bit are the pair's low bits
-                uint32_t val = ((w & 0x1FEu) << ksh) | (un.nv[1] + 2u * (uint32_t)i);
-                val = (val & ~1u) | (w & 1u);
-                const uint32_t tag = ((w >> kPair32Shift) & ((1u << TAGBITS) - 1u)) + 1u;
-                const uint32_t e = find_tag(t[i], tag);
-                const bool valid = (uint32_t)i < un.nv[0];
-                if (valid && e < 8u) atomicMax(&s_val[(w >> (kPair32Shift + TAGBITS)) * 8u + e], val);
-                const bool miss = valid && e >= 8u;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);   // (__ballot goes through an int: a select and a compare)
-                if (miss)
-                    missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                        ((unsigned long long)(w >> kPair32Shift) << 32) | val;
-                mq += (uint32_t)__popcll(m);
+                val[i] = ((w & 0x1FEu) << ksh) | (un.nv[1] + 2u * (uint32_t)i);
+                val[i] = (val[i] & ~1u) | (w & 1u);
+                hr[i] = w >> kPair32Shift;
             }
-            drain_full(par);
-            return;
+        } else {
+            // pair48: word 0 = index bits 0..14, word 1 = slot bits 0..14, word 2 = slot bits 15..21 | alive << 7 | index bits
+            // 15..21 << 8, bit 15 of every word set (kta_alive_partition48); value = (batch-local index + 1) << 1 | alive
+            const uint32_t d6[6] = {(uint32_t)un.q[0].x, (uint32_t)(un.q[0].x >> 32), (uint32_t)un.q[0].y, (uint32_t)(un.q[0].y >> 32),
+                                    (uint32_t)un.q[1].x, (uint32_t)(un.q[1].x >> 32)};
+            const uint32_t wa[4] = {d6[0], d6[1] >> 16, d6[3], d6[4] >> 16}, wb[4] = {d6[0] >> 16, d6[2], d6[3] >> 16, d6[5]},
+                           wc[4] = {d6[1], d6[2] >> 16, d6[4], d6[5] >> 16};                  // (their low 16 bits)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                hr[i] = (wb[i] & 0x7FFFu) | ((wc[i] & 0x7Fu) << 15);
+                const uint32_t idx = (wa[i] & 0x7FFFu) | ((wc[i] & 0x7F00u) << 7);
+                val[i] = (un.nv[1] + idx + 1u) << 1 | ((wc[i] >> 7) & 1u);
+            }
         }
-        // the lane's four pairs as (slot in the bucket, value to maximise): value = order << 1 | alive
-        unsigned long long pr[4] = {un.q[0].x, un.q[0].y, un.q[1].x, un.q[1].y};
-        const bool valid[4] = {un.nv[0] > 0u, un.nv[0] > 1u, un.nv[1] > 0u, un.nv[1] > 1u};
-        uint32_t set[4], tag[4], hr[4];
+        // A lookup is the set's 16 tag bytes — read unconditionally, any pair addresses a set —, a hit one LDS max; the misses of
+        // the unit go to the wave's queue, which always has room for a unit's 256 (it is emptied down to less than 64 after
+        // every unit: whole waves of 64 lanes walk the long way, never the few of one unit).
         uint4 t[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            hr[i] = (uint32_t)(pr[i] >> 32) & ((1u << RBITS) - 1u);
-            set[i] = hr[i] >> TAGBITS;
-            tag[i] = (hr[i] & ((1u << TAGBITS) - 1u)) + 1u;
-            t[i] = *reinterpret_cast<const uint4 *>(s_tag + set[i] * 8u);
-        }
-        uint32_t waiting = 0;                             // bit i: pair i missed and found the queue full
+        for (int i = 0; i < 4; i++) t[i] = *reinterpret_cast<const uint4 *>(s_tag + (hr[i] >> TAGBITS) * 8u);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t e = find_tag(t[i], valid[i] ? tag[i] : 0xFFFFu);     // (no tag is 0xFFFF: an invalid pair finds nothing)
-            if (e < 8u) atomicMax(&s_val[set[i] * 8u + e], (uint32_t)pr[i]);
-            const bool miss = valid[i] && e == 8u;
-            const unsigned long long m = __ballot(miss);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const uint32_t room = kMissQueue - mq, cnt = (uint32_t)__popcll(m);
-            if (miss) {
-                if (rank < room) missq[mq + rank] = ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
-                else waiting |= 1u << i;
-            }
-            mq += cnt < room ? cnt : room;
+            const uint32_t tag = (hr[i] & ((1u << TAGBITS) - 1u)) + 1u;
+            const uint32_t e = find_tag(t[i], tag);
+            const bool valid = (uint32_t)i < un.nv[0];
+            if (valid && e < 8u) atomicMax(&s_val[(hr[i] >> TAGBITS) * 8u + e], val[i]);
+            const bool miss = valid && e >= 8u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);   // (__ballot goes through an int: a select and a compare)
+            if (miss)
+                missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                    ((unsigned long long)hr[i] << 32) | val[i];
+            mq += (uint32_t)__popcll(m);
         }
-        if (mq > kMissQueue / 2 || __any(waiting != 0u)) {
-            for (;;) {                                    // (leaves the queue empty)
-                drain(par);
-                if (!__any(waiting != 0u)) break;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {             // (at most 4 x 64: they fit the empty queue)
-                    const bool w = (waiting >> i) & 1u;
-                    const unsigned long long m = __ballot(w);
-                    if (w) missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                        ((unsigned long long)hr[i] << 32) | (uint32_t)pr[i];
-                    mq += (uint32_t)__popcll(m);
-                }
-                waiting = 0;
-            }
-        }
+        drain_full(par);
     };
     // The driver.  First without checkpoints (no barrier until the end: a compacted topic's bucket fits the table);
     // a bucket that overflows table AND side table that way starts over in careful mode, and tells the buckets
@@ -1636,7 +1800,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     uint32_t inst_start = 0;                            // first segment of the current instalment
     uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
     uint32_t u = 0;                                     // the unit that is merged next
-    constexpr int D = BITMAP ? kApplyDepth : 2;        // (table state: 8-byte pairs, two loads a unit — the registers for two)
+    constexpr int D = BITMAP ? kApplyDepth : 3;        // (table state: six registers a unit instead of four — the registers for three)
     Unit ring[D];
     for (;;) {                                          // one pass per instalment (one more per restart)
         // D units per trip, the buffers taking turns: copying prefetched registers into "current" ones
@@ -1981,21 +2145,21 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         if (fuse) {
             // both handlers in this pass: the scan's sums in LDS behind the rings (see FuseArgs)
             if (fuse->P > kFuseMaxP || (uint64_t)pl.tiles_per_wg * kTile >= (1ull << kFuseCntBits)) return hipErrorInvalidValue;
-            const size_t lds1 = lds0 + (size_t)3 * kFuseMaxP * 8 + (size_t)kPartWaves * 5 * 8;
+            const size_t lds1 = lds0 + (size_t)3 * kFuseSlots * 8 + (size_t)kPartWaves * 5 * 8;
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
             if (e != hipSuccess) return e;
             KTA_UB_MARK(0);
             hipLaunchKernelGGL((kta_alive_partition32<BLOG2, true>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n, pl.tiles_per_wg,
                                reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, pl.pool_pairs, ctl, hist,
-                               FuseArgs{fuse->partition, fuse->ts_ms, fuse->P, fuse->partials, fuse->row_len});
+                               FuseArgs{fuse->partition, fuse->ts_ms, fuse->P, fuse_replicas_log2(fuse->P), fuse->partials, fuse->row_len});
         } else {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition32<BLOG2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
             if (e != hipSuccess) return e;
             KTA_UB_MARK(0);
             hipLaunchKernelGGL((kta_alive_partition32<BLOG2, false>), dim3(pl.segment_wgs), dim3(kPartThreads), lds0, s, c, n, pl.tiles_per_wg,
-                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, pl.pool_pairs, ctl, hist, FuseArgs{nullptr, nullptr, 0, nullptr, 0});
+                               reinterpret_cast<uint32_t *>(pp), ws.counts, pl.cap, pool, pl.pool_pairs, ctl, hist, FuseArgs{nullptr, nullptr, 0, 0, nullptr, 0});
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -2004,7 +2168,7 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
-                           pl.segment_wgs, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
+                           pl.segment_wgs, 0u, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
                            reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, (const uint32_t *)nullptr,
                            WrittenList{nullptr, nullptr, 0});
         e = hipGetLastError();
@@ -2019,44 +2183,49 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         KTA_UB_MARK(3);
         return hipGetLastError();
     }
-    // table state: 8-byte pairs (the survivors' sequence numbers come from their batch-local indices)
-    if (fuse) return hipErrorInvalidValue;              // (the fused pass exists for the bit set state)
+    // table state: 6-byte pairs (a survivor's sequence number comes from its batch-local index: segment x range + index)
+    if ((uint64_t)pl.tiles_per_wg * kTile > (1ull << kIdxBits48)) return hipErrorInvalidValue;   // (the plan keeps a workgroup's range inside a pair's index)
     const uint32_t *skip = c.seq ? flag : nullptr;       // (raised by pass 1 when the batch's seq column does not ascend)
-    // the kernel reads the three i32 columns 16 bytes at a time: align them down together
-    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(c.key_len) & 15u) / 4u);
-    if ((reinterpret_cast<uintptr_t>(c.val_len) & 15u) / 4u != head || (reinterpret_cast<uintptr_t>(c.key_off) & 15u) / 4u != head ||
-        (reinterpret_cast<uintptr_t>(c.key_len) & 3u))
-        return hipErrorInvalidValue;
-    AliveColumns ca = c;
-    ca.key_len -= head;
-    ca.val_len -= head;
-    ca.key_off -= head;
-    const size_t lds1 = (size_t)B * kRing * 8 + (size_t)B * 8 + (size_t)kConsumers * 64 * 4 + 16;
-    if (c.seq) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((kta_alive_partition<BLOG2, true>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head,
-                           pl.tiles_per_wg, pp, ws.counts, pl.cap, pool, ctl, hist, flag);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition<BLOG2, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((kta_alive_partition<BLOG2, false>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, ca, n + head, head,
-                           pl.tiles_per_wg, pp, ws.counts, pl.cap, pool, ctl, hist, flag);
+    const size_t lds0 = (size_t)B * kRingW48 * 2 + (size_t)B * 8 + (size_t)kConsumers * 64 * 4 + 16;
+    const size_t lds1 = lds0 + (fuse ? (size_t)3 * kFuseSlots * 8 + (size_t)kPartWaves * 5 * 8 : 0);
+    FuseArgs fz{nullptr, nullptr, 0, 0, nullptr, 0};
+    if (fuse) {
+        if (fuse->P > kFuseMaxP || (uint64_t)pl.tiles_per_wg * kTile >= (1ull << kFuseCntBits)) return hipErrorInvalidValue;
+        fz = FuseArgs{fuse->partition, fuse->ts_ms, fuse->P, fuse_replicas_log2(fuse->P), fuse->partials, fuse->row_len};
     }
+    unsigned short *pp16 = reinterpret_cast<unsigned short *>(pp);
+#define KTA_LAUNCH_P48(SEQ, FUSE)                                                                                                    \
+    do {                                                                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_partition48<BLOG2, SEQ, FUSE>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);                                              \
+        if (e != hipSuccess) return e;                                                                                               \
+        hipLaunchKernelGGL((kta_alive_partition48<BLOG2, SEQ, FUSE>), dim3(pl.segment_wgs), dim3(kPartThreads), lds1, s, c, n,       \
+                           pl.tiles_per_wg, pp16, ws.counts, pl.cap, pool, ctl, flag, fz);                                           \
+    } while (0)
+    KTA_UB_MARK(0);
+    if (c.seq) {
+        if (fuse) KTA_LAUNCH_P48(true, true);
+        else KTA_LAUNCH_P48(true, false);
+    } else {
+        if (fuse) KTA_LAUNCH_P48(false, true);
+        else KTA_LAUNCH_P48(false, false);
+    }
+#undef KTA_LAUNCH_P48
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    KTA_UB_MARK(1);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
     unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
     hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
-                       pl.segment_wgs, base_seq, c.seq, t, (uint32_t *)nullptr, run,
+                       pl.segment_wgs, pl.tiles_per_wg * kTile, base_seq, c.seq, t, (uint32_t *)nullptr, run,
                        reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip, st.written);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    KTA_UB_MARK(2);
     hipLaunchKernelGGL(kta_alive_pool_direct, dim3(256), dim3(kWG), 0, s, pool, ctl, base_seq, c.seq, t, run, skip, st.written);
+    KTA_UB_MARK(3);
     return hipGetLastError();
 }
 
@@ -2085,21 +2254,26 @@ AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, b
     // [w * tiles_per_wg, (w + 1) * tiles_per_wg): a contiguous, older-to-newer range of the batch
     uint64_t wgs = req_wgs > 0 ? (uint64_t)req_wgs : (uint64_t)(cu_count > 0 ? cu_count : 256);
     if (wgs > kMaxSegWGs) wgs = kMaxSegWGs;
-    const uint64_t ntiles = (n + 3 + kTile - 1) / kTile;              // + 3: columns aligned down by up to three records
+    const uint64_t ntiles = (n + kTile - 1) / kTile;
     const uint64_t want = (ntiles + kProducers - 1) / kProducers;     // at least one tile per producer wave
     if (wgs > want) wgs = want;
     pl.tiles_per_wg = (uint32_t)((ntiles + wgs - 1) / wgs);
+    // table state: a pair48 holds its record's index inside the workgroup's range in kIdxBits48 bits (more workgroups if need be:
+    // 2^28 records in 64 ranges at the least)
+    if (!pair32 && (uint64_t)pl.tiles_per_wg * kTile > (1ull << kIdxBits48)) pl.tiles_per_wg = (uint32_t)((1ull << kIdxBits48) / kTile);
     pl.segment_wgs = (uint32_t)((ntiles + pl.tiles_per_wg - 1) / pl.tiles_per_wg);
     // a segment receives n / (W * B) pairs on average; 1/8 + 48 of slack (8 sigma at 2^26 records) before it
     // overflows into the pool, rounded up to what a wave reads with one load instruction (128 pairs)
     const uint64_t mean = n / ((uint64_t)pl.segment_wgs << pl.bucket_log2) + 1;
     // (and to what a wave of pass 2 reads with one load instruction of four pairs per lane: 256)
     pl.cap = (uint32_t)((mean + mean / 8 + 48 + 255) & ~255ull);
-    pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap / (pair32 ? 2 : 1);
+    pl.pair_words = ((uint64_t)pl.segment_wgs << pl.bucket_log2) * pl.cap * (pair32 ? 4 : 6) / 8;
     pl.count_words = (uint64_t)pl.segment_wgs << pl.bucket_log2;
-    // the pool: at most one pair per record; + a padded block per segment tail; bit set state: + what the consumer waves
-    // leave of their last chunks (pool_tag_note), and behind the pairs one 4-byte tag per block of 16
-    pl.pool_pairs = ((n + 15) & ~15ull) + ((uint64_t)16 * pl.segment_wgs << pl.bucket_log2) + (uint64_t)kPoolChunk * kBlk32 * kConsumers * pl.segment_wgs;
+    // the pool: at most one pair per record; bit set state: + a padded block per segment tail + what the consumer waves leave of
+    // their last chunks (pool_tag_note), and behind the pairs one 4-byte tag per block of 16; table state: + what the producer
+    // waves leave of theirs
+    pl.pool_pairs = ((n + 15) & ~15ull) + (pair32 ? ((uint64_t)16 * pl.segment_wgs << pl.bucket_log2) + (uint64_t)kPoolChunk * kBlk32 * kConsumers * pl.segment_wgs
+                                                  : (uint64_t)kPoolChunk48 * kProducers * pl.segment_wgs);
     pl.pool_words = pl.pool_pairs + (pair32 ? pl.pool_pairs / 32 + 1 : 0);
     pl.ctl_bytes = POOL_WORDS * 8 + ((size_t)4 << pl.bucket_log2) + 4;
     return pl;
@@ -2114,7 +2288,7 @@ hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t 
 
 bool alive_fuse_possible(const AlivePartitionPlan &pl, uint32_t P)
 {
-    return pl.pair32 && P <= kFuseMaxP && (uint64_t)pl.tiles_per_wg * kTile < (1ull << kFuseCntBits);
+    return P <= kFuseMaxP && (uint64_t)pl.tiles_per_wg * kTile < (1ull << kFuseCntBits);
 }
 
 hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s)

@@ -216,13 +216,32 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
     // every refusal comes before the first launch: a batch is counted by both handlers or by neither
     if ((which & 2) && ctx->alive && (!c->key_len || !c->val_len || !c->key_off || !c->key_bytes))
         return fail(ctx, KTA_ERR_INVALID, "key columns missing (count_alive_keys)");
-    // Both handlers over one batch (what kafka.rs:107-109 does with every message): in the bit set state, with at most 256
-    // partitions, pass 1 of the alive-key pass does the metrics handler's work as well (kta_alive.hip, FuseArgs) — the
-    // batch is read once, 40 B + key per record instead of 20 + 28.
+    // Table state: which kernels take the batch is decided before anything is launched (the fused pass below depends on it).
+    // 3 = the partitioned pass for batches of >= 2^21 records (13: for batches of any size — tests), with the automatic
+    // fall-back to the single-kernel filtered update (2) for batches of mostly unique keys; 1 / 2 / 8 / 9 = the
+    // single-kernel variants.  Bit set state: every batch takes the partitioned pass.
+    const bool part_kind = ctx->alive_variant == 3 || ctx->alive_variant == 13 || ctx->alive_variant == 4 || ctx->alive_variant == 14;
+    const bool partitioned = !ctx->alive_table || (part_kind && (n >= kta::kAlivePartitionMin || ctx->alive_variant >= 13));
+    bool use_partitioned = partitioned;
+    if ((which & 2) && ctx->alive && partitioned && ctx->alive_table && ctx->alive_variant < 13) {   // automatic choice only (13 forces it)
+        if (ctx->alive_stats_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
+            ctx->alive_stats_pending = false;
+            const uint64_t pairs = ctx->h_alive_stats[0], claims = ctx->h_alive_stats[1];
+            if (pairs && claims * kAliveUniqueDen > pairs * kAliveUniqueNum) ctx->alive_backoff = kAliveBackoff;
+        }
+        if (ctx->alive_backoff > 0) {
+            ctx->alive_backoff--;
+            use_partitioned = false;
+        }
+    }
+    // Both handlers over one batch (what kafka.rs:107-109 does with every message): with at most 256 partitions, pass 1 of
+    // the partitioned alive-key pass does the metrics handler's work as well (kta_alive.hip, FuseArgs) — the batch is read
+    // once: 40 B + key per record instead of 20 + 28 in the bit set state, 48 B + key instead of 20 + 36 for a sharded
+    // rank's batch with its seq column (table state).
     bool fuse = false;
-    if (which == 3 && ctx->alive && !ctx->alive_table && !ctx->analytics && ctx->fuse_handlers) {
+    if (which == 3 && ctx->alive && use_partitioned && !ctx->analytics && ctx->fuse_handlers) {
         const uint64_t first = n > kta::kAlivePartitionMax ? kta::kAlivePartitionMax : n;
-        const kta::AlivePartitionPlan pl0 = kta::plan_alive_partition(first, ctx->alive_wgs, ctx->cu_count, true);
+        const kta::AlivePartitionPlan pl0 = kta::plan_alive_partition(first, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
         fuse = kta::alive_fuse_possible(pl0, ctx->P) && pl0.segment_wgs <= ctx->max_rows;
     }
     if (which & 1) {
@@ -270,34 +289,11 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
         // Bit set state: every batch takes the partitioned pass (hash + partition, per-bucket merge in LDS, the
         // bucket's bitmap region streamed through LDS); batches are applied in submission order, base_seq and a
         // seq column are not looked at.
-        // Table state: 3 = the partitioned pass for batches of >= 2^21 records (13: for batches of any size —
-        // tests), with the automatic fall-back to the single-kernel filtered update (2) for batches of mostly
-        // unique keys; 1 / 2 / 8 / 9 = the single-kernel variants.  A seq column has to ascend inside a batch
-        // for the partitioned pass (the merge orders a batch's records by their index): checked on the device,
-        // and a batch that fails the check runs the filtered update instead, conditionally, without a host
-        // round trip.
-        const bool part_kind = ctx->alive_variant == 3 || ctx->alive_variant == 13 || ctx->alive_variant == 4 || ctx->alive_variant == 14;
-        const bool partitioned = !ctx->alive_table || (part_kind && (n >= kta::kAlivePartitionMin || ctx->alive_variant >= 13));
+        // Table state: the choice made above.  A seq column has to ascend inside a batch for the partitioned pass (the
+        // merge orders a batch's records by their index): checked on the device, and a batch that fails the check runs
+        // the filtered update instead, conditionally, without a host round trip.  (Both partition kernels read their
+        // columns 4 bytes per lane: any alignment will do.)
         if (ctx->alive_table && ctx->alive_variant != 1 && ctx->alive_variant != 2 && !part_kind) ctx->running_valid = false;   // non-counting kernels
-        bool use_partitioned = partitioned;
-        if (partitioned && ctx->alive_table && ctx->alive_variant < 13) {          // automatic choice only (13 forces it)
-            if (ctx->alive_stats_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
-                ctx->alive_stats_pending = false;
-                const uint64_t pairs = ctx->h_alive_stats[0], claims = ctx->h_alive_stats[1];
-                if (pairs && claims * kAliveUniqueDen > pairs * kAliveUniqueNum) ctx->alive_backoff = kAliveBackoff;
-            }
-            if (ctx->alive_backoff > 0) {
-                ctx->alive_backoff--;
-                use_partitioned = false;
-            }
-        }
-        // (table state: its partition kernel reads the three i32 columns 16 bytes at a time, aligned down together;
-        // columns that do not share their alignment modulo 16 take the single-kernel update, which reads them 4 bytes
-        // at a time.  The bit set state's kernel has no such wish.)
-        if (use_partitioned && ctx->alive_table &&
-            (((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->val_len)) & 15u) ||
-             ((reinterpret_cast<uintptr_t>(c->key_len) ^ reinterpret_cast<uintptr_t>(c->key_off)) & 15u)))
-            use_partitioned = false;
         if (use_partitioned) {
             if (!ctx->d_alive_stats) {   // (four words: builds with KTA_ALIVE_PHASES add instalments and side-table entries)
                 KTA_HIP(ctx, hipMalloc((void **)&ctx->d_alive_stats, 4 * sizeof(uint64_t)));
@@ -350,7 +346,8 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                     ctx->info_fused++;
                     const uint32_t row_len = kta::scan_row_len(ctx->P, false);
                     const kta::AliveFuse fz{c->partition + at, c->ts_ms + at, ctx->P, ctx->d_partials, row_len};
-                    KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws, nullptr, ctx->s_compute, &fz));
+                    KTA_HIP(ctx, kta::launch_alive_partitioned(sl, take, base_seq + at, st, pl, ws, report ? ctx->d_alive_stats : nullptr,
+                                                               ctx->s_compute, &fz));
                     KTA_HIP(ctx, kta::launch_fold_partials(ctx->d_partials, pl.segment_wgs, ctx->P, ctx->d_vec, row_len, ctx->d_avec,
                                                            ctx->s_compute));
                 } else {

@@ -417,46 +417,69 @@ def test_partitioned_alive_pass_at_scale_vs_oracle(hc, ht, state, preset, log2n)
     hc.device_batch_free(b)
 
 
+@pytest.mark.parametrize("state", ["bitset", "table"])
 @pytest.mark.parametrize("P,n,runs", [(1, 70_001, False), (8, 300_000, True), (64, 2_500_000, False), (256, 3_000_003, True),
                                       (257, 200_000, False)])
-def test_both_handlers_in_one_pass_vs_oracle(P, n, runs):
-    """which = 3 in the bit set state with at most 256 partitions: the partition kernel of the alive-key pass also does
+def test_both_handlers_in_one_pass_vs_oracle(P, n, runs, state):
+    """which = 3 with at most 256 partitions: the partition kernel of the alive-key pass also does
     MessageMetrics::handle_message (/root/reference/src/kafka.rs:107-109: every handler sees every message) — counters,
     extrema, averages and panics, alive count and every bit against the oracle; null / empty keys and values, -1
     timestamps, sizes up to 2^31 - 1, batch lengths that are multiples of nothing, two batches.  257 partitions take the
-    two passes (the fused pass keeps 256 partitions' sums in LDS)."""
+    two passes (the fused pass keeps 256 partitions' sums in LDS).  Table state (what a rank of a sharded run keeps): the
+    partitioned pass forced onto these small batches, the second batch with a seq column of global sequence numbers —
+    submitted FIRST: the largest sequence number wins whatever the order of the batches — and the library's own counters
+    say that the fused pass ran."""
     rng = np.random.default_rng(4000 + P)
     o = Oracle(NOW, True)
-    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+    table = state == "table"
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=table) as h:
+        if table:
+            h.set_tuning(alive_variant=13)
+        parts, at = [], 0
         for part in range(2):
             cols = random_cols(rng, n // (part + 1), P, key_space=50_000, tomb=0.3, runs=runs, big_sizes=(P == 8))
             o.run_soa(cols)
+            m = len(cols["partition"])
+            if table and part == 1:
+                cols["seq"] = at + 2 * np.arange(m, dtype=np.uint64)       # ascending, with gaps
+            parts.append((cols, at))
+            at += m
+        for cols, base in (reversed(parts) if table else parts):
             b, nb = h.upload_batch(cols, with_keys=True)
-            h.submit_device(b, nb, 0, which=3)
+            h.submit_device(b, nb, base, which=3)
             h.device_batch_free(b)
         _compare(h, o, P, check_bitmap=True)
+        info = h.alive_pass_info()
+        assert info["slices"] == 2 and info["fused"] == (2 if P <= 256 else 0)
     o.close()
 
 
-def test_both_handlers_in_one_pass_equals_two_passes_with_bad_partition_ids():
+@pytest.mark.parametrize("state", ["bitset", "table"])
+def test_both_handlers_in_one_pass_equals_two_passes_with_bad_partition_ids(state):
     """The fused pass and the two passes (kta_set_fuse(ctx, 0)) leave the same vector, bit for bit, also for what the reference
     has no word for: partition ids outside [0, P) (counted and reported, never accumulated) — while the alive set, which
-    ignores the partition (metric.rs:289-304), takes those records' keys either way."""
+    ignores the partition (metric.rs:289-304), takes those records' keys either way.  Table state: with a seq column."""
     P, n = 64, 1_200_007
     rng = np.random.default_rng(4100)
     cols = random_cols(rng, n, P, key_space=20_000, tomb=0.4)
     cols["partition"][::1001] = 64
     cols["partition"][5::7777] = -3
     cols["partition"][11::9001] = 2**31 - 1
+    table = state == "table"
+    if table:
+        cols["seq"] = 1000 + 3 * np.arange(len(cols["partition"]), dtype=np.uint64)
     got = []
     for fuse in (True, False):
-        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW)
+        h = kta.HipMetricHandler(P, count_alive_keys=True, now=NOW, alive_table=table)
         h.set_fuse(fuse)
+        if table:
+            h.set_tuning(alive_variant=13)
         b, nb = h.upload_batch(cols, with_keys=True)
         h.submit_device(b, nb, 0, which=3)
         h.device_batch_free(b)
         res, c = h.finish(allow_bad_partition=True)      # (waits for the batch)
         vec = h.result_vector_host().copy()
+        assert h.alive_pass_info()["fused"] == (1 if fuse else 0)
         got.append((vec, c.copy(), int(res.bad_partition_records), int(res.alive_keys), h.export_alive_bitmap()))
         h.close()
     bad = int(((cols["partition"] < 0) | (cols["partition"] >= P)).sum())
