@@ -701,14 +701,23 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libkta_hip has no CPU fallback")
+    # KTA_BENCH_SHARE_DEVICE=1 (tests on a 1-GPU box, with KTA_RCCL_LIBRARY pointing at the test double of RCCL — real RCCL
+    # refuses two ranks on one device): every rank on device 0; the line then carries "shared_device": true
+    share_device = os.environ.get("KTA_BENCH_SHARE_DEVICE") == "1"
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # KTA_BENCH_FORCE_COLLECTIVES=1: run the exchange step even with one rank (exercises the RCCL path
     # on a 1-GPU box; the line then carries "forced_collectives": true and is not a headline number)
     force_coll = os.environ.get("KTA_BENCH_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ
     exchange = world > 1 or force_coll
     if exchange:
+        # torch.distributed is the CONTROL plane only — the rendezvous (RCCL's 128-byte id), the barriers around the timed
+        # region, the max over ranks of the elapsed time — and runs over gloo on CPU tensors: every rank process holds ONE
+        # RCCL, the library's own (csrc/kta_comm.hip), which carries every byte of the data path.  (Rounds 1-5 initialised
+        # torch's bundled RCCL as well: two RCCLs in a process, and a path no 2-rank run had ever executed.)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     P = 256
     c5 = args.config == "c5"
@@ -734,13 +743,13 @@ def main():
         # all-reduce SUM + all-reduce MAX on the context's compute stream, stream-ordered behind the fold
         # kernel: a step has no host synchronisation).  torch.distributed only carries the rendezvous (the
         # 128-byte RCCL id), the barriers and the max-over-ranks of the elapsed time.
-        uid = torch.zeros(N.KTA_COMM_ID_BYTES, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+        uid = torch.zeros(N.KTA_COMM_ID_BYTES, dtype=torch.uint8)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(kta.HipMetricHandler.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         if world == 1:
             os.environ["KTA_COMM_FORCE_RCCL"] = "1"        # forced mode: a real one-rank communicator
-        h.comm_create(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        h.comm_create(world, rank, bytes(uid.numpy().tobytes()))
 
     passes = [0]
 
@@ -783,7 +792,7 @@ def main():
     h.set_timing(False)
 
     if exchange:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -827,7 +836,8 @@ def main():
                                     "~256 B), partitions sharded p % n_gpus"), "records_per_gpu": n,
                        "total_records_per_step": n * world, "partitions": P, "partition_order": args.part_mode,
                        "bytes_per_record": BYTES_PER_RECORD, "parallelism": f"partition-sharded x{world}",
-                       "forced_collectives": bool(force_coll),
+                       "forced_collectives": bool(force_coll), "shared_device": bool(share_device),
+                       "control_plane": "torch.distributed over gloo (rendezvous, barriers, max of the elapsed time)" if exchange else None,
                        "exchange": "none (1 GPU)" if not exchange else
                                    ("per step: kta_exchange = alive entries to their hash-range owners (count all-gather, "
                                     "grouped ncclSend / ncclRecv, owner merge + range count), then " if c5 else "per step: kta_exchange = ") +

@@ -301,7 +301,7 @@ def test_baseline_config_5_key_law_sharded_over_two_ranks_with_exchange(tmp_path
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = tmp_path / "libmock_rccl.so"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(root, "tests", "mock_rccl.cpp"),
-                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
+                        "-o", str(lib), "-lrt", "-lpthread"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     script = tmp_path / "w.py"
     script.write_text(_C5_WORKER)

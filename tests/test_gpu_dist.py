@@ -223,6 +223,14 @@ print("OK", stats)
 '''
 
 
+def _build_mock_rccl(tmp_path):
+    lib = tmp_path / "libmock_rccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
+                        "-o", str(lib), "-lrt", "-lpthread"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return lib
+
+
 @pytest.mark.parametrize("nranks,P,alive", [(2, 10, True), (3, 10, True), (4, 256, True), (8, 256, False)])
 def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks, P, alive):
     """The multi-rank paths of csrc/kta_comm.hip (per-owner export, count all-gather, grouped send / recv,
@@ -232,13 +240,74 @@ def test_native_exchange_logic_with_rccl_test_double(tmp_path, nranks, P, alive)
     config 4's sharding (256 partitions, 32 per rank, p % 8) runs with all eight communicator ranks; with -c every
     rank keeps a 32 GiB table, of which four fit the one GPU here and eight do not (8 x 32 GiB + workspaces > 288 GB),
     so the hash-range exchange runs with four owners (hash_range(r, 4))."""
-    lib = tmp_path / "libmock_rccl.so"
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
-                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    lib = _build_mock_rccl(tmp_path)
     script = tmp_path / "w.py"
     script.write_text(_THREADED_WORKER)
     env = dict(os.environ, KTA_RCCL_LIBRARY=str(lib))
     r = subprocess.run([sys.executable, str(script), ROOT, str(nranks), str(P), "1" if alive else "0"], capture_output=True,
                        text=True, timeout=900, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+# ---- the driver's own launch line: one bench.py process per rank ------------------------------------------------
+def _run_bench_ranks(tmp_path, nproc, port, extra, timeout=900):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` as the driver launches it,
+    on the one reachable GPU: every rank process on device 0 (KTA_BENCH_SHARE_DEVICE=1), the library's RCCL replaced by the
+    process-capable test double (tests/mock_rccl.cpp: shared-memory rendezvous keyed by the unique id).  Returns rank 0's
+    JSON line."""
+    lib = _build_mock_rccl(tmp_path)
+    env = dict(os.environ, KTA_RCCL_LIBRARY=str(lib), KTA_RCCL_ONLY_ENV="1", KTA_BENCH_SHARE_DEVICE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline", "--no-alive",
+           "--no-decode", "--no-hostfed"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_rank_processes_config_4(tmp_path, mode):
+    """bench.py's N > 1 path with two rank PROCESSES (gloo rendezvous + barriers, ONE RCCL per process: the library's):
+    config 4's sharding p -> rank p % 2, weak and strong scaling.  bench.py itself asserts that the exchanged result holds
+    the whole job's record count and every partition; here the line's own bookkeeping is checked."""
+    n = 1 << 23
+    line = _run_bench_ranks(tmp_path, 2, 29531 if mode == "weak" else 29532, ["--records-per-gpu", str(n), "--scaling", mode])
+    per_rank = n if mode == "weak" else n // 2
+    assert line["n_gpus"] == 2 and line["scaling"] == mode and line["steps"] == 3
+    assert line["config"]["records_per_gpu"] == per_rank and line["config"]["total_records_per_step"] == 2 * per_rank
+    assert line["config"]["shared_device"] is True and line["config"]["forced_collectives"] is False
+    assert "gloo" in line["config"]["control_plane"] and "kta_exchange" in line["config"]["exchange"]
+    assert abs(line["value"] - 2 * per_rank * 3 / (line["ms_per_step"] * 3e-3)) < 1e-3 * line["value"]
+    assert line["roofline"]["launches"] == 3 and line["roofline"]["frac"] > 0.02
+
+
+def test_bench_two_rank_processes_config_5(tmp_path):
+    """--config c5 with two rank processes: both handlers per step (the fused table pass) and the WHOLE exchange — alive
+    entries to their hash-range owners (count all-gather, grouped send / recv, owner merge), then the grouped all-reduces.
+    The alive count of the exchanged result against the C oracle: every pass submits the same records with later sequence
+    numbers, rank 0's before rank 1's, so what is left is rank 0's batch followed by rank 1's."""
+    import kafka_topic_analyzer_amd as kta
+    from kafka_topic_analyzer_amd import distributed as D
+    from oracle_c import Oracle
+    n = 1 << 21
+    line = _run_bench_ranks(tmp_path, 2, 29533, ["--records-per-gpu", str(n), "--config", "c5"])
+    assert line["n_gpus"] == 2 and line["config"]["records_per_gpu"] == n
+    spec, _ = kta.synth_preset("c5")
+    o = Oracle(count_alive_keys=True)
+    for rank in range(2):
+        o.run_soa(kta.synth_fill_host(D.shard_spec(spec, rank, 2), rank * n, n, with_keys=True))
+    assert line["alive_pass"]["alive_keys"] == o.alive_keys() > 0
+    o.close()
+
+
+def test_bench_eight_rank_processes_config_4(tmp_path):
+    """The target machine's eight ranks as eight bench.py processes (without -c: eight 32 GiB tables do not fit one GPU):
+    config 4's sharding, 32 partitions per rank, one grouped all-reduce per step."""
+    n = 1 << 21
+    line = _run_bench_ranks(tmp_path, 8, 29534, ["--records-per-gpu", str(n)], timeout=1200)
+    assert line["n_gpus"] == 8 and line["config"]["total_records_per_step"] == 8 * n
+    assert line["config"]["parallelism"] == "partition-sharded x8"

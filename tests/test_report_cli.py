@@ -264,7 +264,7 @@ def test_cli_on_raw_kafka_log_segments(tmp_path, with_c):
 def mock_rccl(tmp_path_factory):
     lib = tmp_path_factory.mktemp("mock") / "libmock_rccl.so"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "mock_rccl.cpp"),
-                        "-o", str(lib)], capture_output=True, text=True, timeout=600)
+                        "-o", str(lib), "-lrt", "-lpthread"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return str(lib)
 
