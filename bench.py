@@ -126,6 +126,49 @@ def cpu_baseline_metrics(h, batch, n_sample, P, min_seconds=10.0):
     return out
 
 
+def boundary_per_message_report(kta, device, n_records=1 << 26, seconds=6.0):
+    """What the drop-in costs per message.  /root/reference/src/kafka.rs:107-109 calls handle_message once per polled message;
+    its replacement is kta_handle_message (copies partition, timestamp, lengths and — with -c — the key bytes into a pinned
+    staging batch, submits the batch when it is full).  ONE host thread replays host-resident records through that entry
+    in a native loop (kta_replay_messages: an indirect call per message, no ctypes), the GPU's work — H2D copy, both
+    handlers — overlapped behind it; records/s, with the host-side breakdown the library keeps (kta_handle_message_stats).
+    Two rows: config 4's records (metrics handler), config 3's with 16-byte keys and -c (both handlers)."""
+    rows = {}
+    for name, preset, alive, P in (("c4", "c4", False, 256), ("c3_alive_keys", "c3", True, 64)):
+        spec, _ = kta.synth_preset(preset)
+        cols = kta.synth_fill_host(spec, 0, n_records, with_keys=alive)
+        h = kta.HipMetricHandler(P, count_alive_keys=alive, device=device, batch_capacity=1 << 22,
+                                 key_bytes_capacity=(16 << 22) if alive else 0, n_staging=3)
+        h.replay_messages(cols, min(n_records, 1 << 24))      # warm-up: staging slabs pinned, kernels loaded
+        h.sync()
+        h.reset()
+        passes, t0 = 0, time.perf_counter()
+        while passes < 64:
+            h.replay_messages(cols)
+            passes += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        h.flush()
+        t_host = time.perf_counter() - t0                     # the caller's thread is free again here
+        h.sync()
+        t_all = time.perf_counter() - t0
+        st = h.handle_message_stats()
+        res, _ = h.finish()
+        assert res.overall_count == n_records * passes == st["messages"], "the per-message entry lost records"
+        rows[name] = {"records": n_records * passes, "value": n_records * passes / t_all, "unit": "records/s",
+                      "host_thread_records_per_s": n_records * passes / t_host, "ns_per_message": t_host / (n_records * passes) * 1e9,
+                      "host_breakdown": {"staging_batches": st["batches"], "submit_ms_total": st["submit_ns"] / 1e6,
+                                         "ring_wait_ms_total": st["ring_wait_ns"] / 1e6,
+                                         "copy_into_pinned_columns_ms_total": (t_host * 1e9 - st["submit_ns"] - st["ring_wait_ns"]) / 1e6},
+                      "bytes_per_record_over_pcie": 20 + (4 + 16 if alive else 0),
+                      **(_alive_checked(res.alive_keys, "c3", 0, n_records) if alive else {})}
+        h.close()
+    return {"what": "kta_handle_message per record on ONE host thread (native replay loop, indirect call per message), GPU work "
+                    "overlapped; reference boundary: MetricHandler::handle_message, kafka.rs:107-109", "host_cores_used": 1,
+            "rows": rows, "note": "compare with cpu_baseline (the reference's handlers on one core): this is the same thread's "
+                                   "cost when the handlers' work is the GPU's"}
+
+
 def alive_pass_report(kta, device, steps, warmup, n_records, cpu_seconds, extras=True):
     """The --count-alive-keys pass (FNV + the reference's bit set) on the config-3 shape.  The batch is as large as
     the ABI takes with 16-byte keys (key_off is a u32: < 4 GiB of key bytes): the bit set's 512 MiB are streamed
@@ -717,6 +760,8 @@ def main():
         # RCCL, the library's own (csrc/kta_comm.hip), which carries every byte of the data path.  (Rounds 1-5 initialised
         # torch's bundled RCCL as well: two RCCLs in a process, and a path no 2-rank run had ever executed.)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: no need to resolve the host's own name
         dist.init_process_group(backend="gloo")
 
     P = 256
@@ -875,6 +920,7 @@ def main():
                                                        args.decode_records, args.cpu_seconds)
         if world == 1 and not args.no_hostfed and not c5:
             # PCIe-inclusive legs (the link is the bound: never `value`)
+            line["boundary_per_message"] = boundary_per_message_report(kta, local_rank)
             line["host_fed"] = host_fed_report(kta, local_rank)
             line["raw_log_e2e"] = raw_log_e2e_report(kta, local_rank)
         sys.stdout.flush()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 5   /* 5: kta_set_fuse, kta_alive_pass_info; 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
+#define KTA_ABI_VERSION 6   /* 6: kta_replay_messages, kta_handle_message_stats; the table state takes the fused pass; kta_kafka_set_variant takes 0, 1, 2, 10, 11 only (the other geometries went in round 5); 5: kta_set_fuse, kta_alive_pass_info; 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
 
 /* status codes */
 #define KTA_OK 0
@@ -193,6 +193,16 @@ int kta_handle_message(kta_ctx *ctx, int32_t partition, int64_t ts_ms, const voi
                        int64_t key_len, int64_t val_len);
 /* Submit the partially filled staging batch, if any. */
 int kta_flush(kta_ctx *ctx);
+/* kta_handle_message for each of the n records of HOST columns, in order — what the reference's consume loop
+ * (kafka.rs:92-135) does with the messages it polls, as a native loop: a host in a language with an expensive foreign
+ * call (the ctypes mirror, a JVM) replays decoded records through the per-message entry without paying that call per
+ * message, and bench.py times the entry itself with it (`boundary_per_message`).  cols: partition, key_len, val_len,
+ * ts_ms; with -c also key_off and key_bytes (a key of length >= 0 is passed as a non-null pointer, -1 as key None). */
+int kta_replay_messages(kta_ctx *ctx, const kta_batch *host_cols, uint64_t n);
+/* Host-side cost of the per-message entry since kta_create / kta_reset: out[0] messages taken, out[1] staging batches
+ * submitted by it, out[2] nanoseconds spent submitting them (the copy's and the kernels' launches), out[3] nanoseconds
+ * blocked because the staging ring had wrapped onto a batch still in flight (the GPU, or the link, was the slower side). */
+int kta_handle_message_stats(kta_ctx *ctx, uint64_t out[4]);
 /* The next record of kta_handle_message / kta_kafka_consume gets this global sequence number (a rank of a
  * sharded run positions itself at the first record of each of its partitions' stretches). */
 int kta_seek_seq(kta_ctx *ctx, uint64_t next_seq);

@@ -121,6 +121,27 @@ class HipMetricHandler:
     def flush(self) -> None:
         self._check(self._lib.kta_flush(self._ctx))
 
+    def replay_messages(self, cols: dict, n: Optional[int] = None) -> None:
+        """kta_handle_message for every record of host (numpy) columns, as a native loop (kta_replay_messages)."""
+        b = KtaBatch()
+        keep = []
+        for name, dt in (("partition", np.int32), ("key_len", np.int32), ("val_len", np.int32), ("ts_ms", np.int64)):
+            a = np.ascontiguousarray(cols[name], dtype=dt)
+            keep.append(a)
+            setattr(b, name, a.ctypes.data)
+        if "key_off" in cols and "key_bytes" in cols:
+            ko = np.ascontiguousarray(cols["key_off"], dtype=np.uint32)
+            kb = np.ascontiguousarray(cols["key_bytes"], dtype=np.uint8)
+            keep += [ko, kb]
+            b.key_off, b.key_bytes = ko.ctypes.data, kb.ctypes.data
+        m = len(keep[0]) if n is None else n
+        self._check(self._lib.kta_replay_messages(self._ctx, C.byref(b), m))
+
+    def handle_message_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.kta_handle_message_stats(self._ctx, C.byref(out)))
+        return {"messages": int(out[0]), "batches": int(out[1]), "submit_ns": int(out[2]), "ring_wait_ns": int(out[3])}
+
     def submit_columns(self, partition, key_len, val_len, ts_ms, key_off=None, key_bytes=None,
                        base_seq: Optional[int] = None) -> None:
         """Feed a struct-of-arrays batch through the pinned staging ring (chunked to its capacity)."""

@@ -108,6 +108,8 @@ SIGNATURES = {
     "kta_handle_message": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
     "kta_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "kta_flush": (C.c_int, [_P]),
+    "kta_replay_messages": (C.c_int, [_P, C.c_void_p, C.c_uint64]),
+    "kta_handle_message_stats": (C.c_int, [_P, C.POINTER(C.c_uint64 * 4)]),
     "kta_seek_seq": (C.c_int, [_P, C.c_uint64]),
     "kta_batch_acquire": (C.c_int, [_P, C.POINTER(KtaBatch)]),
     "kta_batch_submit": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -184,7 +186,7 @@ SIGNATURES = {
 _lib = None
 
 
-KTA_ABI_VERSION = 5  # include/kta_hip.h
+KTA_ABI_VERSION = 6  # include/kta_hip.h
 
 
 def load() -> C.CDLL:

@@ -57,7 +57,7 @@ for d in (1, 40):
 table[f"c5:0:0:{n_big}"] = alive_after("c5", 0, n_big)[n_big]
 # alive_pass / both_handlers resubmit records [0, n_big) (idempotent); alive_pass_table walks six consecutive batches
 steps = [n_big * (k + 1) for k in range(6)]
-for upto, v in alive_after("c3", 0, steps[-1], steps).items():
+for upto, v in alive_after("c3", 0, steps[-1], [n_hot] + steps).items():     # (n_hot: boundary_per_message's c3 row)
     table[f"c3:0:0:{upto}"] = v
 json.dump({"source": "tests/golden/make_bench_alive_counts.py (C oracle over the generator's records, CPU)", "alive_keys": table},
           sys.stdout, indent=1)

@@ -113,6 +113,24 @@ def test_golden_scenarios_per_message_entry(hc, name):
 
 
 # ------------------------------------------------------------------------------------- random streams
+@pytest.mark.parametrize("state", ["bitset", "table"])
+def test_native_replay_through_the_per_message_entry(hc, ht, state):
+    """kta_replay_messages = kta_handle_message for every record of host columns (the reference's loop, kafka.rs:107-109), as a
+    native loop: counters, extrema, alive count and the alive set equal the oracle's; null and empty keys stay distinct; the
+    library's own bookkeeping counts every message and the staging batches it submitted (a staging batch holds 2^16 records)."""
+    hc = ht if state == "table" else hc
+    rng = np.random.default_rng(31)
+    cols = random_cols(rng, 150_001, 8, key_space=4000, tomb=0.35)
+    o = Oracle(NOW, True)
+    o.run_soa(cols)
+    hc.reset()
+    hc.replay_messages(cols)
+    hc.flush()
+    st = hc.handle_message_stats()
+    assert st["messages"] == len(cols["partition"]) and st["batches"] == len(cols["partition"]) // (1 << 16)
+    _compare(hc, o, 8, check_bitmap=True)
+
+
 @pytest.mark.parametrize("P,n,runs,variant", [
     (1, 5000, False, 0), (1, 70001, True, 16), (3, 20000, False, 16), (8, 150000, False, 0),
     (8, 150000, True, 16), (64, 200003, False, 16), (256, 300000, False, 0), (256, 300000, True, 16),
