@@ -649,14 +649,19 @@ def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
     buf = np.zeros(ln.value + 64, np.uint8)
     lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n_records, rpb, buf.ctypes.data, ln.value, C.byref(ln))
     out = {}
-    for alive in (False, True):
+    # (the first leg of the process pays what the second does not — the blob ring's pinned pages touched for the first time, the
+    # decode kernels loaded: round 5's line had `metrics` at 46 GB/s behind `count_alive_keys` at 52 on the same blobs — so an
+    # untimed leg goes first and the order of the timed ones decides nothing)
+    for alive in (None, False, True):
+        warm_only = alive is None
+        alive = bool(alive)
         h = kta.HipMetricHandler(256, count_alive_keys=alive, device=device)
         h._check(lib.kta_kafka_configure(h._ctx, 0, 3))
         filled, sizes, recs = 0, [], []
         total_bytes = total_recs = 0
         stages, at, k = 3, 0, 0
         t0 = None
-        for k in range(stages + passes * stages):
+        for k in range(stages + (1 if warm_only else passes) * stages):
             if k == stages:
                 h.sync()
                 t0 = time.perf_counter()
@@ -678,7 +683,10 @@ def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
         h.sync()
         dt = time.perf_counter() - t0
         res, _ = h.finish(allow_bad_partition=True)
-        assert res.overall_count == sum(recs) * (passes + 1)
+        assert res.overall_count == sum(recs) * ((1 if warm_only else passes) + 1)
+        if warm_only:
+            h.close()
+            continue
         out["count_alive_keys" if alive else "metrics"] = {
             "workload": f"c4 records as v2 record batches of {rpb} (~16 KiB), uncompressed; {passes * stages} pinned blobs of "
                         f"{sizes[0]} bytes resubmitted" + (", -c (keys zero-copy from the blob)" if alive else ""),

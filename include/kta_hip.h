@@ -375,12 +375,12 @@ int kta_set_tuning(kta_ctx *ctx, int scan_workgroups, int scan_variant, int aliv
  * kta_create, only sets the initial value.  In the fused pass all kernel time is booked on timer kind 2 (the
  * alive-key update) and kinds 0 / 1 see only the fold: kta_kernel_time_stats returns launches[0] == 0 there. */
 int kta_set_fuse(kta_ctx *ctx, int enable);
-/* What the partitioned alive-key pass did since kta_create / kta_reset — host-side counters, nothing is waited for:
+/* What the partitioned alive-key pass did since kta_create / kta_reset:
  * out[0] the most records one launch pair takes (larger batches are applied piece after piece), out[1] launch pairs,
  * out[2] of them with both handlers in the one pass, out[3] of them whose metrics handler ran as a scan although the
- * batch began fused, out[4] buckets handed to the fallback kernel (hot keys that overflow their segments; exact, slow) as
- * far as sampled — the last launch of every bit-set-state batch of 2^24 records and more, read when the NEXT batch or this
- * call finds the copy complete —, out[5] the fuse switch. */
+ * batch began fused, out[4] buckets handed to the fallback kernel (hot keys that overflow their segments; exact, slow) —
+ * counted on the device by every launch pair; this call waits for the context's compute stream to read the word —,
+ * out[5] the fuse switch. */
 int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6]);
 
 #ifdef __cplusplus

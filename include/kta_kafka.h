@@ -125,9 +125,9 @@ int kta_kafka_decode_rounds_host(const uint8_t *blob, uint64_t blob_len, const k
                                  int32_t *partition, int32_t *key_len, int32_t *val_len, int64_t *ts_ms,
                                  uint32_t *key_off, uint64_t *n_key_bytes, uint64_t *n_bad_batches);
 
-/* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned — 128-byte
- * aligned, as hipMalloc and the blob ring give it, for the kernel's window loads to fall on whole lines —
- * readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
+/* Device: parse the records of `n_batches` indexed batches out of `blob_device` (16-byte aligned: that is all
+ * correctness asks for; 128-byte alignment, as hipMalloc and the blob ring give it, is a performance recommendation
+ * only — the kernel's window loads then fall on whole lines — readable for 64 bytes past `blob_len`) into the device columns `out` (capacity >= total records).
  * Keys are ZERO-COPY: when out->key_off is set, key_off[i] is the offset of record i's key inside the
  * blob, so the caller passes `blob_device` itself as `key_bytes` when submitting the columns
  * (out->key_bytes is ignored; the blob must then be < 4 GiB and stay alive until the kernels ran).

@@ -1951,7 +1951,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
                                                                     const uint32_t *__restrict__ fail_from,
                                                                     const uint32_t *__restrict__ pool_hist,
                                                                     uint32_t *__restrict__ bitmap,
-                                                                    long long *__restrict__ running)
+                                                                    long long *__restrict__ running,
+                                                                    unsigned long long *__restrict__ failed_total)
 {
     constexpr uint32_t RBITS = 32 - BLOG2;
     constexpr uint32_t kSub = 1u << 14;                  // slots per pass
@@ -1966,6 +1967,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_fallback(const uint32
     // sub-ranges (twelve such buckets took 20 ms with one workgroup each while 244 CUs idled).
     const uint32_t nfail = (uint32_t)pool_ctl[POOL_FAILED];
     if (nfail == 0u) return;
+    if (failed_total && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(failed_total, (unsigned long long)nfail);   // kta_alive_pass_info
     constexpr uint32_t B = 1u << BLOG2;
     uint32_t share = B / (nfail < B ? nfail : B);
     share = share > 32u ? 32u : share;
@@ -2179,7 +2181,8 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kta_alive_fallback<BLOG2>), dim3(B), dim3(kApplyThreads), lds3, s, reinterpret_cast<const uint32_t *>(pp),
-                           ws.counts, pl.cap, pl.segment_wgs, pool, pl.pool_pairs, ctl, ws.fail_from, hist, st.bitmap, run);
+                           ws.counts, pl.cap, pl.segment_wgs, pool, pl.pool_pairs, ctl, ws.fail_from, hist, st.bitmap, run,
+                           reinterpret_cast<unsigned long long *>(ws.failed_total));
         KTA_UB_MARK(3);
         return hipGetLastError();
     }
@@ -2235,11 +2238,6 @@ const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2)
 {
     return reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned long long *>(ws.pool_ctl) + POOL_WORDS) +
            (1u << bucket_log2);
-}
-
-const void *alive_failed_word(const AliveWorkspace &ws)
-{
-    return reinterpret_cast<const unsigned long long *>(ws.pool_ctl) + POOL_FAILED;
 }
 
 AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32)

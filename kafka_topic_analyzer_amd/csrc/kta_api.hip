@@ -86,7 +86,7 @@ struct kta_ctx {
     hipEvent_t ev_alive_stats = nullptr;
     bool alive_stats_pending = false;
     bool fuse_handlers = true;      // both handlers of a batch in one pass where that is possible (KTA_NO_FUSE=1: never)
-    bool alive_failed_pending = false;
+    uint64_t *d_failed_total = nullptr; // buckets handed to kta_alive_fallback since create / reset (kta_alive_pass_info)
     int alive_backoff = 0;
     // what the partitioned pass did since kta_create / kta_reset (kta_alive_pass_info): launch pairs, of them with both
     // handlers in the one pass, of them with the metrics handler through the scan although the batch began fused, and the
@@ -316,17 +316,15 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
             // The number of such buckets is sampled for kta_alive_pass_info.  (Round 4 applied the batches that followed one
             // with such buckets in slices of 2^26 records; with the groups sized from the fills a whole batch of config 5's
             // law takes 8.2 ms where four slices took 10.1, and the slicing went.)
-            if (!ctx->alive_table && ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
-                ctx->alive_failed_pending = false;
-                ctx->info_failed_buckets += ctx->h_alive_stats[2];
+            if (!ctx->d_failed_total) {
+                KTA_HIP(ctx, hipMalloc((void **)&ctx->d_failed_total, sizeof(uint64_t)));
+                KTA_HIP(ctx, hipMemsetAsync(ctx->d_failed_total, 0, sizeof(uint64_t), ctx->s_compute));
             }
-            uint64_t first_take = 0;
             if (report) KTA_HIP(ctx, hipMemsetAsync(ctx->d_alive_stats, 0, 4 * sizeof(uint64_t), ctx->s_compute));
             for (uint64_t at = 0; at < n;) {
                 const uint64_t left = n - at;
                 kta::AlivePartitionPlan pl = kta::plan_alive_partition(left, ctx->alive_wgs, ctx->cu_count, !ctx->alive_table);
                 const uint64_t take = left < pl.max_records ? left : pl.max_records;
-                if (at == 0) first_take = take;
                 if (ctx->pairs_cap < pl.pair_words || ctx->pair_counts_cap < pl.count_words || ctx->pool_cap < pl.pool_words) {
                     KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
                     if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
@@ -349,7 +347,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                                      ctx->alive_table && c->seq ? c->seq + at : nullptr};
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,
                                    ctx->d_alive_running, written_list(ctx)};
-                kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from};
+                kta::AliveWorkspace ws{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from, ctx->d_failed_total};
                 ctx->info_slices++;
                 if (fuse && kta::alive_fuse_possible(pl, ctx->P) && pl.segment_wgs <= ctx->max_rows) {
                     ctx->info_fused++;
@@ -377,13 +375,6 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                                                           ctx->d_alive_running, ctx->s_compute,
                                                           kta::alive_order_flag(ws, (int)pl.bucket_log2), written_list(ctx)));
                 at += take;
-            }
-            if (!ctx->alive_table && !ctx->alive_failed_pending && first_take >= (1ull << 24)) {
-                KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats + 2, kta::alive_failed_word(
-                                                kta::AliveWorkspace{ctx->d_pairs, ctx->d_pair_counts, ctx->d_pool, ctx->d_pool_ctl, ctx->d_fail_from}),
-                                            sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->s_compute));
-                KTA_HIP(ctx, hipEventRecord(ctx->ev_alive_stats, ctx->s_compute));
-                ctx->alive_failed_pending = true;
             }
             if (report) {
                 KTA_HIP(ctx, hipMemcpyAsync(ctx->h_alive_stats, ctx->d_alive_stats, 2 * sizeof(uint64_t),
@@ -417,7 +408,7 @@ int reset_state(kta_ctx *ctx)
         ctx->running_valid = true;
         // a new topic: what the old one's batches taught about backing off does not carry over (a word still on its way
         // lands in h_alive_stats before any later copy — same stream — and is never looked at)
-        ctx->alive_failed_pending = false;
+        if (ctx->d_failed_total) KTA_HIP(ctx, hipMemsetAsync(ctx->d_failed_total, 0, sizeof(uint64_t), ctx->s_compute));
         ctx->alive_stats_pending = false;
         ctx->alive_backoff = 0;
         ctx->info_slices = ctx->info_fused = ctx->info_scanned = ctx->info_failed_buckets = 0;
@@ -552,6 +543,7 @@ void kta_destroy(kta_ctx *ctx)
     if (ctx->d_pool) (void)hipFree(ctx->d_pool);
     if (ctx->d_pool_ctl) (void)hipFree(ctx->d_pool_ctl);
     if (ctx->d_fail_from) (void)hipFree(ctx->d_fail_from);
+    if (ctx->d_failed_total) (void)hipFree(ctx->d_failed_total);
     if (ctx->d_hash_scratch) (void)hipFree(ctx->d_hash_scratch);
     if (ctx->d_alive_stats) (void)hipFree(ctx->d_alive_stats);
     if (ctx->h_alive_stats) (void)hipHostFree(ctx->h_alive_stats);
@@ -1151,10 +1143,12 @@ int kta_set_fuse(kta_ctx *ctx, int enable)
 int kta_alive_pass_info(kta_ctx *ctx, uint64_t out[6])
 {
     if (!ctx || !out) return KTA_ERR_INVALID;
-    // the word of the last batch that was sampled, if it has arrived (never waited for)
-    if (ctx->alive_failed_pending && hipEventQuery(ctx->ev_alive_stats) == hipSuccess) {
-        ctx->alive_failed_pending = false;
-        ctx->info_failed_buckets += ctx->h_alive_stats[2];
+    // the device's own count (every launch pair's fallback kernel adds what pass 2 handed it): waits for the compute stream
+    ctx->info_failed_buckets = 0;
+    if (ctx->d_failed_total) {
+        KTA_HIP(ctx, hipSetDevice(ctx->device));
+        KTA_HIP(ctx, hipMemcpyAsync(&ctx->info_failed_buckets, ctx->d_failed_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->s_compute));
+        KTA_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
     }
     out[0] = kta::kAlivePartitionMax;
     out[1] = ctx->info_slices;

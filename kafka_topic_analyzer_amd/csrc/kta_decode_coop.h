@@ -106,7 +106,7 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
     constexpr uint32_t NLOAD = W / (L * 16);      // staged 16-byte loads per lane and window
     constexpr uint32_t NT = R / L;                // parse rounds per window
     static_assert(W % (L * 16) == 0 && R % L == 0, "window geometry");
-    constexpr bool KIB = W % 1024 == 0;           // the wave loads a KiB of ONE window per instruction (the dispatcher's geometries)
+    constexpr bool KIB = kta::rec::line_windows(W);           // the wave loads a KiB of ONE window per instruction (the dispatcher's geometries)
     __shared__ uint4 s_win[G][W / 16 + 1];        // + 1: the register paths read whole dwords up to 16 bytes ahead
     __shared__ uint32_t s_start[G][R + 1];        // record starts relative to the window base; [found]: where the last one ends
     __shared__ uint64_t s_next[G];                // absolute position after the last chained record

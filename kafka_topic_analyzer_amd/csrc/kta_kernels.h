@@ -125,7 +125,9 @@ struct AliveWorkspace {
     uint32_t *counts;
     uint64_t *pool;
     void *pool_ctl;         // ctl_bytes
-    uint32_t *fail_from;    // u32[buckets] (bit set state)
+    uint32_t *fail_from;    // u32[2 x buckets] (bit set state): per bucket the first segment pass 2 left to kta_alive_fallback
+                            // (or none), then the list of the buckets it gave up
+    uint64_t *failed_total; // bit set state: += the buckets a launch pair handed to kta_alive_fallback (device word; may be null)
 };
 AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32);
 // Both handlers in one pass (bit set state): pass 1 also reads partition and ts_ms and writes one row of the scan's partial
@@ -145,8 +147,6 @@ hipError_t launch_alive_partitioned(const AliveColumns &c, uint64_t n, uint64_t 
                                     const AliveFuse *fuse = nullptr /* null: the alive-key pass only */);
 // device word that the launch pair sets when the batch's seq column does not ascend (the pair then did nothing)
 const uint32_t *alive_order_flag(const AliveWorkspace &ws, int bucket_log2);
-// bit set state: the word that counts the buckets the last launch pair handed to kta_alive_fallback
-const void *alive_failed_word(const AliveWorkspace &ws);
 // popcount of the bit set -> *out += (u64)
 hipError_t launch_bitmap_count(const uint32_t *bitmap, uint64_t *out, hipStream_t s);
 // K4: sum_all_alive (metric.rs:282-284): count table entries whose low bit is set -> *out (u64)

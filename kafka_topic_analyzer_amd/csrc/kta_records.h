@@ -26,7 +26,10 @@ namespace rec {
 // Where a window of W bytes that has to hold the byte at `pos` begins: on a 128-byte line for the windows the dispatcher uses
 // (the loads are non-temporal — the log is read once — and a window that begins inside a line would fetch that line twice), on a
 // 16-byte block for the small windows of the tests.  Host statement and kernel agree on it, so they agree on the rounds.
-KTA_REC_HD uint64_t window_base(uint64_t pos, uint32_t W) { return pos & ~(W >= 1024u ? 127ull : 15ull); }
+// line_windows(W): ONE predicate for both — a geometry whose windows are whole KiB takes the wave-wide KiB loads of the kernel
+// (kta_decode_coop.h) AND bases on 128-byte lines; every other window size gets the per-group 16-byte loads and 16-byte bases.
+constexpr bool line_windows(uint32_t W) { return W % 1024u == 0u; }
+KTA_REC_HD uint64_t window_base(uint64_t pos, uint32_t W) { return pos & ~(line_windows(W) ? 127ull : 15ull); }
 
 // The four bytes at byte offset (sh & 3) of the dword pair lo, hi.
 KTA_REC_HD uint32_t bytes4(uint32_t lo, uint32_t hi, uint32_t sh)

@@ -1,4 +1,4 @@
-// decode_coop_fuzz.cpp — TEST HARNESS: kafka_decode_coop / kafka_decode_coop_pf (csrc/kta_decode_coop.h, the kernel's own
+// decode_coop_fuzz.cpp — TEST HARNESS: kafka_decode_coop (csrc/kta_decode_coop.h, the kernel's own
 // source over tests/native/wave_emu.h) under AddressSanitizer on damaged record sets.  The blob lies in a heap block
 // of exactly the bytes the device contract promises (16-byte aligned, 64 readable bytes behind blob_len), the output
 // columns in blocks of exactly n_records entries: a read or write outside them aborts — on the GPU it would be a

@@ -86,7 +86,7 @@ int main(int argc, char **argv)
     const kta::AliveFuse fz{pt, ts, 256, partials, kta::scan_row_len(256, false)};
     printf("seq column: %s   both handlers in the pass: %s\n", with_seq ? "yes" : "no", with_fuse ? "yes" : "no");
     kta::AliveState st{table, bitmap, running};
-    kta::AliveWorkspace ws{pairs, counts, pool, ctl, fail_from};
+    kta::AliveWorkspace ws{pairs, counts, pool, ctl, fail_from, nullptr};
     uint64_t *d_stats;
     CK(hipMalloc(&d_stats, 32));
     hipEvent_t a, b;
