@@ -520,7 +520,9 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     # the same kernel family at other batch sizes (the geometry is chosen per call from the mean batch size):
     # one row per size, each with its own launch time — a profile's per-kernel average mixes them
     rep["by_batch_size"] = []
-    for rpb2, label in ((8, "~2 KiB"), (60, "~16 KiB"), (500, "~134 KiB")):
+    # (the last two rows: few, very large batches — 500 / 125 batches of 4 000 / 16 000 records — are bound by the serial chain
+    # of ONE batch, a dependent LDS read per record whatever the geometry: rows for the record, not a target)
+    for rpb2, label in ((8, "~2 KiB"), (60, "~16 KiB"), (500, "~134 KiB"), (4000, "~1 MiB"), (16000, "~4 MiB")):
         n2 = min(n_records, 2_000_000)
         lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n2, rpb2, None, 0, C.byref(ln))
         buf2 = np.zeros(ln.value + 64, np.uint8)

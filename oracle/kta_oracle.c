@@ -494,6 +494,33 @@ void kto_run_soa(kto_metrics *m, kto_logcompaction *lc, uint64_t n, const int32_
     }
 }
 
+/* TEST HARNESS, not part of the restatement: kto_run_soa's loop for the LogCompaction handler alone, over the records whose
+ * key hashes into [slot_lo, slot_hi) — the others are passed by.  A record touches ONE bit, the one at fnv1a(key)
+ * (metric.rs:273-280, 294-303), so K instances over disjoint slot ranges, each fed the whole topic in consumption order,
+ * hold between them exactly what one instance holds: every slot sees its own records in order.  The tests run the instances
+ * on K threads (the 2^30-record oracle of config 3 took 207 s of a 1200 s GPU step on one). */
+void kto_lc_run_soa_slot_range(kto_logcompaction *lc, uint64_t n, const int32_t *key_len, const int32_t *val_len,
+                               const uint32_t *key_off, const uint8_t *key_bytes, const uint32_t *slots,
+                               uint64_t slot_lo, uint64_t slot_hi)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        if (key_len[i] < 0) continue;                    /* key None: ignored by the handler (metric.rs:302) */
+        const uint8_t *k = key_bytes + key_off[i];
+        const uint64_t slot = slots ? slots[i] : kto_fnv1a(k, (size_t)key_len[i]);   /* (slots: kto_fnv1a_soa's column) */
+        if (slot < slot_lo || slot >= slot_hi) continue;
+        kto_lc_handle_message(lc, k, key_len[i], val_len[i]);
+    }
+}
+
+/* TEST HARNESS: fnv1a (metric.rs:256-260) of the records [first, first + n) of a batch's keys into out[first ...] (0 for
+ * key None) — the column the slot-range instances pick their records by, computed once instead of once per instance. */
+void kto_fnv1a_soa(uint64_t first, uint64_t n, const int32_t *key_len, const uint32_t *key_off, const uint8_t *key_bytes,
+                   uint32_t *out)
+{
+    for (uint64_t i = first; i < first + n; i++)
+        out[i] = key_len[i] < 0 ? 0u : (uint32_t)kto_fnv1a(key_bytes + key_off[i], (size_t)key_len[i]);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Additive analytics — NO reference counterpart (see kta_oracle.h).          */
 /* ------------------------------------------------------------------------ */

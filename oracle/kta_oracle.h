@@ -119,6 +119,14 @@ void kto_lc_export_words(const kto_logcompaction *lc, uint32_t *dst, uint64_t n_
 void kto_run_soa(kto_metrics *m, kto_logcompaction *lc, uint64_t n, const int32_t *part,
                  const int32_t *key_len, const int32_t *val_len, const int64_t *ts_ms,
                  const uint32_t *key_off, const uint8_t *key_bytes);
+/* TEST HARNESS (no reference counterpart): the LogCompaction handler over the records whose key hashes into
+ * [slot_lo, slot_hi) — K instances over disjoint slot ranges hold between them what one instance holds (kta_oracle.c). */
+void kto_lc_run_soa_slot_range(kto_logcompaction *lc, uint64_t n, const int32_t *key_len, const int32_t *val_len,
+                               const uint32_t *key_off, const uint8_t *key_bytes, const uint32_t *slots /* or NULL */,
+                               uint64_t slot_lo, uint64_t slot_hi);
+/* TEST HARNESS: fnv1a of the keys of the records [first, first + n) into out[first ...] (0 for key None) */
+void kto_fnv1a_soa(uint64_t first, uint64_t n, const int32_t *key_len, const uint32_t *key_off, const uint8_t *key_bytes,
+                   uint32_t *out);
 
 /* dense export for comparisons: out[p*7 + c], c in reference field order
  * (total, tombstones, alive, key_null, key_non_null, key_size_sum, value_size_sum) */

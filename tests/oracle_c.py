@@ -52,6 +52,8 @@ def lib():
         L.kto_lc_nbits.argtypes = [C.c_void_p]
         L.kto_lc_export_words.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.kto_run_soa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        L.kto_lc_run_soa_slot_range.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint64, C.c_uint64]
+        L.kto_fnv1a_soa.argtypes = [C.c_uint64, C.c_uint64] + [C.c_void_p] * 4
         L.kto_export_counters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -133,6 +135,59 @@ class Oracle:
         out = np.zeros(n_words, dtype=np.uint32)
         self.L.kto_lc_export_words(self.lc, out.ctypes.data, n_words)
         return out
+
+
+class SlotRangeAliveOracle:
+    """The LogCompaction oracle on K threads: K instances over disjoint ranges of the 2^32 slots, each fed the WHOLE topic in
+    consumption order and applying only the records whose key hashes into its range (kto_lc_run_soa_slot_range, a harness
+    function of the oracle: a record touches one bit, so every slot still sees its own records in order).  Between them the
+    instances hold exactly the single instance's BitSet."""
+
+    def __init__(self, k=16):
+        from concurrent.futures import ThreadPoolExecutor
+        assert k & (k - 1) == 0 and k <= 64
+        self.L = lib()
+        self.k = k
+        self.lcs = [self.L.kto_lc_new() for _ in range(k)]
+        self.pool = ThreadPoolExecutor(k)
+
+    def run_soa(self, cols):
+        n = len(cols["key_len"])
+        a = {f: np.ascontiguousarray(cols[f]) for f in ("key_len", "val_len", "key_off", "key_bytes")}
+        step = (1 << 32) // self.k
+        slots = np.empty(n, np.uint32)               # every key hashed ONCE (by the oracle's own fnv1a), a share per thread
+        per = (n + self.k - 1) // self.k
+
+        def hash_share(j):                           # (ctypes calls release the GIL)
+            lo = min(j * per, n)
+            self.L.kto_fnv1a_soa(lo, min(per, n - lo), a["key_len"].ctypes.data, a["key_off"].ctypes.data,
+                                 a["key_bytes"].ctypes.data, slots.ctypes.data)
+        list(self.pool.map(hash_share, range(self.k)))
+
+        def one(j):
+            self.L.kto_lc_run_soa_slot_range(self.lcs[j], n, a["key_len"].ctypes.data, a["val_len"].ctypes.data,
+                                             a["key_off"].ctypes.data, a["key_bytes"].ctypes.data, slots.ctypes.data,
+                                             j * step, (j + 1) * step)
+        list(self.pool.map(one, range(self.k)))
+
+    def alive_keys(self):
+        return sum(int(self.L.kto_lc_sum_all_alive(lc)) for lc in self.lcs)
+
+    def alive_words(self, n_words=1 << 27):
+        out = np.zeros(n_words, dtype=np.uint32)
+        per = n_words // self.k
+        for j, lc in enumerate(self.lcs):
+            tmp = np.zeros((j + 1) * per, dtype=np.uint32)
+            self.L.kto_lc_export_words(lc, tmp.ctypes.data, (j + 1) * per)
+            assert not tmp[:j * per].any()           # nothing outside its range
+            out[j * per:(j + 1) * per] = tmp[j * per:]
+        return out
+
+    def close(self):
+        for lc in self.lcs:
+            self.L.kto_lc_free(lc)
+        self.lcs = []
+        self.pool.shutdown()
 
 
 def analytics(cols, P):

@@ -12,7 +12,10 @@
 The oracle is single-threaded like the reference (src/kafka.rs:92-135).  For the counter configs it runs as
 T independent instances over consecutive chunks of the topic (its state is sums and extrema, so the
 instances merge by + / min / max — done here in numpy, nothing of the product involved); the BitSet of c3 is
-order dependent and runs in one instance, fed chunk by chunk in consumption order.  Records come from the
+order dependent PER SLOT: it runs as K instances over disjoint ranges of the 2^32 slots, every instance fed the whole
+topic chunk by chunk in consumption order and taking the records whose key hashes into its range (oracle_c.
+SlotRangeAliveOracle; tests/test_oracle.py holds it against the single instance) — one instance took 207 s of the GPU
+step for 2^30 records.  Records come from the
 counter-based generator (include/kta_synth.h), which the device and the host evaluate identically
 (test_device_generator_matches_host_generator)."""
 import os
@@ -24,7 +27,7 @@ import pytest
 import kafka_topic_analyzer_amd as kta
 from kafka_topic_analyzer_amd import _native as N
 from helpers import NOW
-from oracle_c import Oracle
+from oracle_c import Oracle, SlotRangeAliveOracle
 
 pytestmark = pytest.mark.gpu
 
@@ -130,36 +133,42 @@ def test_baseline_config_1_one_partition_1m_records_64_byte_keys(state, variant)
     o.close()
 
 
-def test_baseline_config_3_alive_keys_2e30_records():
-    sp, _ = kta.synth_preset("c3")
-    n, P = 1 << 30, 64
-    o = Oracle(NOW, True)
-    # the oracle's BitSet consumes the topic in order; three generator threads run a few chunks ahead of it
+def _alive_oracle_threaded(sp, n):
+    """-> SlotRangeAliveOracle over the records [0, n) of the topic, in consumption order (generator threads a few chunks ahead)."""
     from concurrent.futures import ThreadPoolExecutor
+    o = SlotRangeAliveOracle(16 if (os.cpu_count() or 8) >= 24 else 8)
     chunks = [(lo, min(CHUNK * 4, n - lo)) for lo in range(0, n, CHUNK * 4)]
     pool = ThreadPoolExecutor(6)
     ahead = [pool.submit(kta.synth_fill_host, sp, lo, m, True) for lo, m in chunks[:8]]
+    for k in range(len(chunks)):
+        cols = ahead.pop(0).result()
+        if k + 8 < len(chunks):
+            ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 8][0], chunks[k + 8][1], True))
+        o.run_soa(cols)
+    pool.shutdown()
+    return o
+
+
+def test_baseline_config_3_alive_keys_2e30_records():
+    sp, _ = kta.synth_preset("c3")
+    n, P = 1 << 30, 64
     with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
         slice_n = 1 << 27                      # one device batch at a time: 2^27 records, 2 GiB of keys (key_off is u32)
         b = h.device_batch_alloc(slice_n, slice_n * 16)
         for lo in range(0, n, slice_n):
             assert h.synth_fill_device(sp, lo, slice_n, b) == slice_n * 16
             h.submit_device(b, slice_n, lo)    # both handlers, as the reference runs them
-            h.sync()
-        for k in range(len(chunks)):
-            cols = ahead.pop(0).result()
-            if k + 8 < len(chunks):
-                ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 8][0], chunks[k + 8][1], True))
-            o.run_soa(cols)
-        pool.shutdown()
+        # (the GPU works while the oracles do)
+        want_c, earliest, latest, smallest, largest = _oracle_counters_threaded(sp, n, P)
+        o = _alive_oracle_threaded(sp, n)
         res, c = h.finish()
         assert res.alive_keys == o.alive_keys() and 0 < res.alive_keys <= 10_000_000
-        assert np.array_equal(c, o.counters(P)) and res.overall_count == n
+        assert np.array_equal(c, want_c) and res.overall_count == n
         # (both handlers of a slice ran as ONE pass over it — the fused partition kernel: the extrema come from there too)
         mm = kta.MessageMetrics(res, c, NOW)
-        assert mm.earliest_message() == o.earliest() and mm.latest_message() == o.latest()
-        assert mm.smallest_message() == o.get("smallest_message") and mm.largest_message() == o.get("largest_message")
-        assert mm.overall_size() == o.get("overall_size")
+        assert (mm.earliest_message(), mm.latest_message()) == (earliest, latest)
+        assert (mm.smallest_message(), mm.largest_message()) == (smallest, largest)
+        assert mm.overall_size() == int(want_c[:, N.KTA_C_KEY_SIZE_SUM].sum() + want_c[:, N.KTA_C_VALUE_SIZE_SUM].sum())
         assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
         h.device_batch_free(b)
     o.close()
@@ -170,26 +179,18 @@ _C5_ONE_GPU = {}
 
 
 def _c5_one_gpu_oracle(n):
-    """ONE oracle (both handlers) over the first n records of config 5's topic, in consumption order; kept for the
-    two parametrisations of the test below (the BitSet is order dependent: one instance, chunk after chunk)."""
+    """The oracle (both handlers) over the first n records of config 5's topic, in consumption order; kept for the two
+    parametrisations of the test below.  MessageMetrics as independent instances over chunks (sums and extrema merge),
+    the BitSet as instances over slot ranges (order matters per slot only)."""
     if n in _C5_ONE_GPU:
         return _C5_ONE_GPU[n]
-    from concurrent.futures import ThreadPoolExecutor
     sp, _ = kta.synth_preset("c5")
     P = int(sp.n_partitions)
-    o = Oracle(NOW, True)
-    chunks = [(lo, min(CHUNK * 4, n - lo)) for lo in range(0, n, CHUNK * 4)]
-    pool = ThreadPoolExecutor(6)
-    ahead = [pool.submit(kta.synth_fill_host, sp, lo, m, True) for lo, m in chunks[:8]]
-    for k in range(len(chunks)):
-        cols = ahead.pop(0).result()
-        if k + 8 < len(chunks):
-            ahead.append(pool.submit(kta.synth_fill_host, sp, chunks[k + 8][0], chunks[k + 8][1], True))
-        o.run_soa(cols)
-    pool.shutdown()
-    want = {"alive_keys": o.alive_keys(), "words": o.alive_words().copy(), "counters": o.counters(P).copy(),
-            "earliest": o.earliest(), "latest": o.latest(), "smallest": o.get("smallest_message"),
-            "largest": o.get("largest_message"), "overall_size": o.get("overall_size")}
+    counters, earliest, latest, smallest, largest = _oracle_counters_threaded(sp, n, P)
+    o = _alive_oracle_threaded(sp, n)
+    want = {"alive_keys": o.alive_keys(), "words": o.alive_words(), "counters": counters,
+            "earliest": earliest, "latest": latest, "smallest": smallest, "largest": largest,
+            "overall_size": int(counters[:, N.KTA_C_KEY_SIZE_SUM].sum() + counters[:, N.KTA_C_VALUE_SIZE_SUM].sum())}
     o.close()
     _C5_ONE_GPU[n] = want
     return want
