@@ -232,7 +232,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
 
 // pool control words (device memory, zeroed before every launch pair)
-enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_WORDS = 3 };
+enum : uint32_t { POOL_CURSOR = 0, POOL_FAILED = 1, POOL_DENSE = 2, POOL_RANGES = 3, POOL_WORDS = 4 };
 
 // ------------------------------------------------------------------------------------------------------
 // pass 1, bit set state: the same partition with 4-byte pairs whose order is implicit
@@ -1314,7 +1314,20 @@ struct ApplyShared {
 
 // BITMAP: the persistent state is the reference's bit set (u32 words, bit h & 31 of word h >> 5); else the
 // u64 last-writer table.
-template <int BLOG2, bool BITMAP>
+// RANGES (bit set state only): the instantiation that takes the buckets whose distinct slots did not fit the table in the
+// plain attempt — listed by kta_alive_apply<BLOG2, true, false> behind fail_from's 2 B words, POOL_RANGES of them.  Such a
+// bucket is applied in 2^rho PASSES over ALL its pairs, pass r taking the slots of the r-th 2^rho-th of the bucket's slot
+// range (the top rho bits of the slot in the bucket) and sweeping only that part of the bucket's bit set: every pair of a slot
+// is in one pass, so a pass is a plain attempt — segments in any order, no checkpoints — on a table whose sets are chosen by
+// the next 11 bits down.  rho starts at 1 (or at what an earlier bucket of the batch needed: POOL_DENSE) and doubles the
+// parts when a pass does not fit — what earlier passes applied is the final state of their slots, applying it again changes
+// nothing — up to 16 parts; what defeats that too (a few sets taking everything) goes on in careful mode, rounds 4-5's
+// instalments in segment order, and from there to kta_alive_fallback.  Rounds 4-5 sent every overflowing bucket straight to
+// careful mode: a batch of 20 M distinct keys (19.5 k slots per bucket against the table's 16 k) was applied in 26 instalments
+// per bucket, each a sweep of the bucket's 512 KiB — 7.6 ms instead of 2.6 —, config 5's law on one GPU (97 k slots per
+// bucket) in 32.
+constexpr uint32_t kMaxRho = 4;
+template <int BLOG2, bool BITMAP, bool RANGES>
 __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned long long *__restrict__ pairs,
                                                                  const uint32_t *__restrict__ counts, uint32_t cap,
                                                                  uint32_t W, uint32_t range, uint64_t base_seq,
@@ -1331,6 +1344,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     constexpr uint32_t RBITS = 32 - BLOG2;             // hash bits below the bucket
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
     static_assert(TAGBITS <= 15, "tags are 16 bit");
+    static_assert(BITMAP || !RANGES, "slot-range passes are the bit set state's");
+    constexpr bool kHasCareful = !BITMAP || RANGES;    // (the bit set state's plain instantiation hands what does not fit to the RANGES one)
     constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
     static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
     // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
@@ -1343,9 +1358,13 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ovf + kOvf);            // W segment fills
     uint32_t *s_slice = s_cnt + ((W + 31u) & ~31u);                          // BITMAP: one slice of the region
     __shared__ ApplyShared sh;
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x;
     if (skip_flag && *skip_flag) return;               // the batch was handed to another path (unordered seq column)
-    if (BITMAP) {
+    if (RANGES) {                                      // the b-th bucket of the list
+        if (b >= (uint32_t)pool_ctl[POOL_RANGES]) return;
+        b = fail_from[(2u << BLOG2) + b];
+    }
+    if (BITMAP && !RANGES) {
         // a bucket with pool pairs is not attempted: its pairs are not all in its segments
         if (pool_hist[b] != 0u) {
             if (threadIdx.x == 0) {
@@ -1367,9 +1386,14 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         sh.next_seg = 0;
         // Another bucket's workgroup may set the word at any moment.  Waves that read it for themselves could
         // disagree, and a workgroup whose waves run in different modes does not meet at the same barriers.
-        sh.dense = pool_ctl[POOL_DENSE] != 0ull ? 1u : 0u;
+        // (bit set state: the word is the rho an earlier bucket needed, 0 = none did)
+        sh.dense = BITMAP ? (uint32_t)pool_ctl[POOL_DENSE] : (pool_ctl[POOL_DENSE] != 0ull ? 1u : 0u);
     }
     __syncthreads();
+    if (BITMAP && !RANGES && sh.dense != 0u) {         // an earlier bucket of this batch did not fit: no attempt, straight to the list
+        if (threadIdx.x == 0) fail_from[(2u << BLOG2) + (uint32_t)atomicAdd(&pool_ctl[POOL_RANGES], 1ull)] = b;
+        return;
+    }
     for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
         const uint32_t cw = counts[(uint64_t)b * W + w];
         s_cnt[w] = cw;
@@ -1380,6 +1404,9 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     KTA_PHASE(1, 0);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     long long delta = 0;
+    // RANGES: the bucket's slot range is taken in 2^rho parts, the current pass takes part ridx (wave-uniform; rho = 0 in
+    // careful mode and in the other instantiations, where everything below folds to the constants it was written with)
+    uint32_t rho = 0, ridx = 0;
 
     // global value of a survivor (table state): ((sequence + 1) << 1) | alive
     auto global_val = [&](uint32_t lo) __attribute__((always_inline)) -> unsigned long long {
@@ -1401,19 +1428,29 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             // owns the slots of the sets [128 v, 128 v + 128) and walks them in 16 pieces of 8 sets = 2 KiB of bit
             // set = 32 bytes per lane; the piece's 64 table entries are one per lane.  The next piece is requested
             // while this one is worked on.
-            uint32_t *mine = bitmap + ((size_t)b << (RBITS - 5)) + (size_t)wave * kSliceWords;
+            // (RANGES: a set holds 2^(TAGBITS - rho) slots, so the wave's 128 sets are 1 / 2^rho of its share of the bucket's
+            // region, a piece of 2 KiB of bit set is 8 << rho sets = 64 << rho entries, 2^rho per lane, and the wave has
+            // 16 >> rho pieces)
+            const uint32_t tbits = TAGBITS - rho;
+            const uint32_t psets = 8u << rho, np = (kSliceSets / 8u) >> rho;       // sets of a piece; pieces of this wave
+            uint32_t *mine = bitmap + ((size_t)b << (RBITS - 5)) + (size_t)ridx * ((1u << (RBITS - 5)) >> rho) +
+                             (size_t)wave * (kSliceWords >> rho);
             uint32_t *buf = s_slice + wave * (kSliceWords / kSliceSets * 8u);       // 512 words of this wave
-            constexpr uint32_t kPieces = kSliceSets / 8u;                          // 16
+            constexpr uint32_t kPieces = kSliceSets / 8u;                          // 16: at most; also "no piece"
             constexpr uint32_t kPieceWords = kSliceWords / kPieces;                // 512
             // Which of the wave's pieces hold entries at all (a small batch leaves most of the region alone).  The
             // pieces are walked from a start that differs from wave to wave and bucket to bucket: in step, 4096
             // waves would otherwise ask for addresses that differ by multiples of 32 KiB — a handful of the
             // memory's channels — at every moment.  Bit i of `occupied` = piece (i + start) % 16.
-            const uint32_t start = (wave + b * 5u) & (kPieces - 1u);
+            const uint32_t start = (wave + b * 5u) & (np - 1u);
             uint32_t occupied = 0;
 #pragma unroll 4
-            for (uint32_t i = 0; i < kPieces; i++)
-                occupied |= (__any(s_tag[(wave * kSliceSets + ((i + start) & (kPieces - 1u)) * 8u) * 8u + lane] != 0) ? 1u : 0u) << i;
+            for (uint32_t i = 0; i < np; i++) {
+                bool any_tag = false;
+                for (uint32_t k = 0; k < (1u << rho); k++)
+                    any_tag |= s_tag[(wave * kSliceSets + ((i + start) & (np - 1u)) * psets) * 8u + k * 64u + lane] != 0;
+                occupied |= (__any(any_tag) ? 1u : 0u) << i;
+            }
             const uint4 *src = reinterpret_cast<const uint4 *>(mine);
             // The occupied pieces, one request ahead.  Loads and stores share one in-order counter (vmcnt): the next
             // piece is requested BEFORE this piece's stores, so the wait for it lets exactly those stores pend.
@@ -1422,7 +1459,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 return rest ? (uint32_t)__builtin_ctz(rest) : kPieces;
             };
             auto request = [&](uint32_t i, uint4 &q0, uint4 &q1) __attribute__((always_inline)) {   // unconditional: countable
-                const uint32_t mc = ((i < kPieces ? i : 0u) + start) & (kPieces - 1u);
+                const uint32_t mc = ((i < kPieces ? i : 0u) + start) & (np - 1u);
                 q0 = src[(size_t)mc * (kPieceWords / 4u) + lane];
                 q1 = src[(size_t)mc * (kPieceWords / 4u) + lane + 64u];
             };
@@ -1434,29 +1471,31 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             auto apply_side = [&](unsigned long long pr, uint32_t m) __attribute__((always_inline)) {
                 if (pr == 0ull) return;
                 const uint32_t h = (uint32_t)(pr >> 32) - 1u, lo = (uint32_t)pr;
-                const uint32_t set_local = (h >> TAGBITS) & (kSliceSets - 1u);
-                if ((set_local >> 3) != m) return;
-                const uint32_t bit = ((set_local & 7u) << TAGBITS) | (h & ((1u << TAGBITS) - 1u));
+                const uint32_t set_local = (h >> tbits) & (kSliceSets - 1u);
+                if ((set_local >> (3u + rho)) != m) return;
+                const uint32_t bit = ((set_local & (psets - 1u)) << tbits) | (h & ((1u << tbits) - 1u));
                 const uint32_t mk = 1u << (bit & 31u);
                 const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
                 delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
             };
             auto piece = [&](uint32_t i, const uint4 &q0, const uint4 &q1) __attribute__((always_inline)) {
-                const uint32_t m = (i + start) & (kPieces - 1u);
+                const uint32_t m = (i + start) & (np - 1u);
                 uint4 *sl = reinterpret_cast<uint4 *>(buf);
                 sl[lane] = q0;
                 sl[lane + 64u] = q1;
                 KTA_LDS_ORDER();
-                const uint32_t e = (wave * kSliceSets + m * 8u) * 8u + lane;            // the lane's tag: half-word lane & 7 of set lane >> 3
-                const uint32_t ev = (e & ~7u) | entry_of_half(lane & 7u);                 // ... and its value
-                const uint32_t tag = s_tag[e], lo = s_val[ev];
-                if (tag) {
-                    const uint32_t bit = ((lane >> 3) << TAGBITS) | (tag - 1u);
-                    const uint32_t mk = 1u << (bit & 31u);
-                    const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
-                    delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
-                    s_tag[e] = 0;
-                    s_val[ev] = 0u;
+                for (uint32_t k = 0; k < (1u << rho); k++) {
+                    const uint32_t e = (wave * kSliceSets + m * psets) * 8u + k * 64u + lane;   // the lane's tag: half-word lane & 7 of the piece's set 8 k + (lane >> 3)
+                    const uint32_t ev = (e & ~7u) | entry_of_half(lane & 7u);             // ... and its value
+                    const uint32_t tag = s_tag[e], lo = s_val[ev];
+                    if (tag) {
+                        const uint32_t bit = ((8u * k + (lane >> 3)) << tbits) | (tag - 1u);
+                        const uint32_t mk = 1u << (bit & 31u);
+                        const uint32_t old = lo & 1u ? atomicOr(&buf[bit >> 5], mk) : atomicAnd(&buf[bit >> 5], ~mk);
+                        delta += (long long)(lo & 1u) - (long long)((old & mk) != 0u);
+                        s_tag[e] = 0;
+                        s_val[ev] = 0u;
+                    }
                 }
                 apply_side(side0, m);
                 apply_side(side1, m);
@@ -1698,11 +1737,17 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
     };
     uint32_t claimed = 0;
-    bool careful = __builtin_amdgcn_readfirstlane(sh.dense) != 0u;   // an earlier bucket of this batch overflowed its table: check as we go
+    // table state: an earlier bucket of this batch overflowed its table: check as we go.  Bit set state: the plain
+    // instantiation never is careful (what does not fit goes to the RANGES one, which starts with slot-range passes)
+    bool careful = !BITMAP && __builtin_amdgcn_readfirstlane(sh.dense) != 0u;
+    if (RANGES) {
+        rho = (uint32_t)__builtin_amdgcn_readfirstlane(sh.dense);
+        rho = rho < 1u ? 1u : (rho > kMaxRho ? kMaxRho : rho);
+    }
     // The merge of one pair that found no entry for its slot: merge_new_slot, out of line.
     const uint32_t o_tag = lds_offset(s_tag), o_val = lds_offset(s_val), o_ovf = lds_offset(s_ovf), o_any = lds_offset(&sh.any_ovf);
     auto merge_new = [&](uint32_t h, uint32_t lo, uint32_t par) __attribute__((always_inline)) {
-        const uint32_t how = merge_new_slot(o_tag, o_val, o_ovf, lds_offset(&sh.ovf_n[par]), o_any, TAGBITS, h, lo);
+        const uint32_t how = merge_new_slot(o_tag, o_val, o_ovf, lds_offset(&sh.ovf_n[par]), o_any, TAGBITS - rho, h, lo);
         claimed += how == 1u ? 1u : 0u;
         if (how == 3u) {
             // Full as well: the attempt is given up (fast attempt; bit set state) or the record takes the direct path
@@ -1770,15 +1815,23 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         // A lookup is the set's 16 tag bytes — read unconditionally, any pair addresses a set —, a hit one LDS max; the misses of
         // the unit go to the wave's queue, which always has room for a unit's 256 (it is emptied down to less than 64 after
         // every unit: whole waves of 64 lanes walk the long way, never the few of one unit).
-        uint4 t[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = *reinterpret_cast<const uint4 *>(s_tag + (hr[i] >> TAGBITS) * 8u);
+        // RANGES: this pass takes the slots whose top rho bits are ridx; of those, the next 11 bits choose the set.
+        const uint32_t tbits = TAGBITS - rho;
+        bool mine[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t tag = (hr[i] & ((1u << TAGBITS) - 1u)) + 1u;
+            mine[i] = !RANGES || (hr[i] >> (RBITS - rho)) == ridx;
+            if (RANGES) hr[i] &= (1u << (RBITS - rho)) - 1u;
+        }
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = *reinterpret_cast<const uint4 *>(s_tag + (hr[i] >> tbits) * 8u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t tag = (hr[i] & ((1u << tbits) - 1u)) + 1u;
             const uint32_t e = find_tag(t[i], tag);
-            const bool valid = (uint32_t)i < un.nv[0];
-            if (valid && e < 8u) atomicMax(&s_val[(hr[i] >> TAGBITS) * 8u + e], val[i]);
+            const bool valid = (uint32_t)i < un.nv[0] && mine[i];
+            if (valid && e < 8u) atomicMax(&s_val[(hr[i] >> tbits) * 8u + e], val[i]);
             const bool miss = valid && e >= 8u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);   // (__ballot goes through an int: a select and a compare)
             if (miss)
@@ -1796,7 +1849,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // instalment's totals in registers, fed from the counter slot of the interval just ended (ApplyShared).
     // (Whatever the workgroup decides on comes out of LDS through readfirstlane: a value loaded per lane is divergent
     // to the compiler, and so is every loop counter of a loop that such a value leaves.)
-    if (careful) pick_group_size();
+    if (kHasCareful && careful) pick_group_size();
     uint32_t inst_start = 0;                            // first segment of the current instalment
     uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
     uint32_t u = 0;                                     // the unit that is merged next
@@ -1808,6 +1861,12 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         // unconditionally (a unit past the end loads a clamped address and merges nothing): under a branch the
         // compiler could not count it and would wait with vmcnt(0).
         dynamic = !careful;
+        if (RANGES && dynamic) {                         // a new pass over all the bucket's segments: hand them out again
+            lds_barrier();
+            if (threadIdx.x == 0) sh.next_seg = 0;
+            lds_barrier();
+            seg = 0, seg_unit = 0, seg_units = 0, u = 0;
+        }
 #pragma unroll
         for (int s = 0; s + 1 < D; s++) issue(u + (uint32_t)s, ring[s]);
         bool flush = false, failed = false, stop = false;
@@ -1822,7 +1881,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 merge(ring[s], par);
                 u++;
                 KTA_PHASE(1, 3);
-                if (careful && u % chunks == 0u) {
+                if (kHasCareful && careful && u % chunks == 0u) {
                     drain(par);                           // the queued misses are in before anybody looks at the table as a whole
                     if (u < KTA_UNITS) {
 #pragma unroll
@@ -1864,7 +1923,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             failed = __builtin_amdgcn_readfirstlane(sh.fail[0] | sh.fail[1] | sh.fail[2]) != 0u;
         }
         if (failed) {
-            if (careful) {
+            if (kHasCareful && careful) {
                 if (BITMAP) {                            // handed to kta_alive_fallback from this instalment on
                     if (threadIdx.x == 0) {
                         fail_from[b] = inst_start;
@@ -1877,18 +1936,38 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                     return;
                 }
                 // (table state never fails in careful mode: its last resort is the direct path)
-            } else {                                     // the fast attempt did not fit: start over, carefully
+            } else if (BITMAP && !RANGES) {
+                // The plain attempt did not fit — nothing has been applied, nothing counted: the bucket goes on the list of
+                // the RANGES instantiation, which runs next, and the buckets of this batch still to come skip their attempt.
+                if (threadIdx.x == 0) {
+                    fail_from[(2u << BLOG2) + (uint32_t)atomicAdd(&pool_ctl[POOL_RANGES], 1ull)] = b;
+                    atomicMax(&pool_ctl[POOL_DENSE], 1ull);
+                }
+                return;
+            } else {                                     // the pass did not fit: start over — in more parts, or carefully
                 lds_barrier();                           // everybody has seen the verdict
                 for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + 2 * kOvf; e += kApplyThreads) s_val[e] = 0u;
+                const bool more_parts = RANGES && rho < kMaxRho;
                 if (threadIdx.x == 0) {
                     sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = sh.fail[0] = sh.fail[1] = sh.fail[2] = 0;
                     sh.any_ovf = 0;
-                    pool_ctl[POOL_DENSE] = 1ull;
+                    if (RANGES) atomicMax(&pool_ctl[POOL_DENSE], (unsigned long long)(more_parts ? rho + 1u : kMaxRho));
+                    else pool_ctl[POOL_DENSE] = 1ull;
                 }
                 mq = 0;
                 claimed = 0;
-                careful = true;
                 u = 0;
+                if (more_parts) {
+                    // (the parts applied so far hold the FINAL state of their slots: their slots' pairs were all in their
+                    // passes.  Taking them again in smaller parts finds every bit as it should be and counts nothing.)
+                    rho++;
+                    ridx = 0;
+                    lds_barrier();
+                    continue;
+                }
+                rho = 0;                                 // careful mode works on the whole bucket, in segment order
+                ridx = 0;
+                careful = true;
                 lds_barrier();
                 pick_group_size();
                 continue;
@@ -1896,6 +1975,10 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         }
         KTA_PHASE(1, 1);
         end_instalment();                                // (the one call site: the sweep is long)
+        if (RANGES && !careful) {                        // the next part of the slot range, or done
+            if (++ridx < (1u << rho)) continue;
+            break;
+        }
         if (u >= KTA_UNITS) break;
         inst_start = (u / chunks) * KTA_GS;
         tot_occ = tot_ovf = last_occ = 0;
@@ -2166,10 +2249,20 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         KTA_UB_MARK(1);
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+                           pl.segment_wgs, 0u, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
+                           reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, (const uint32_t *)nullptr,
+                           WrittenList{nullptr, nullptr, 0});
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // the buckets that did not fit the table in one piece, in slot-range passes (returns at once when there are none)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((kta_alive_apply<BLOG2, true, true>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
                            pl.segment_wgs, 0u, base_seq, (const uint64_t *)nullptr, (unsigned long long *)nullptr, st.bitmap, run,
                            reinterpret_cast<unsigned long long *>(stats), hist, ws.fail_from, ctl, (const uint32_t *)nullptr,
                            WrittenList{nullptr, nullptr, 0});
@@ -2217,11 +2310,11 @@ hipError_t launch_pair(const AliveColumns &c, uint64_t n, uint64_t base_seq, con
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     KTA_UB_MARK(1);
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kta_alive_apply<BLOG2, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
     unsigned long long *t = reinterpret_cast<unsigned long long *>(st.table);
-    hipLaunchKernelGGL((kta_alive_apply<BLOG2, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
+    hipLaunchKernelGGL((kta_alive_apply<BLOG2, false, false>), dim3(B), dim3(kApplyThreads), lds2, s, pp, ws.counts, pl.cap,
                        pl.segment_wgs, pl.tiles_per_wg * kTile, base_seq, c.seq, t, (uint32_t *)nullptr, run,
                        reinterpret_cast<unsigned long long *>(stats), hist, (uint32_t *)nullptr, ctl, skip, st.written);
     e = hipGetLastError();

@@ -342,7 +342,7 @@ int run_device_batch(kta_ctx *ctx, const kta_batch *c, uint64_t n, uint64_t base
                     ctx->pool_cap = pl.pool_words;
                 }
                 if (!ctx->d_pool_ctl) KTA_HIP(ctx, hipMalloc(&ctx->d_pool_ctl, pl.ctl_bytes));
-                if (!ctx->d_fail_from) KTA_HIP(ctx, hipMalloc((void **)&ctx->d_fail_from, 2 * sizeof(uint32_t) << pl.bucket_log2));   // (per bucket + the list of given-up buckets)
+                if (!ctx->d_fail_from) KTA_HIP(ctx, hipMalloc((void **)&ctx->d_fail_from, 3 * sizeof(uint32_t) << pl.bucket_log2));   // (per bucket + the list of given-up buckets + the list for the slot-range passes)
                 kta::AliveColumns sl{c->key_len + at, c->val_len + at, c->key_off + at, c->key_bytes,
                                      ctx->alive_table && c->seq ? c->seq + at : nullptr};
                 kta::AliveState st{ctx->alive_table ? ctx->d_table : nullptr, ctx->alive_table ? nullptr : ctx->d_bitmap,

@@ -1505,6 +1505,26 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
     return KTA_OK;
 }
 
+int kta_kafka_descs_alloc(kta_ctx *ctx, uint64_t n, kta_kafka_batch_desc **out)
+{
+    if (!ctx || !out) return KTA_ERR_INVALID;
+    *out = nullptr;
+    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
+    KK(ctx, hipHostMalloc((void **)out, (n ? n : 1) * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
+    return KTA_OK;
+}
+
+int kta_kafka_descs_free(kta_ctx *ctx, kta_kafka_batch_desc *descs)
+{
+    if (!ctx) return KTA_ERR_INVALID;
+    if (descs) {
+        // (a copy out of the array may still be on its way)
+        KK(ctx, hipStreamSynchronize(kta_internal_copy_stream(ctx)));
+        KK(ctx, hipHostFree(descs));
+    }
+    return KTA_OK;
+}
+
 int kta_kafka_configure(kta_ctx *ctx, uint64_t blob_capacity, int n_stages)
 {
     if (!ctx || n_stages < 0 || n_stages > 16) return KTA_ERR_INVALID;

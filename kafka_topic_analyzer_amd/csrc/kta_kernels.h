@@ -125,8 +125,9 @@ struct AliveWorkspace {
     uint32_t *counts;
     uint64_t *pool;
     void *pool_ctl;         // ctl_bytes
-    uint32_t *fail_from;    // u32[2 x buckets] (bit set state): per bucket the first segment pass 2 left to kta_alive_fallback
-                            // (or none), then the list of the buckets it gave up
+    uint32_t *fail_from;    // u32[3 x buckets] (bit set state): per bucket the first segment pass 2 left to kta_alive_fallback
+                            // (or none), then the list of the buckets it gave up, then the list of the buckets whose slots
+                            // did not fit pass 2's table in one piece (applied in slot-range passes)
     uint64_t *failed_total; // bit set state: += the buckets a launch pair handed to kta_alive_fallback (device word; may be null)
 };
 AlivePartitionPlan plan_alive_partition(uint64_t n, int req_wgs, int cu_count, bool pair32);

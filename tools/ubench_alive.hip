@@ -78,7 +78,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(k_fill2, dim3(2048), dim3(256), 0, 0, pt, ts, sq, n);
     kta::AlivePartitionPlan pl = kta::plan_alive_partition(n, wgs, 256, !table_state);
     CK(hipMalloc(&pairs, pl.pair_words * 8)); CK(hipMalloc(&counts, pl.count_words * 4)); CK(hipMalloc(&pool, (pl.pool_words + 8) * 8));
-    CK(hipMalloc(&ctl, pl.ctl_bytes)); CK(hipMalloc(&fail_from, 8u << pl.bucket_log2));
+    CK(hipMalloc(&ctl, pl.ctl_bytes)); CK(hipMalloc(&fail_from, 12u << pl.bucket_log2));
     printf("n=2^%d distinct=%llu %s state buckets=2^%u segment_wgs=%u tiles/wg=%u cap=%u workspace=%.0f MB\n", log2n,
            (unsigned long long)distinct, table_state ? "table" : "bit set", pl.bucket_log2, pl.segment_wgs, pl.tiles_per_wg, pl.cap,
            pl.pair_words * 8 / 1e6);
