@@ -460,16 +460,13 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
     buf = np.zeros(ln.value + 64, np.uint8)
     lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n_records, rpb, buf.ctypes.data, ln.value, C.byref(ln))
     nb_cap = n_records // rpb + 2
-    h = kta.HipMetricHandler(256, device=device)
-    # (the descriptors in pinned memory: their upload, on the copy stream beside the kernels of the step before, is then a DMA
-    # the host does not wait for — kta_kafka_descs_alloc)
-    descs = C.POINTER(N.KtaKafkaBatchDesc)()
-    h._check(lib.kta_kafka_descs_alloc(h._ctx, nb_cap, C.byref(descs)))
+    descs = (N.KtaKafkaBatchDesc * nb_cap)()
     st = N.KtaKafkaIndexStats()
     t0 = time.perf_counter()
     rc = lib.kta_kafka_index_host(buf.ctypes.data_as(C.c_char_p), ln.value, 0, 0, 0, 0, descs, nb_cap, C.byref(st))
     t_index = time.perf_counter() - t0
     assert rc == 0 and st.n_records == n_records
+    h = kta.HipMetricHandler(256, device=device)
     d_blob = h.device_batch_alloc((ln.value + 3) // 4 + 32)
     h._check(lib.kta_copy_to_device(h._ctx, d_blob.partition, buf.ctypes.data, (ln.value + 63) // 64 * 64))
     out = h.device_batch_alloc(n_records, 16)  # key_off wanted: keys stay in the blob (zero-copy)
@@ -520,7 +517,6 @@ def kafka_decode_report(kta, device, steps, warmup, n_records, cpu_seconds):
                                       f"({t_total:.1f} s), oracle/kta_kafka_oracle.c sequential decoder"}}
     h.device_batch_free(out)
     h.device_batch_free(d_blob)
-    h._check(lib.kta_kafka_descs_free(h._ctx, descs))
     # the same kernel family at other batch sizes (the geometry is chosen per call from the mean batch size):
     # one row per size, each with its own launch time — a profile's per-kernel average mixes them
     rep["by_batch_size"] = []

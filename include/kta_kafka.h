@@ -137,12 +137,6 @@ int kta_kafka_decode_rounds_host(const uint8_t *blob, uint64_t blob_len, const k
 int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t blob_len,
                             const kta_kafka_batch_desc *descs_host, uint64_t n_batches, uint64_t n_records,
                             const kta_batch *out, uint64_t *n_key_bytes, uint64_t *n_bad_batches);
-/* Descriptor arrays in PINNED host memory: kta_kafka_decode_device uploads `descs_host` on the context's copy stream, beside
- * the kernels of the call before; from pinned memory that upload is a DMA the host does not wait for (from pageable memory
- * it is staged, and blocks the caller for its duration: 0.19 ms for the 66 667 descriptors of a 1 GB log).  Optional: any
- * host array will do. */
-int kta_kafka_descs_alloc(kta_ctx *ctx, uint64_t n, kta_kafka_batch_desc **out);
-int kta_kafka_descs_free(kta_ctx *ctx, kta_kafka_batch_desc *descs);
 
 /* ---- the raw-log pipeline -----------------------------------------------------------------
  * The fetcher writes each Fetch response's record set (or a chunk of a `*.log` segment, cut anywhere)

@@ -176,8 +176,6 @@ SIGNATURES = {
     "kta_kafka_encode_synth_host_ex": (C.c_int, [C.POINTER(KtaSynthSpec), C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "kta_kafka_set_variant": (C.c_int, [_P, C.c_int]),
-    "kta_kafka_descs_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(C.POINTER(KtaKafkaBatchDesc))]),
-    "kta_kafka_descs_free": (C.c_int, [_P, C.POINTER(KtaKafkaBatchDesc)]),
     "kta_kafka_set_inflate_limit": (C.c_int, [_P, C.c_uint64]),
     "kta_kafka_set_check_crcs": (C.c_int, [_P, C.c_int]),
     "kta_kafka_crc_errors": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -1308,7 +1308,6 @@ struct ApplyShared {
     uint32_t any_ovf;        // the side table holds something (this instalment)
     uint32_t next_seg;       // fast attempt: the next segment to hand out
     uint32_t dense;          // POOL_DENSE as thread 0 found it: ONE reading for the whole workgroup
-    uint32_t gmax[5];        // careful mode: the fullest aligned group of 1, 2, 4, 8, 16 segments (pick_group_size)
     long long w[kApplyWaves];
 };
 
@@ -1321,9 +1320,9 @@ struct ApplyShared {
 // is in one pass, so a pass is a plain attempt — segments in any order, no checkpoints — on a table whose sets are chosen by
 // the next 11 bits down.  rho starts at 1 (or at what an earlier bucket of the batch needed: POOL_DENSE) and doubles the
 // parts when a pass does not fit — what earlier passes applied is the final state of their slots, applying it again changes
-// nothing — up to 16 parts; what defeats that too (a few sets taking everything) goes on in careful mode, rounds 4-5's
-// instalments in segment order, and from there to kta_alive_fallback.  Rounds 4-5 sent every overflowing bucket straight to
-// careful mode: a batch of 20 M distinct keys (19.5 k slots per bucket against the table's 16 k) was applied in 26 instalments
+// nothing — up to 16 parts; what defeats that too (a few sets taking everything) goes to kta_alive_fallback.  Rounds 4-5 sent every
+// overflowing bucket into careful mode (instalments in segment order — still the table state's way, which has the direct
+// path as its last resort): a batch of 20 M distinct keys (19.5 k slots per bucket against the table's 16 k) was applied in 26 instalments
 // per bucket, each a sweep of the bucket's 512 KiB — 7.6 ms instead of 2.6 —, config 5's law on one GPU (97 k slots per
 // bucket) in 32.
 constexpr uint32_t kMaxRho = 4;
@@ -1345,7 +1344,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     constexpr uint32_t TAGBITS = RBITS - kSetLog2;     // slots of one set = 2^TAGBITS, a tag = slot in set + 1
     static_assert(TAGBITS <= 15, "tags are 16 bit");
     static_assert(BITMAP || !RANGES, "slot-range passes are the bit set state's");
-    constexpr bool kHasCareful = !BITMAP || RANGES;    // (the bit set state's plain instantiation hands what does not fit to the RANGES one)
+    constexpr bool kHasCareful = !BITMAP;              // (bit set state: what does not fit goes to the RANGES instantiation, and from there to kta_alive_fallback)
     constexpr uint32_t kSliceWords = (kSliceSets << TAGBITS) / 32;   // u32 words of one bitmap slice
     static_assert(!BITMAP || kSliceWords == 2 * 4 * kApplyThreads, "a thread moves two 16-byte pieces of a slice");
     // a new instalment once this many entries are claimed (see checkpoint): with 8-way sets the lists of
@@ -1444,7 +1443,6 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             // memory's channels — at every moment.  Bit i of `occupied` = piece (i + start) % 16.
             const uint32_t start = (wave + b * 5u) & (np - 1u);
             uint32_t occupied = 0;
-#pragma unroll 4
             for (uint32_t i = 0; i < np; i++) {
                 bool any_tag = false;
                 for (uint32_t k = 0; k < (1u << rho); k++)
@@ -1623,53 +1621,13 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     const uint32_t *region_pairs32 = reinterpret_cast<const uint32_t *>(pairs) + (uint64_t)b * W * cap;
     const uint32_t loads = cap >> 8;
     const uint32_t chunks = loads;
-    // Careful mode merges one GROUP of segments — one per wave, each older than the next group's — between two
-    // checkpoints, so a group has to fit the table whatever its keys are: sixteen segments of a 2^28-record batch hold 15 k
-    // pairs, and with mostly unique keys (config 5's law on one GPU) that is more than the table and its side table
-    // take — every bucket went to kta_alive_fallback, 137 ms for the batch (round 4).  Bit set state: gs segments per
-    // group, the largest power of two whose fullest group holds at most 10 k pairs (at most 5 per set on average: the
-    // 8-way sets and the side table hold that with room to spare), found from the segment fills when the workgroup
-    // enters careful mode (pick_group_size); the waves gs ... 15 then only keep the barriers company.  (Measured and dropped in
-    // round 5: groups of at most 4 k pairs shared by all sixteen waves, so that the table fills to its three quarters before
-    // it is emptied — 22 instead of 32 instalments on config 5's law, 7.8 instead of 8.1 ms; but with the table that full a
-    // compacted topic of 20 M keys sent 12 of its 1024 buckets to the fallback kernel, 26 instead of 7.6 ms: the forecast is
-    // only safe with room to spare.)
+    // Careful mode (table state only since round 6: the bit set state's overflowing buckets are applied in slot-range
+    // passes, see RANGES) merges one GROUP of sixteen segments — one per wave, each older than the next group's — between
+    // two checkpoints; what a group's slots overflow of table and side table takes the direct path.  (Rounds 4-5 sized the
+    // bit set state's groups from the segment fills, pick_group_size: a group had to fit whatever its keys were.)
     const uint32_t groups16 = (W + kApplyWaves - 1) / kApplyWaves, units16 = groups16 * chunks;
-    uint32_t gs_c = kApplyWaves, units_c = units16;      // bit set state, careful mode: set by pick_group_size
-#define KTA_GS (BITMAP ? gs_c : (uint32_t)kApplyWaves)      /* segments of a group; units of a wave's walk (the same for every wave) */
-#define KTA_UNITS (BITMAP ? units_c : units16)
-    auto pick_group_size = [&]() __attribute__((always_inline)) {
-        if (!BITMAP) return;                             // (table state: what does not fit takes the direct path)
-        constexpr uint32_t kGroupPairs = 10240;
-        uint32_t *lvl = s_slice;                         // W words of scratch: the miss queues are empty here
-        if (threadIdx.x < 5) sh.gmax[threadIdx.x] = 0u;
-        lds_barrier();
-        for (uint32_t w = threadIdx.x; w < W; w += kApplyThreads) {
-            lvl[w] = s_cnt[w];
-            atomicMax(&sh.gmax[0], s_cnt[w]);
-        }
-        lds_barrier();
-        uint32_t have = W;                               // entries of the level below
-        for (uint32_t l = 1; l <= 4u; l++) {             // level l: the pairs of every aligned group of 2^l segments (W <= 1024: one per thread)
-            const uint32_t ng = (have + 1u) >> 1, g = threadIdx.x;
-            const uint32_t v = g < ng ? lvl[2u * g] + (2u * g + 1u < have ? lvl[2u * g + 1u] : 0u) : 0u;
-            lds_barrier();                               // (everybody has read the level below)
-            if (g < ng) {
-                lvl[g] = v;
-                atomicMax(&sh.gmax[l], v);
-            }
-            lds_barrier();
-            have = ng;
-        }
-        uint32_t l = 4;
-        gs_c = kApplyWaves;
-        while (gs_c > 1u && (uint32_t)__builtin_amdgcn_readfirstlane(sh.gmax[l]) > kGroupPairs) {
-            gs_c >>= 1;
-            l--;
-        }
-        units_c = ((W + gs_c - 1) / gs_c) * chunks;
-        lds_barrier();                                   // (the scratch is the miss queues' again)
-    };
+#define KTA_GS ((uint32_t)kApplyWaves)                      /* segments of a group */
+#define KTA_UNITS units16                                   /* units of a wave's walk in careful mode (the same for every wave) */
     // bit set state: what pass 2 maximises per slot is (segment w, window, position in the segment) << 1 | alive; the
     // position takes ksh = ceil(log2(cap)) bits (cap >= 256, so the window's field starts above bit 8)
     const uint32_t ksh = 32u - (uint32_t)__builtin_clz(cap - 1u);
@@ -1707,7 +1665,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
             seg = (u / chunks) * KTA_GS + __builtin_amdgcn_readfirstlane(wave);
         }
         seg = __builtin_amdgcn_readfirstlane(seg);
-        const bool on = seg < W && (dynamic || (u < KTA_UNITS && (!BITMAP || (uint32_t)__builtin_amdgcn_readfirstlane(wave) < gs_c)));
+        const bool on = seg < W && (dynamic || u < KTA_UNITS);
         const uint32_t cnt = on ? (uint32_t)__builtin_amdgcn_readfirstlane(s_cnt[on ? seg : 0u]) : 0u;
         if (BITMAP) {
             const uint32_t *sp = region_pairs32 + (uint64_t)(on ? seg : 0u) * cap;
@@ -1783,6 +1741,22 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     };
     // Merge the unit `un`: four pairs per lane, their four lookups in flight together (one form for both states since round 6:
     // the table state's used to collect misses over several units and make a miss that found the queue full wait).
+    // RANGES: one pair per lane — (slot inside this pass's part) << 32 | value —, what merge does with four
+    unsigned long long *todoq = missq + 192;             // (the wave's own pairs waiting for a full wave of them: < 128; its misses: < 128)
+    uint32_t tq = 0;                                     // wave-uniform
+    auto merge_one = [&](unsigned long long pr, bool on, uint32_t par) __attribute__((always_inline)) {
+        const uint32_t tb = TAGBITS - rho;
+        const uint32_t x = on ? (uint32_t)(pr >> 32) : 0u, v = (uint32_t)pr;
+        const uint4 t = *reinterpret_cast<const uint4 *>(s_tag + (x >> tb) * 8u);
+        const uint32_t e = find_tag(t, (x & ((1u << tb) - 1u)) + 1u);
+        if (on && e < 8u) atomicMax(&s_val[(x >> tb) * 8u + e], v);
+        const bool miss = on && e >= 8u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);
+        mq = __builtin_amdgcn_readfirstlane(mq);
+        if (miss) missq[mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ((unsigned long long)x << 32) | v;
+        mq += (uint32_t)__popcll(m);
+        drain_full(par);
+    };
     auto merge = [&](const Unit &un, uint32_t par) __attribute__((always_inline)) {
         static_assert(kApplyUnroll == 2 && kMissQueue >= 5 * 64, "a unit's misses fit the queue behind what drain_full leaves");
         mq = __builtin_amdgcn_readfirstlane(mq);         // (wave-uniform by construction: see issue)
@@ -1812,16 +1786,28 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                 val[i] = (un.nv[1] + idx + 1u) << 1 | ((wc[i] >> 7) & 1u);
             }
         }
-        // A lookup is the set's 16 tag bytes — read unconditionally, any pair addresses a set —, a hit one LDS max; the misses of
-        // the unit go to the wave's queue, which always has room for a unit's 256 (it is emptied down to less than 64 after
-        // every unit: whole waves of 64 lanes walk the long way, never the few of one unit).
-        // RANGES: this pass takes the slots whose top rho bits are ridx; of those, the next 11 bits choose the set.
+        // RANGES: this pass takes the slots whose top rho bits are ridx — one pair in 2^rho; of those, the next 11 bits choose
+        // the set.  A unit's own pairs are compacted into a second queue of the wave first and merged 64 at a time, a pair per
+        // lane (merge_one): the foreign pairs cost the unpacking and a ballot, not the lookup (with eight parts a pass paid
+        // the whole merge for seven eighths of its pairs: 5.3 ms of pass 2 on config 5's law).
         const uint32_t tbits = TAGBITS - rho;
-        bool mine[4];
+        if (RANGES) {
+            tq = __builtin_amdgcn_readfirstlane(tq);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            mine[i] = !RANGES || (hr[i] >> (RBITS - rho)) == ridx;
-            if (RANGES) hr[i] &= (1u << (RBITS - rho)) - 1u;
+            for (int i = 0; i < 4; i++) {
+                const bool own = (uint32_t)i < un.nv[0] && (hr[i] >> (RBITS - rho)) == ridx;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(own);
+                if (own)
+                    todoq[tq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        ((unsigned long long)(hr[i] & ((1u << (RBITS - rho)) - 1u)) << 32) | val[i];
+                tq += (uint32_t)__popcll(m);
+                if (tq >= 64u) {                           // (wave-uniform)
+                    tq -= 64u;
+                    KTA_LDS_ORDER();
+                    merge_one(todoq[tq + lane], true, par);
+                }
+            }
+            return;
         }
         uint4 t[4];
 #pragma unroll
@@ -1830,7 +1816,7 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
         for (int i = 0; i < 4; i++) {
             const uint32_t tag = (hr[i] & ((1u << tbits) - 1u)) + 1u;
             const uint32_t e = find_tag(t[i], tag);
-            const bool valid = (uint32_t)i < un.nv[0] && mine[i];
+            const bool valid = (uint32_t)i < un.nv[0];
             if (valid && e < 8u) atomicMax(&s_val[(hr[i] >> tbits) * 8u + e], val[i]);
             const bool miss = valid && e >= 8u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(miss);   // (__ballot goes through an int: a select and a compare)
@@ -1849,7 +1835,6 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
     // instalment's totals in registers, fed from the counter slot of the interval just ended (ApplyShared).
     // (Whatever the workgroup decides on comes out of LDS through readfirstlane: a value loaded per lane is divergent
     // to the compiler, and so is every loop counter of a loop that such a value leaves.)
-    if (kHasCareful && careful) pick_group_size();
     uint32_t inst_start = 0;                            // first segment of the current instalment
     uint32_t tot_occ = 0, tot_ovf = 0, last_occ = 0, par = 0;
     uint32_t u = 0;                                     // the unit that is merged next
@@ -1912,6 +1897,12 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
 #pragma unroll
             for (int s = 0; s + 1 < D; s++) merge(ring[s], par);
         }
+        if (RANGES) {                                    // what is left of the wave's own pairs (less than a wave of them)
+            tq = __builtin_amdgcn_readfirstlane(tq);
+            KTA_LDS_ORDER();
+            merge_one(todoq[lane < tq ? lane : 0u], lane < tq, par);
+            tq = 0;
+        }
         drain(par);
         if (dynamic && !flush) u = KTA_UNITS;              // (segments were handed out: every wave counted its own units)
         if (!failed && !flush) {                         // the last units are in: did everything fit?
@@ -1944,20 +1935,30 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                     atomicMax(&pool_ctl[POOL_DENSE], 1ull);
                 }
                 return;
-            } else {                                     // the pass did not fit: start over — in more parts, or carefully
+            } else if (RANGES && rho >= kMaxRho) {
+                // Sixteen parts do not hold it either (a few sets take everything): the bucket goes to kta_alive_fallback, from
+                // its first segment on.  What the passes so far applied stays applied — it is the final state of its slots, which
+                // the fallback kernel, resolving everything again, finds as it should be — and counted.
+                if (threadIdx.x == 0) {
+                    fail_from[b] = 0u;
+                    fail_from[(1u << BLOG2) + (uint32_t)atomicAdd(&pool_ctl[POOL_FAILED], 1ull)] = b;
+                }
+                add_running(delta, running, sh.w);
+                return;
+            } else {                                     // the pass did not fit: start over — in more parts (RANGES), or carefully (table state)
                 lds_barrier();                           // everybody has seen the verdict
                 for (uint32_t e = threadIdx.x; e < kEntries + kEntries / 2 + 2 * kOvf; e += kApplyThreads) s_val[e] = 0u;
-                const bool more_parts = RANGES && rho < kMaxRho;
                 if (threadIdx.x == 0) {
                     sh.occ[0] = sh.occ[1] = sh.occ[2] = sh.ovf_n[0] = sh.ovf_n[1] = sh.ovf_n[2] = sh.fail[0] = sh.fail[1] = sh.fail[2] = 0;
                     sh.any_ovf = 0;
-                    if (RANGES) atomicMax(&pool_ctl[POOL_DENSE], (unsigned long long)(more_parts ? rho + 1u : kMaxRho));
+                    if (RANGES) atomicMax(&pool_ctl[POOL_DENSE], (unsigned long long)(rho + 1u));
                     else pool_ctl[POOL_DENSE] = 1ull;
                 }
                 mq = 0;
+                tq = 0;
                 claimed = 0;
                 u = 0;
-                if (more_parts) {
+                if (RANGES) {
                     // (the parts applied so far hold the FINAL state of their slots: their slots' pairs were all in their
                     // passes.  Taking them again in smaller parts finds every bit as it should be and counts nothing.)
                     rho++;
@@ -1965,11 +1966,8 @@ __global__ __launch_bounds__(kApplyThreads) void kta_alive_apply(const unsigned 
                     lds_barrier();
                     continue;
                 }
-                rho = 0;                                 // careful mode works on the whole bucket, in segment order
-                ridx = 0;
                 careful = true;
                 lds_barrier();
-                pick_group_size();
                 continue;
             }
         }

@@ -954,7 +954,9 @@ struct BlobStage {
 struct KafkaState {
     // The descriptors of a decode call travel on the COPY stream into one of two device buffers that take turns, so that
     // the upload of call k + 1 (5.9 MB for 66 667 batches; from pageable memory a staged, host-blocking copy) runs beside the
-    // kernels of call k instead of in front of its own: round 5's bench line had a step of 0.396 ms around a 0.210 ms kernel.
+    // kernels of call k instead of in front of its own: round 5's bench line had a step of 0.396 ms around a 0.210 ms kernel,
+    // now 0.23-0.25 around 0.21-0.22.  (Descriptors in pinned memory — the upload a DMA the host does not wait for — were tried
+    // as an API and dropped: a host that enqueues that far ahead of the GPU met 9 ms stalls of the runtime every few calls.)
     kta_kafka_batch_desc *d_descs2[2] = {nullptr, nullptr};
     uint64_t desc_cap2[2] = {0, 0};
     hipEvent_t ev_desc_up[2] = {nullptr, nullptr}, ev_desc_free[2] = {nullptr, nullptr};   // uploaded (copy stream) / no longer read (compute stream)
@@ -1501,26 +1503,6 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
         KK(ctx, hipStreamSynchronize(s));
         if (n_bad_batches) *n_bad_batches = scal[1];
         if (n_key_bytes) *n_key_bytes = scal[0];
-    }
-    return KTA_OK;
-}
-
-int kta_kafka_descs_alloc(kta_ctx *ctx, uint64_t n, kta_kafka_batch_desc **out)
-{
-    if (!ctx || !out) return KTA_ERR_INVALID;
-    *out = nullptr;
-    KK(ctx, hipSetDevice(kta_internal_device(ctx)));
-    KK(ctx, hipHostMalloc((void **)out, (n ? n : 1) * sizeof(kta_kafka_batch_desc), hipHostMallocDefault));
-    return KTA_OK;
-}
-
-int kta_kafka_descs_free(kta_ctx *ctx, kta_kafka_batch_desc *descs)
-{
-    if (!ctx) return KTA_ERR_INVALID;
-    if (descs) {
-        // (a copy out of the array may still be on its way)
-        KK(ctx, hipStreamSynchronize(kta_internal_copy_stream(ctx)));
-        KK(ctx, hipHostFree(descs));
     }
     return KTA_OK;
 }

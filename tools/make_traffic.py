@@ -50,7 +50,7 @@ def find(sub, counter, largest_grid=False):
 
 
 KIB = 1024.0
-out = {"round": 5, "source": path,
+out = {"round": 6, "source": path,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 5 --warmup 1 "
                  "--preroll 5 --no-cpu-baseline` (tools/profile_round.sh; --no-alive-extras: every kernel at one launch size), turned into this file by tools/make_traffic.py; counters "
                  "are KiB per launch (average over the launches of the kernel unless stated).  FETCH_SIZE is doubled for wide "
@@ -90,23 +90,28 @@ rd, wr = entry("kta_alive_partition32_fused", "kta_alive_partition32<10,true>", 
                "both handlers in one pass: reads = partition, key_len, val_len, ts_ms, key_off, 16 B keys (40 B/record); writes = the "
                "4-byte pairs + one row of the scan's partial workspace per workgroup")
 print("partition32 fused: read %.3f GB vs 40 B x %d = %.3f GB; wrote %.3f GB" % (rd / 1e9, n_alive, 40 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
-rd, wr = entry("kta_alive_apply", "kta_alive_apply<10,true>", "kta_alive_apply<10, true>", 0, 2.0,
+rd, wr = entry("kta_alive_apply", "kta_alive_apply<10,true,false>", "kta_alive_apply<10, true, false>", 0, 2.0,
                "reads = the pair stream (4 B x records) + the 512 MiB bit set, both wide coalesced streams (FETCH_SIZE doubled); "
                "writes = the 512 MiB bit set in whole lines.  None of this is algorithmic input: the batch's algorithmic bytes are "
                "booked on kta_alive_partition32")
 print("apply: read %.3f GB vs pairs %.3f + bit set 0.537 GB; wrote %.3f GB vs 0.537" % (rd / 1e9, 4 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
-# table state (alive_pass_table): pass 1 with 8-byte pairs (and the order check of the seq column), pass 2 on the 32 GiB table
-rd, wr = entry("kta_alive_partition", "kta_alive_partition<10,true>", "kta_alive_partition<10, true>", 36 * n_alive, 2.0,
-               "table state, batches with a seq column: reads = the batch (28 B/record) + the seq column (8 B/record: its order is "
-               "checked here; neighbouring lanes' fifth values overlap); writes = 8-byte pairs (hash, batch-local index, alive) in "
-               "64-byte blocks")
-print("partition (table state): read %.3f GB vs 36 B x records = %.3f GB; wrote %.3f GB vs 8 B x records = %.3f GB"
-      % (rd / 1e9, 36 * n_alive / 1e9, wr / 1e9, 8 * n_alive / 1e9), file=sys.stderr)
-rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false>", "kta_alive_apply<10, false>", 0, 2.0,
-               "table state: reads = the 8-byte pair stream (doubled: a wide stream) + one 8-byte table entry and one seq value per "
+# table state (alive_pass_table / both_handlers_table): pass 1 with 6-byte pairs (the seq column's order checked by the consumer
+# waves), alone and with the metrics handler's work in it; pass 2 on the 32 GiB table
+rd, wr = entry("kta_alive_partition48", "kta_alive_partition48<10,true,false>", "kta_alive_partition48<10, true, false>", 36 * n_alive, 2.0,
+               "table state, batches with a seq column: reads = the batch (28 B/record) + the seq column (8 B/record, read by the consumer "
+               "waves, every line once); writes = 6-byte pairs (slot in the bucket, alive, index inside the workgroup's range) as a dense "
+               "stream in 64-byte blocks")
+print("partition48 (table state): read %.3f GB vs 36 B x records = %.3f GB; wrote %.3f GB vs 6 B x records = %.3f GB"
+      % (rd / 1e9, 36 * n_alive / 1e9, wr / 1e9, 6 * n_alive / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_partition48_fused", "kta_alive_partition48<10,true,true>", "kta_alive_partition48<10, true, true>", 48 * n_alive, 2.0,
+               "table state, both handlers in the one pass: reads = partition, key_len, val_len, ts_ms, key_off, 16 B keys (40 B/record) + "
+               "the seq column (8 B/record); writes = the 6-byte pairs + one row of the scan's partial workspace per workgroup")
+print("partition48 fused: read %.3f GB vs 48 B x records = %.3f GB; wrote %.3f GB" % (rd / 1e9, 48 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
+rd, wr = entry("kta_alive_apply_table", "kta_alive_apply<10,false,false>", "kta_alive_apply<10, false, false>", 0, 2.0,
+               "table state: reads = the 6-byte pair stream (doubled: a wide stream) + one 8-byte table entry and one seq value per "
                "surviving slot (the doubling overstates those scattered reads); writes = one partial write per slot whose entry changes "
                "+ the written list")
-print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 8 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
+print("apply (table state): read %.3f GB vs pairs %.3f GB + survivors; wrote %.3f GB" % (rd / 1e9, 6 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 
 # the 4 M-record launch of ~16 KiB batches: 66 667 batches x 16 lanes -> grid 1 066 688; batches below 28 KiB take <4, 3 KiB, 16>
 # (kta_kafka.hip: pick_geometry) — the row is found by that grid size, whichever geometry served it

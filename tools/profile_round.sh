@@ -3,7 +3,7 @@
 # Per-round profile recipe (tools/profile_round.sh rNN) (run on the GPU box through gpurun): the bench line, rocprofv3 kernel stats of the same
 # command, and the HBM traffic counters in their own passes.  tools/make_traffic.py turns pmc.txt into
 # profiles/traffic.json; the text summaries are copied to profiles/ by hand.
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_${TAG}
