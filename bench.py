@@ -412,11 +412,34 @@ def alive_hot_key_report(kta, device, n_records):
     h.close()
     unique = {"workload": f"c5 law (100 M distinct 16 B keys, 50 % tombstones), bit set state, {n5} records per batch, 4 batches",
               "kernel_ms_per_batch": per_launch, "records_per_s_last": n5 / (per_launch[-1] * 1e-3), **_alive_checked(res.alive_keys, "c5", 0, n5),
-              "note": "every bucket restarts in careful mode and is applied in about 32 instalments (each streams the bucket's 512 KiB of "
-                      "bit set through LDS); round 4 sent all 1024 buckets of the first such batch to the fallback kernel (137 ms) and "
-                      "applied the following batches in slices of 2^26 records (9.4 ms)"}
+              "note": "a bucket holds six times the slots of pass 2's LDS table: it is applied in eight slot-range passes over all its "
+                      "pairs, each sweeping an eighth of the bucket's 512 KiB of bit set (kta_alive_apply<.., RANGES>, round 6); round 5 "
+                      "applied it in about 32 instalments in segment order, each a sweep of the whole 512 KiB (7.9-8.1 ms)"}
+    # a compacted topic of MORE keys than pass 2's tables hold in one piece (20 M distinct: 19.5 k slots per bucket against 16 k):
+    # two slot-range passes per bucket (rounds 4-5: an instalment after every group of segments, 7.6 ms)
+    spec, _ = kta.synth_preset("c3")
+    spec.n_distinct_keys = 20_000_000
+    h = kta.HipMetricHandler(64, count_alive_keys=True, device=device)
+    b = h.device_batch_alloc(n5, n5 * 16)
+    h.synth_fill_device(spec, 0, n5, b)
+    h.submit_device(b, n5, 0, which=2)
+    h.sync()
+    h.kernel_time_stats()
+    h.set_timing(True)
+    for k in range(3):
+        h.submit_device(b, n5, 0, which=2)
+    h.sync()
+    avg_ms, cnt = h.kernel_time_stats()
+    h.set_timing(False)
+    res, _ = h.finish()
+    info = h.alive_pass_info()
+    h.device_batch_free(b)
+    h.close()
+    many = {"workload": f"c3 shape with 20 M distinct keys, bit set state, {n5} records per batch", "kernel_ms": avg_ms[2], "launches": int(cnt[2]),
+            "records_per_s": n5 / (avg_ms[2] * 1e-3), "buckets_to_the_fallback_kernel": info["failed_buckets"],
+            **_alive_checked(res.alive_keys, "c3", 20_000_000, n5)}
     return {"workload": f"c3 shape with 1 / 40 distinct keys over {n_records} records (bit set state)", "rows": rows,
-            "mostly_unique_keys": unique}
+            "mostly_unique_keys": unique, "many_keys": many}
 
 
 def _recompress_batches(lib, raw, codec):

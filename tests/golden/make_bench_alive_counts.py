@@ -55,6 +55,7 @@ n_hot, n_big = 1 << 26, 15 << 24
 for d in (1, 40):
     table[f"c3:{d}:0:{n_hot}"] = alive_after("c3", d, n_hot)[n_hot]
 table[f"c5:0:0:{n_big}"] = alive_after("c5", 0, n_big)[n_big]
+table[f"c3:20000000:0:{n_big}"] = alive_after("c3", 20_000_000, n_big)[n_big]      # alive_pass_hot_key's "many_keys" row
 # alive_pass / both_handlers resubmit records [0, n_big) (idempotent); alive_pass_table walks six consecutive batches
 steps = [n_big * (k + 1) for k in range(6)]
 for upto, v in alive_after("c3", 0, steps[-1], [n_hot] + steps).items():     # (n_hot: boundary_per_message's c3 row)

@@ -175,6 +175,33 @@ def test_baseline_config_3_alive_keys_2e30_records():
 
 
 
+def test_compacted_topic_of_20m_keys_takes_slot_range_passes_vs_oracle():
+    """More distinct keys per batch than pass 2's tables hold in one piece: 20 M keys over 2^27 records are 19.5 k slots per
+    bucket against the table's 16 k + 2 k.  The bucket's plain attempt fails, it is listed for kta_alive_apply<.., RANGES>
+    and applied in two slot-range passes (rounds 4-5: an instalment after every group of segments, 7.6 instead of 2.6 ms
+    at 2^28 records); nothing reaches the fallback kernel.  Two batches — the second revisits the first's keys — against
+    the oracle: alive count, every bit, the fused pass's counters."""
+    sp, _ = kta.synth_preset("c3")
+    sp.n_distinct_keys = 20_000_000
+    P, nb, batches = 64, 1 << 27, 2
+    with kta.HipMetricHandler(P, count_alive_keys=True, now=NOW) as h:
+        b = h.device_batch_alloc(nb, nb * 16)
+        for k in range(batches):
+            assert h.synth_fill_device(sp, k * nb, nb, b) == nb * 16
+            h.submit_device(b, nb, k * nb, which=3)
+            h.sync()
+        want_c, earliest, latest, smallest, largest = _oracle_counters_threaded(sp, nb * batches, P)
+        o = _alive_oracle_threaded(sp, nb * batches)
+        res, c = h.finish()
+        info = h.alive_pass_info()
+        assert info["slices"] == batches == info["fused"] and info["failed_buckets"] == 0, info
+        assert res.alive_keys == o.alive_keys() and 10_000_000 < res.alive_keys <= 20_000_000
+        assert np.array_equal(c, want_c) and res.overall_count == nb * batches
+        assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
+        h.device_batch_free(b)
+    o.close()
+
+
 _C5_ONE_GPU = {}
 
 
@@ -199,9 +226,9 @@ def _c5_one_gpu_oracle(n):
 @pytest.mark.parametrize("which", [2, 3])
 def test_config_5_key_law_on_one_gpu_full_batches_vs_oracle(which):
     """The path a single GPU takes on config 5's key law (100 M distinct 16-byte keys, 50 % tombstones) in the bit set
-    state: a bucket of a 15 x 2^24-record batch holds ten times the distinct slots of pass 2's LDS table, so every bucket
-    restarts in careful mode and is applied in instalments — groups of segments sized from the fills so that a group
-    always fits (kta_alive.hip: pick_group_size; round 4 sent all 1024 buckets of such a batch to kta_alive_fallback and
+    state: a bucket of a 15 x 2^24-record batch holds six times the distinct slots of pass 2's LDS table, so every bucket
+    fails its plain attempt and is applied in eight slot-range passes (kta_alive.hip: kta_alive_apply<.., RANGES>; rounds
+    4-5 applied it in instalments in segment order, round 4 sent all 1024 buckets of such a batch to kta_alive_fallback and
     applied the following batches in slices, a path no test reached and whose running count was wrong).  Two
     consecutive batches against ONE oracle fed in consumption order (/root/reference/src/metric.rs:288-305 is order
     dependent, kafka.rs:107-109 runs both handlers per message): every bit of the set, the running alive count, and for

@@ -557,31 +557,49 @@ def test_adversarial_alive_shapes_at_scale(hc, ht, state, shape, log2n):
     assert np.array_equal(h.export_alive_bitmap(), o.alive_words())
 
 
-def test_bucket_given_up_in_careful_mode_is_resolved_exactly(hc):
-    """A bucket WITHOUT pool pairs that pass 2 gives up in careful mode — not a hot key's bucket (those overflow their segments
-    into the pool), but one whose table overflows: 2 000 keys whose hashes fall into ONE slice of 128 sets of one bucket
-    (2^18 consecutive slots; a slice holds 128 x 8 entries + 128 in its side table), all of them in the first sixteenth of the
-    batch, i.e. in the first group of segments, among random keys.  The fast attempt fails, careful mode's first group
-    fails, and kta_alive_fallback resolves the bucket from its first segment on, its workgroups sharing the 256 sub-ranges
-    (the library's counter says that exactly one bucket went there).  Count and every bit against the oracle; twice, the
-    second batch on top of what the first left (/root/reference/src/metric.rs:289-304: the order decides)."""
-    n = 1 << 24
-    rng = np.random.default_rng(4242)
-    want_prefix = (0x155 << 4) | 7                       # hash >> 18: bucket 0x155, slice 7
-    special = np.zeros((0, 16), np.uint8)
-    while len(special) < 2000:
-        cand = rng.integers(0, 256, size=(4_000_000, 16), dtype=np.uint8)
-        special = np.concatenate([special, cand[(_fnv32_np(cand) >> 18) == want_prefix]])
-    special = special[:2000]
-    assert fnv32(special[0].tobytes()) >> 18 == want_prefix
-    pool_keys = rng.integers(0, 256, size=(1 << 20, 16), dtype=np.uint8)        # the ordinary keys
-    keys = pool_keys[rng.integers(0, len(pool_keys), size=n)]
-    where = rng.choice(n // 16 - 1000, size=4000, replace=False)                 # every special key twice, in the first group's records
-    keys[where] = special[np.arange(4000) % 2000]
-    cols = {"partition": rng.integers(0, 64, size=n).astype(np.int32), "key_len": np.full(n, 16, np.int32),
+def _keys_with_hash_prefix(rng, want_prefix, shift, count):
+    """`count` distinct random 16-byte keys whose reference hash (src/fnv32.rs:92-101) has `want_prefix` above bit `shift`:
+    random candidates, hashed by the C oracle's fnv1a on a few threads (numpy's 16 passes over 64-bit arrays are too slow for the
+    hundreds of millions of candidates an 18-bit prefix asks for)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle_c import lib
+    L, T, m = lib(), (16 if (os.cpu_count() or 8) >= 32 else 8), 1 << 24
+    pool = ThreadPoolExecutor(T)
+    kl = np.full(m, 16, np.int32)
+    ko = (np.arange(m, dtype=np.uint64) * 16).astype(np.uint32)
+    out = np.empty(m, np.uint32)
+    found = np.zeros((0, 16), np.uint8)
+    while len(found) < count:
+        cand = rng.integers(0, 256, size=(m, 16), dtype=np.uint8)
+        list(pool.map(lambda j: L.kto_fnv1a_soa(j * (m // T), m // T, kl.ctypes.data, ko.ctypes.data, cand.ctypes.data, out.ctypes.data),
+                      range(T)))
+        found = np.concatenate([found, cand[(out >> shift) == want_prefix]])
+    pool.shutdown()
+    keys = found[:count]
+    assert fnv32(keys[0].tobytes()) >> shift == want_prefix and len(np.unique(keys, axis=0)) == count
+    return keys
+
+
+def _special_keys_batch(rng, n, special, where, pool_keys=1 << 20):
+    keys = rng.integers(0, 256, size=(pool_keys, 16), dtype=np.uint8)[rng.integers(0, pool_keys, size=n)]   # the ordinary keys
+    keys[where] = special[np.arange(len(where)) % len(special)]
+    return {"partition": rng.integers(0, 64, size=n).astype(np.int32), "key_len": np.full(n, 16, np.int32),
             "val_len": np.where(rng.random(n) < 0.4, -1, 100).astype(np.int32),
             "ts_ms": np.full(n, 1_600_000_000_000, np.int64), "key_off": (np.arange(n, dtype=np.uint64) * 16).astype(np.uint32),
             "key_bytes": keys.reshape(-1), "n_key_bytes": 16 * n}
+
+
+def test_bucket_given_up_in_careful_mode_is_resolved_exactly(hc):
+    """A bucket that pass 2 does not attempt and kta_alive_fallback resolves: 2 000 keys whose hashes fall into one bucket, every
+    one of them twice within the first sixteenth of the batch — sixteen segments take 250 of them each on top of their 64
+    ordinary pairs, more than a segment's 256, so the bucket's pairs overflow into the pool (the name is round 5's, when the
+    case was thought to reach careful mode; the bit set state has none any more).  Count and every bit against the oracle;
+    twice, the second batch on top of what the first left (/root/reference/src/metric.rs:289-304: the order decides); the
+    library's counter says that exactly one bucket went to the fallback kernel in either batch."""
+    n = 1 << 24
+    rng = np.random.default_rng(4242)
+    special = _keys_with_hash_prefix(rng, (0x155 << 4) | 7, 18, 2000)            # hash >> 18: bucket 0x155, its slots' seventh sixteenth
+    cols = _special_keys_batch(rng, n, special, rng.choice(n // 16 - 1000, size=4000, replace=False))
     o = Oracle(NOW, True)
     hc.reset()
     b, nb = hc.upload_batch(cols, with_keys=True)
@@ -595,6 +613,34 @@ def test_bucket_given_up_in_careful_mode_is_resolved_exactly(hc):
     assert info["failed_buckets"] == 2, info             # one bucket, in either batch
     assert res.alive_keys == o.alive_keys()
     assert np.array_equal(hc.export_alive_bitmap(), o.alive_words())
+
+
+def test_bucket_that_sixteen_slot_ranges_do_not_hold_goes_to_the_fallback_kernel(hc):
+    """What defeats the slot-range passes of pass 2 (kta_alive_apply<.., RANGES>): 1 500 distinct keys whose slots lie in ONE
+    window of 2^14 consecutive slots, spread evenly over the batch (six per segment: nothing overflows into the pool).  At
+    every number of parts, 1 to 16, the window lies inside one slice of 128 sets, which holds 128 x 8 entries + the 128 of
+    its side table: the plain attempt fails, the passes with 2, 4, 8 and 16 parts fail, and the bucket is handed to
+    kta_alive_fallback from its first segment on — after parts of its slot range may already have been applied, which the
+    fallback kernel must find as they should be.  Count, running count and every bit against the oracle, over two batches."""
+    n = 1 << 24
+    rng = np.random.default_rng(777)
+    special = _keys_with_hash_prefix(rng, (0x2A3 << 8) | 0x5C, 14, 1500)        # hash >> 14: bucket 0x2A3, window 0x5C of its 256
+    cols = _special_keys_batch(rng, n, special, rng.choice(n, size=3000, replace=False))
+    o = Oracle(NOW, True)
+    hc.reset()
+    b, nb = hc.upload_batch(cols, with_keys=True)
+    for k in range(2):
+        o.run_soa(cols)
+        hc.submit_device(b, nb, k * nb, which=2)
+        hc.sync()
+    info = hc.alive_pass_info()
+    res, _ = hc.finish()
+    hc.device_batch_free(b)
+    assert info["failed_buckets"] == 2, info             # that one bucket, in either batch
+    assert res.alive_keys == o.alive_keys()
+    words = hc.export_alive_bitmap()
+    assert np.array_equal(words, o.alive_words())
+    assert int(np.bitwise_count(words).sum(dtype=np.uint64)) == res.alive_keys
 
 
 def test_max_partitions_uses_large_dynamic_lds():
