@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkta_hip.so")
+LIB_PATH = os.environ.get("KTA_LIB_PATH") or os.path.join(HERE, "libkta_hip.so")   # (KTA_LIB_PATH: another build of the library, tools/build_variant.sh)
 
 KTA_OK = 0
 KTA_ERR_INVALID = -1

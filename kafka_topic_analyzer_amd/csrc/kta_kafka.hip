@@ -301,7 +301,9 @@ struct LzWindow {
             if (in_ring) {
                 if (lane < n) v = ring()[s & (kLzRing - 1)];
             } else {                                               // further back: written back already (kLzRing >= chunk + 64)
-                __threadfence();
+                // (workgroup scope: the wave's own earlier stores have reached L2 — a wait, no cache maintenance; the
+                // agent-scope fence that stood here until round 6 also wrote the L2 back and invalidated it, per far match)
+                __threadfence_block();
                 if (lane < n) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (lane < n) ring()[(op + lane) & (kLzRing - 1)] = v;
@@ -415,6 +417,81 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         if (abs - wabs >= kZsWin) fetch(abs, 1);   // (unsigned: also abs < wabs and the empty window)
         return uni(reinterpret_cast<const uint8_t *>(win4)[abs - wabs]);
     }
+    // The FSE decoding table of w.norm[0 .. n_sym) (kta_zstd.h: zs_build_fse, RFC 8878 4.1.1) with all 64 lanes: the spec's
+    // loops — spread the symbols over the cells with a stride, then walk the cells in order handing every symbol its states —
+    // are two chains of dependent LDS accesses, 2^log long, which a wave that executes them lane-uniformly pays at full LDS
+    // latency each: three tables of 2^9 cells were most of the 58 k instructions and 0.35 ms a batch took (rounds 2-5).
+    //   * the symbols "less than one" (norm -1) take the cells from the top, one each, in symbol order: a ballot;
+    //   * the stride is odd, so raw step r lands on cell (r x step) mod size, every cell once; the cells below `high` are
+    //     kept, in the order of r, and kept cell number j belongs to the symbol whose run of counts holds j (prefix sums of
+    //     the counts, one symbol per lane; a cell finds its symbol by bisection);
+    //   * cell i's state number is count(symbol) + the cells of that symbol below i: 64 cells at a time in ascending order,
+    //     a lane counts its symbol among the lower lanes (64 readlanes) on top of what the chunks before left in w.next.
+    __device__ __forceinline__ bool build_fse(kta::ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
+    {
+        const uint32_t size = 1u << log, mask = size - 1u;
+        __syncthreads();                                   // (w.norm was written lane-uniformly: every lane's writes are in)
+        const int32_t cnt = lane < n_sym ? (int32_t)w.norm[lane] : 0;        // lane = symbol (at most 53 of them)
+        const bool less = cnt == -1;
+        const unsigned long long mless = __builtin_amdgcn_ballot_w64(less);
+        const uint32_t n_less = (uint32_t)__popcll(mless), high = size - n_less;
+        const uint32_t k_less = __builtin_amdgcn_mbcnt_hi((uint32_t)(mless >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mless, 0u));
+        if (less) t[size - 1u - k_less] = lane;
+        // exclusive prefix sums of the positive counts -> w.next[symbol] (the run of kept cells of the symbol begins there)
+        uint32_t run = cnt > 0 ? (uint32_t)cnt : 0u, incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += up;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total + n_less != size) return false;          // (the counts do not fill the table: zs_build_fse ends with pos != 0)
+        uint16_t *first = w.first;
+        first[lane] = (uint16_t)(incl - run);
+        __syncthreads();
+        const uint32_t step = (size >> 1) + (size >> 3) + 3u;
+        uint32_t kept_before = 0;                          // (wave-uniform) kept cells of the chunks before this one
+        for (uint32_t r0 = 0; r0 < size; r0 += 64u) {
+            const uint32_t r = r0 + lane, pos = (r * step) & mask;
+            const bool keep = r < size && pos < high;
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
+            const uint32_t j = kept_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            kept_before += (uint32_t)__popcll(mk);
+            // the last symbol whose run begins at or below j (runs of length 0 begin where the next one does: take the last)
+            uint32_t lo = 0, hi = n_sym;                   // answer in [lo, hi)
+#pragma unroll 1
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)first[mid] <= j) lo = mid; else hi = mid;
+            }
+            if (keep) t[pos] = lo;
+        }
+        __syncthreads();
+        // states: next[symbol] = its count (1 for the less-than-one symbols), then the cells in ascending order
+        w.next[lane] = (uint16_t)(less ? 1u : run);
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < size; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const bool on = i < size;
+            const uint32_t sym = on ? t[i] : 0xFFFFu;
+            uint32_t below = 0, same = 0;
+#pragma unroll 8
+            for (uint32_t k = 0; k < 64u; k++) {
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)k);
+                same += sk == sym ? 1u : 0u;
+                below += sk == sym && k < lane ? 1u : 0u;
+            }
+            const uint32_t x = on ? (uint32_t)w.next[sym] + below : 1u;
+            __syncthreads();                               // (every lane has read its symbol's counter)
+            if (on && below + 1u == same) w.next[sym] = (uint16_t)(x + 1u);   // the chunk's last cell of the symbol leaves the counter behind it
+            if (on) {
+                const uint32_t nb = log - kta::zs_highbit(x);
+                t[i] = sym | (nb << 8) | (((x << nb) - size) << 16);
+            }
+            __syncthreads();
+        }
+        return true;
+    }
     // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; outside the slice: zeros
     __device__ __forceinline__ uint64_t le64(uint64_t base, uint64_t n, int64_t first)
     {
@@ -439,6 +516,12 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     uint64_t op;
     uint8_t *ring;
     uint32_t lane;
+    // (Round 6 measured the kernel without its literal copies (- 0.43 of 2.59 ms) and without its match copies (- 1.03), then
+    // tried what those numbers suggested: far matches without any fence (s_waitcnt vmcnt(63): what lies behind the ring is
+    // more than 63 stores old) — kept, worth nothing measurable —, every match served from the ring (- 0.08 ms: the far
+    // path is not it), the 256 bytes behind a literal run requested ahead and dealt with ds_bpermute (+ 0.16 ms: dropped).
+    // What a batch costs is its ~ 50 k instructions at the ~ 11 cycles each that two waves per SIMD leave exposed; the
+    // copies are a third of them.  More waves — under 128 registers and 10 KiB of LDS a wave — is the way, not done.)
 
     __device__ __forceinline__ void put(uint64_t i, uint8_t v)
     {
@@ -497,7 +580,13 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
             if (dist <= kZsRing) {
                 if (i < len) v = ring[s & (kZsRing - 1)];
             } else {
-                __threadfence();
+                // The bytes behind the ring were stored at least kZsRing / 64 = 128 store instructions ago (a store moves at most
+                // 64 bytes), and a wave's memory operations complete in order: once all but its last 63 are done, those stores
+                // have reached L2, where the load — agent scope: past L1 — finds them.  No fence: the workgroup-scope fence
+                // waits for EVERY earlier store, the literals and matches just written, a memory round trip per far match
+                // (and rounds 2-5's agent-scope fence wrote the L2 back on top of it).
+                static_assert(kZsRing >= 64 * 64, "what lies behind the ring is more than 63 stores old");
+                asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
                 if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (i < len) put(i, v);
@@ -519,7 +608,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
             kta::ZsMem m{src.memory()};
             ok = kta::zs_huf_stream(w, m, my_at, my_n, out + my_out, my_count);
         }
-        __threadfence();
+        __threadfence_block();                             // (the lanes' literals are read back by the wave's other lanes, past L1)
         return __builtin_amdgcn_ballot_w64(!ok) == 0;
     }
 };

@@ -51,6 +51,7 @@ struct ZsWork {
     uint16_t huf[1 << 11];
     int16_t norm[64];          // normalized counts of the table being built
     uint16_t next[64];         // per-symbol state counters while building
+    uint16_t first[64];        // (the wave source's table build: where a symbol's run of cells begins)
     uint8_t weights[256];
     uint8_t ll_log, of_log, ml_log, huf_log;
     uint8_t have_ll, have_of, have_ml, have_huf;
@@ -235,6 +236,20 @@ KTA_ZSTD_HD bool zs_build_fse(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint
     return true;
 }
 
+// A source may bring its own way of building the table — the wave source does (kta_kafka.hip: all 64 lanes at it; the loops
+// above are ~2 500 dependent LDS round trips for three tables of 2^9 cells when every lane of a wave walks them alike) —;
+// every other source takes the loops above, which are the format's own words (RFC 8878 4.1.1).
+template <class S>
+KTA_ZSTD_HD auto zs_build_fse_any(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym, int) -> decltype(src.build_fse(w, t, log, n_sym))
+{
+    return src.build_fse(w, t, log, n_sym);
+}
+template <class S>
+KTA_ZSTD_HD bool zs_build_fse_any(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym, long)
+{
+    return zs_build_fse(src, w, t, log, n_sym);
+}
+
 KTA_ZSTD_HD void zs_build_rle(uint32_t *t, uint32_t sym) { t[0] = sym; }   // log 0: one state, no bits
 
 // Predefined distributions (RFC 8878 3.1.1.3.2.2.1-3): literal lengths and match lengths accuracy 6, offsets 5.
@@ -265,7 +280,7 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         zs_default_norm(w, which);
         log = which == 1 ? 5 : 6;
         have = 1;
-        return zs_build_fse(src, w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53));
+        return zs_build_fse_any(src, w, t, log, which == 0 ? 36 : (which == 1 ? 29 : 53), 0);
     }
     if (mode == 1) {
         if (*pos >= n || src.byte(base + *pos) > max_sym) return false;
@@ -282,7 +297,7 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
         *pos += f.bit >> 3;
         log = (uint8_t)l;
         have = 1;
-        return zs_build_fse(src, w, t, l, n_sym);
+        return zs_build_fse_any(src, w, t, l, n_sym, 0);
     }
     return have != 0;   // repeat: the previous block's table
 }
@@ -310,7 +325,7 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
         ZsFwd f = zs_fwd_init(base + 1, hb);
         uint32_t n_sym = 0;
         const uint32_t log = zs_read_norm(src, f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
-        if (!log || !zs_build_fse(src, w, w.wfse, log, n_sym)) return 0;
+        if (!log || !zs_build_fse_any(src, w, w.wfse, log, n_sym, 0)) return 0;
         const uint64_t at = f.bit >> 3;
         if (at >= hb) return 0;
         ZsBack b;
