@@ -751,8 +751,12 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition32(AliveColum
         const uint32_t f = s_pos[b], k = f / kBlk32, rem = f % kBlk32;
         if (rem) {
             if ((k + 1u) * kBlk32 <= cap) {
-                uint32_t *dst = pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * kBlk32;
-                for (uint32_t q = 0; q < rem; q++) dst[q] = s_ring32[ring32_at(b, k * kBlk32 + q)];
+                // the WHOLE block, its unwritten entries zero (a zero pair is no pair, and pass 2 reads a segment as far as
+                // its fill): four 16-byte stores of one line — entry by entry these were 2 M four-byte writes per batch,
+                // each a read-modify-write at the memory's side (round 6's WRITE_SIZE: 6.5 % over the pairs' bytes)
+                uint4 *dst = reinterpret_cast<uint4 *>(pairs + ((uint64_t)b * W + w) * cap + (uint64_t)k * kBlk32);
+#pragma unroll
+                for (uint32_t q = 0; q < kBlk32 / 4u; q++) dst[q] = *reinterpret_cast<const uint4 *>(s_ring32 + ring32_at(b, k * kBlk32 + 4u * q));
             } else {
                 // a whole pool block, padded (a zero pair is no pair); behind everything the consumers wrote (pool_tag_note)
                 const unsigned long long at = atomicAdd(&pool_ctl[POOL_CURSOR], (unsigned long long)kBlk32);
@@ -1182,9 +1186,13 @@ __global__ __launch_bounds__(kPartThreads) void kta_alive_partition48(AliveColum
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         const uint32_t pos = s_ctl[b].x, out = s_ctl[b].y;
         const uint32_t lim = pos < cap ? pos : cap;
-        const uint32_t remw = (6u * lim - out) / 2u;                               // words still in the ring: less than a block
-        unsigned short *dst = seg_base + (uint64_t)b * W * cap * 3u + out / 2u;
-        for (uint32_t q = 0; q < remw; q++) dst[q] = s_ring48[ring48_at(b, out / 2u + q)];
+        // (less than a block of words is still in the ring: the WHOLE block goes out, its unwritten words zero — pass 2 reads a
+        // segment as far as its fill —, four 16-byte stores of one line instead of up to 31 two-byte ones)
+        if (6u * lim != out) {
+            uint4 *dst = reinterpret_cast<uint4 *>(seg_base + (uint64_t)b * W * cap * 3u + out / 2u);
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) dst[q] = *reinterpret_cast<const uint4 *>(s_ring48 + ring48_at(b, out / 2u + 8u * q));
+        }
         counts[(uint64_t)b * W + w] = lim;
     }
 }

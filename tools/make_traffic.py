@@ -97,13 +97,13 @@ rd, wr = entry("kta_alive_apply", "kta_alive_apply<10,true,false>", "kta_alive_a
 print("apply: read %.3f GB vs pairs %.3f + bit set 0.537 GB; wrote %.3f GB vs 0.537" % (rd / 1e9, 4 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
 # table state (alive_pass_table / both_handlers_table): pass 1 with 6-byte pairs (the seq column's order checked by the consumer
 # waves), alone and with the metrics handler's work in it; pass 2 on the 32 GiB table
-rd, wr = entry("kta_alive_partition48", "kta_alive_partition48<10,true,false>", "kta_alive_partition48<10, true, false>", 36 * n_alive, 2.0,
+rd, wr = entry("kta_alive_partition48", "kta_alive_partition48<10,true,false>", "kta_alive_partition48<10, true, false", 36 * n_alive, 2.0,
                "table state, batches with a seq column: reads = the batch (28 B/record) + the seq column (8 B/record, read by the consumer "
                "waves, every line once); writes = 6-byte pairs (slot in the bucket, alive, index inside the workgroup's range) as a dense "
                "stream in 64-byte blocks")
 print("partition48 (table state): read %.3f GB vs 36 B x records = %.3f GB; wrote %.3f GB vs 6 B x records = %.3f GB"
       % (rd / 1e9, 36 * n_alive / 1e9, wr / 1e9, 6 * n_alive / 1e9), file=sys.stderr)
-rd, wr = entry("kta_alive_partition48_fused", "kta_alive_partition48<10,true,true>", "kta_alive_partition48<10, true, true>", 48 * n_alive, 2.0,
+rd, wr = entry("kta_alive_partition48_fused", "kta_alive_partition48<10,true,true>", "kta_alive_partition48<10, true, true", 48 * n_alive, 2.0,
                "table state, both handlers in the one pass: reads = partition, key_len, val_len, ts_ms, key_off, 16 B keys (40 B/record) + "
                "the seq column (8 B/record); writes = the 6-byte pairs + one row of the scan's partial workspace per workgroup")
 print("partition48 fused: read %.3f GB vs 48 B x records = %.3f GB; wrote %.3f GB" % (rd / 1e9, 48 * n_alive / 1e9, wr / 1e9), file=sys.stderr)
