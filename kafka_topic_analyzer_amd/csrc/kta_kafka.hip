@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kGzipLanes) void kafka_zstd_inflate(uint8_t *buffer
 // written output, behind a fence), the four Huffman streams of a literals section run on four lanes.
 // The policy methods are force-inlined: a call would pass `this` through memory, and the LDS address
 // spaces of the window, the ring and the tables would be lost (flat accesses, private-memory traffic).
-constexpr uint32_t kZsWin = 2048;
+constexpr uint32_t kZsWin = 2048;                  // (1 KiB — a thirteenth wave per CU — measured the same: round 6)
 constexpr uint64_t kZsNoWindow = 1ull << 62;       // (x - kZsNoWindow is huge for every buffer offset x: "not in the window")
 
 struct ZsWaveSrc {                 // byte source: the batch payload behind an LDS window (absolute buffer offsets)
@@ -585,8 +585,10 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
                 // have reached L2, where the load — agent scope: past L1 — finds them.  No fence: the workgroup-scope fence
                 // waits for EVERY earlier store, the literals and matches just written, a memory round trip per far match
                 // (and rounds 2-5's agent-scope fence wrote the L2 back on top of it).
-                static_assert(kZsRing >= 64 * 64, "what lies behind the ring is more than 63 stores old");
-                asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                static_assert(kZsRing >= 1024, "what lies behind the ring is at least 16 stores old");
+                if (kZsRing >= 64 * 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                else if (kZsRing >= 32 * 64) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
                 if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (i < len) put(i, v);
@@ -637,10 +639,15 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
 
 __global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
 {
+    // The wave is bound by latencies, so what the kernel delivers goes with the waves a CU holds, and those go with the LDS:
+    // tables 10 KiB + window 2 KiB + the mirror of the output's last bytes.  That mirror was 8 KiB (8 waves per CU) until
+    // round 6; matches that reach behind it read the output from L2, which costs little (every match served from the ring:
+    // - 3 %), so it is 1 KiB now — 12 waves per CU: 2.42 -> 1.95 ms for 1 M records in 16 KiB batches (4 KiB: 2.24, 2 KiB: 2.10).
+    constexpr uint32_t kRing = 1024;
     __shared__ kta::ZsWork s_w;
     __shared__ uint4 s_win[kZsWin / 16];
-    __shared__ uint8_t s_ring[8192];
-    zstd_inflate_wave<8192>(buffer, descs, n_batches, &s_w, s_win, s_ring);
+    __shared__ uint8_t s_ring[kRing];
+    zstd_inflate_wave<kRing>(buffer, descs, n_batches, &s_w, s_win, s_ring);
 }
 
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
