@@ -153,6 +153,11 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             // Every lane takes part in every group's window: W / 1024 instructions per group, each a KiB of one window on a
             // 128-byte line (against 256 bytes of each of G windows: - 2 % at 16 KiB batches, - 4 % at 2 KiB, round 5); the
             // window's base and size come from the group's first lane through scalar registers.
+            // (A group that does not run this round still takes its instructions: the blob's first block into its own window.
+            // Passing it over with a scalar branch on the group's first lane — round 6, ADVICE of round 5 — cost the ordinary
+            // case 12-15 %: 0.151 / 0.139 / 0.151 ms instead of 0.126 / 0.120 / 0.136 at 2 / 16 / 134 KiB, the loads no longer one
+            // straight run.  Waves whose batches differ much in size pay for their finished groups; the dispatcher deals
+            // neighbouring batches to a wave, which are mostly of a size.)
             constexpr uint32_t PER = W / 1024;
             uint4 stage[NLOAD];
 #pragma unroll
