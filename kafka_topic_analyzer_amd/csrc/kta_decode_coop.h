@@ -155,8 +155,8 @@ __device__ __forceinline__ void decode_coop_rounds(const uint4 *blocks, const kt
             // window's base and size come from the group's first lane through scalar registers.
             // (A group that does not run this round still takes its instructions: the blob's first block into its own window.
             // Passing it over with a scalar branch on the group's first lane — round 6, ADVICE of round 5 — cost the ordinary
-            // case 12-15 %: 0.151 / 0.139 / 0.151 ms instead of 0.126 / 0.120 / 0.136 at 2 / 16 / 134 KiB, the loads no longer one
-            // straight run.  Waves whose batches differ much in size pay for their finished groups; the dispatcher deals
+            // case 10-18 %: 0.153 / 0.142 / 0.154 ms instead of 0.130 / 0.127 / 0.139 at 2 / 16 / 134 KiB side by side on one box,
+            // the loads no longer one straight run.  Waves whose batches differ much in size pay for their finished groups; the dispatcher deals
             // neighbouring batches to a wave, which are mostly of a size.)
             constexpr uint32_t PER = W / 1024;
             uint4 stage[NLOAD];
