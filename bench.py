@@ -761,6 +761,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # (multi-process GPU work on this pool needs dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # first: its bundled HIP runtime must be the one this process loads
     import torch.distributed as dist
     import numpy as np
