@@ -17,7 +17,7 @@ def test_bench_with_forced_collectives_one_rank():
     env = dict(os.environ, KTA_BENCH_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-alive",
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-alive", "--no-decode", "--no-hostfed",
            "--records-per-gpu", str(1 << 24)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
