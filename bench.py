@@ -674,27 +674,26 @@ def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
     buf = np.zeros(ln.value + 64, np.uint8)
     lib.kta_kafka_encode_synth_host(C.byref(spec), 0, n_records, rpb, buf.ctypes.data, ln.value, C.byref(ln))
     out = {}
-    # (the first leg of the process pays what the second does not — the blob ring's pinned pages touched for the first time, the
-    # decode kernels loaded: round 5's line had `metrics` at 46 GB/s behind `count_alive_keys` at 52 on the same blobs — so an
-    # untimed leg goes first and the order of the timed ones decides nothing)
-    for alive in (None, False, True):
-        warm_only = alive is None
-        alive = bool(alive)
+
+    def leg(log, log_len, alive, n_passes, codec=None):
+        """The log cut into the ring's three pinned blobs once, then the blobs resubmitted n_passes times; returns the row."""
         h = kta.HipMetricHandler(256, count_alive_keys=alive, device=device)
         h._check(lib.kta_kafka_configure(h._ctx, 0, 3))
-        filled, sizes, recs = 0, [], []
+        sizes, recs = [], []
         total_bytes = total_recs = 0
-        stages, at, k = 3, 0, 0
+        stages, at = 3, 0
         t0 = None
-        for k in range(stages + (1 if warm_only else passes) * stages):
+        for k in range(stages + n_passes * stages):
             if k == stages:
                 h.sync()
                 t0 = time.perf_counter()
             ptr, cap = C.c_void_p(), C.c_uint64()
             h._check(lib.kta_kafka_blob_acquire(h._ctx, C.byref(ptr), C.byref(cap)))
-            if k < stages:      # fill each pinned blob once with the next stretch of the log
-                take = min(cap.value, ln.value - at)
-                C.memmove(ptr, buf.ctypes.data + at, take)
+            if k < stages:      # fill each pinned blob once with the next stretch of the log (a short log: all of it, again)
+                if at >= log_len:
+                    at = 0
+                take = min(cap.value, log_len - at)
+                C.memmove(ptr, log.ctypes.data + at, take)
                 sizes.append(take)
             st = N.KtaKafkaIndexStats()
             h._check(lib.kta_kafka_blob_submit(h._ctx, sizes[k % stages], k % 256, C.byref(st)))
@@ -708,16 +707,43 @@ def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
         h.sync()
         dt = time.perf_counter() - t0
         res, _ = h.finish(allow_bad_partition=True)
-        assert res.overall_count == sum(recs) * ((1 if warm_only else passes) + 1)
-        if warm_only:
-            h.close()
-            continue
-        out["count_alive_keys" if alive else "metrics"] = {
-            "workload": f"c4 records as v2 record batches of {rpb} (~16 KiB), uncompressed; {passes * stages} pinned blobs of "
-                        f"{sizes[0]} bytes resubmitted" + (", -c (keys zero-copy from the blob)" if alive else ""),
-            "records": total_recs, "raw_log_bytes": total_bytes, "ms": dt * 1e3,
-            "records_per_s": total_recs / dt, "raw_log_GBps": total_bytes / dt / 1e9}
+        assert res.overall_count == sum(recs) * (n_passes + 1) and res.bad_partition_records == 0
         h.close()
+        what = "uncompressed" if codec is None else codec
+        return {"workload": f"c4 records as v2 record batches of {rpb} (~16 KiB), {what}; {n_passes * stages} pinned blobs of "
+                            f"{sizes[0]} bytes resubmitted" + (", -c (keys zero-copy from the blob)" if alive else ""),
+                "records": total_recs, "raw_log_bytes": total_bytes, "ms": dt * 1e3,
+                "records_per_s": total_recs / dt, "raw_log_GBps": total_bytes / dt / 1e9}
+
+    # (the first leg of the process pays what the second does not — the blob ring's pinned pages touched for the first time, the
+    # decode kernels loaded: round 5's line had `metrics` at 46 GB/s behind `count_alive_keys` at 52 on the same blobs — so an
+    # untimed leg goes first and the order of the timed ones decides nothing)
+    leg(buf, ln.value, False, 1)
+    out["metrics"] = leg(buf, ln.value, False, passes)
+    out["count_alive_keys"] = leg(buf, ln.value, True, passes)
+    # The same pipeline fed COMPRESSED logs (1 M records per codec; `raw_log_GBps` is then GB/s of compressed log over the link):
+    # where the inflate kernel keeps up with PCIe the row sits at the link's rate, where it does not the kernel is the bound.
+    nc = min(n_records, 1_000_000)
+    codecs = [(2, "snappy"), (3, "lz4"), (1, "gzip")]
+    try:
+        import pyarrow  # noqa: F401  (libzstd for the zstd sample)
+        codecs.append((4, "zstd"))
+    except ImportError:
+        pass
+    out["compressed"] = {}
+    for codec, name in codecs:
+        enc = codec if codec in (2, 3) else 0x100   # gzip / zstd: the real libraries over the uncompressed, patterned batches
+        cl = C.c_uint64()
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, None, 0, C.byref(cl))
+        cbuf = np.zeros(cl.value + 128, np.uint8)
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, cbuf.ctypes.data, cl.value, C.byref(cl))
+        if codec in (1, 4):
+            z = _recompress_batches(lib, cbuf[:cl.value].tobytes(), codec)
+            cbuf = np.zeros(len(z) + 128, np.uint8)
+            cbuf[:len(z)] = np.frombuffer(z, np.uint8)
+            cl.value = len(z)
+        leg(cbuf, cl.value, False, 1, name)                       # (the codec's kernels loaded, the inflate area allocated)
+        out["compressed"][name] = leg(cbuf, cl.value, False, passes, name)
     return out
 
 
