@@ -109,6 +109,10 @@ int64_t kta_snappy_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, ui
 int64_t kta_lz4_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 /* zstd (one or more frames) inflate on the host (the same code the device runs).  Returns the bytes produced or -1. */
 int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
+/* The same with the table layout of the device's wave-per-batch kernel, where the Huffman table lies over the
+ * sequence tables and what must outlive a block goes through a spill (csrc/kta_zstd.h, ZsWorkSmall): the host's
+ * execution of that text, for tests.  Returns the bytes produced or -1. */
+int64_t kta_zstd_inflate_host_small(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);
 /* gzip (one member) inflate on the host: the code the device runs, stage by stage (Huffman decoding into
  * literals + match tokens, then the copies).  Returns the bytes produced or -1. */
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap);

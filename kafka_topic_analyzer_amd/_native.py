@@ -157,6 +157,7 @@ SIGNATURES = {
     "kta_kafka_index_host": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(KtaKafkaBatchDesc), C.c_uint64, C.POINTER(KtaKafkaIndexStats)]),
     "kta_zstd_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
+    "kta_zstd_inflate_host_small": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_gzip_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_gzip_inflate_lane_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "kta_lz4_inflate_host": (C.c_int64, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),

@@ -427,7 +427,8 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
     //     the counts, one symbol per lane; a cell finds its symbol by bisection);
     //   * cell i's state number is count(symbol) + the cells of that symbol below i: 64 cells at a time in ascending order,
     //     a lane counts its symbol among the lower lanes (64 readlanes) on top of what the chunks before left in w.next.
-    __device__ __forceinline__ bool build_fse(kta::ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
+    template <class W>
+    __device__ __forceinline__ bool build_fse(W &w, uint32_t *t, uint32_t log, uint32_t n_sym)
     {
         const uint32_t size = 1u << log, mask = size - 1u;
         __syncthreads();                                   // (w.norm was written lane-uniformly: every lane's writes are in)
@@ -521,7 +522,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     // more than 63 stores old) — kept, worth nothing measurable —, every match served from the ring (- 0.08 ms: the far
     // path is not it), the 256 bytes behind a literal run requested ahead and dealt with ds_bpermute (+ 0.16 ms: dropped).
     // What a batch costs is its ~ 50 k instructions at the ~ 11 cycles each that two waves per SIMD leave exposed; the
-    // copies are a third of them.  More waves — under 128 registers and 10 KiB of LDS a wave — is the way, not done.)
+    // copies are a third of them.  More waves — under 128 registers and 10 KiB of LDS a wave — was the way: kafka_zstd_inflate_coop.)
 
     __device__ __forceinline__ void put(uint64_t i, uint8_t v)
     {
@@ -595,10 +596,23 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
         }
         op += len;
     }
+    // The tables of the work struct (LDS) to and from the batch's spill (global): every lane moves the same words both ways,
+    // so what it reads back is what it wrote itself.  (Rare: a frame of several blocks; kta_zstd.h, ZsWorkSmall.)
+    __device__ __forceinline__ void spill_words(uint32_t *plain, const uint32_t *work, uint32_t n)
+    {
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) plain[i] = work[i];
+    }
+    __device__ __forceinline__ void unspill_words(uint32_t *work, const uint32_t *plain, uint32_t n)
+    {
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) work[i] = plain[i];
+        __syncthreads();
+    }
     // the Huffman streams of a literals section, one lane each, straight from memory (a lane on its own cannot
     // use the wave's window); the decoded literals are read back by all lanes (lit_buf)
-    template <class S>
-    __device__ __forceinline__ bool huf_streams(const kta::ZsWork &w, S &src, uint32_t streams, const uint64_t at[4],
+    template <class W, class S>
+    __device__ __forceinline__ bool huf_streams(const W &w, S &src, uint32_t streams, const uint64_t at[4],
                                                 const uint64_t n[4], const uint64_t count[4], uint8_t *out)
     {
         const uint64_t my_at = lane == 0 ? at[0] : (lane == 1 ? at[1] : (lane == 2 ? at[2] : at[3]));
@@ -616,7 +630,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
 };
 
 template <uint32_t kZsRing>
-__device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches, kta::ZsWork *s_w,
+__device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches, kta::ZsWorkSmall *s_w,
                                                   uint4 *s_win, uint8_t *s_ring)
 {
     const uint32_t lane = threadIdx.x;
@@ -626,11 +640,14 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
     if (!(d.flags & KTA_KB_ZSTD) || d.status) return;
     const uint64_t src0 = d.byte_off + KTA_KAFKA_BATCH_HEADER, n = (uint64_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER;
     const uint64_t cap = d.payload_end - d.payload_off;
-    const uint64_t scratch = ((d.payload_end + 63) & ~63ull) + kZstdWorkBytes;   // the literals of a Huffman-coded section
+    const uint64_t spill = (d.payload_end + 63) & ~63ull;                        // where the lane kernel has its tables
+    const uint64_t scratch = spill + kZstdWorkBytes;                             // the literals of a Huffman-coded section
+    static_assert(sizeof(kta::ZsSpill) <= kZstdWorkBytes, "the spill lies in the lane kernel's table space");
     const uint64_t lit_cap = d.scratch_end > scratch ? d.scratch_end - scratch : 0;
     ZsWaveSrc src{buffer, src0, src0 + n, s_win, kZsNoWindow, lane};
     ZsOutWave<kZsRing> out{buffer + d.payload_off, 0, s_ring, lane};
-    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, s_w, buffer + scratch, lit_cap);
+    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, s_w, buffer + scratch, lit_cap,
+                                             d.scratch_end >= scratch ? reinterpret_cast<kta::ZsSpill *>(buffer + spill) : nullptr);
     if (lane == 0) {
         if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
         else descs[b].payload_end = d.payload_off + (uint64_t)got;   // the slice was sized by a bound
@@ -639,14 +656,20 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
 
 __global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
 {
-    // The wave is bound by latencies, so what the kernel delivers goes with the waves a CU holds, and those go with the LDS:
-    // tables 10 KiB + window 2 KiB + the mirror of the output's last bytes.  That mirror was 8 KiB (8 waves per CU) until
-    // round 6; matches that reach behind it read the output from L2, which costs little (every match served from the ring:
-    // - 3 %), so it is 1 KiB now — 12 waves per CU: 2.42 -> 1.95 ms for 1 M records in 16 KiB batches (4 KiB: 2.24, 2 KiB: 2.10).
-    constexpr uint32_t kRing = 1024;
-    __shared__ kta::ZsWork s_w;
+    // The wave is bound by latencies, so what the kernel delivers goes with the waves a CU holds, and those go with the LDS a
+    // wave takes (160 KiB a CU, handed out in 1280-byte pieces) until the registers bind at four waves per SIMD (120 VGPRs):
+    //   rounds 2-5  tables 10 KiB + window 2 KiB + an 8 KiB mirror of the output's last bytes   8 waves per CU   2.42 ms
+    //   round 6     the mirror 1 KiB: matches that reach behind it read the output from L2,
+    //               which costs little (every match served from the mirror: - 3 %)             12 (11)           1.95 ms
+    //   round 6     the Huffman table over the sequence tables (kta_zstd.h, ZsWorkSmall: a block
+    //               is done with the one before it builds the others; 6 KiB of tables), which
+    //               leaves room for a 2 KiB mirror in 8 pieces = 10 240 bytes                     16               1.56 ms
+    // for 1 M records in 16 KiB batches, 96 MB compressed (1 KiB mirror with the small tables: 1.60 ms).
+    constexpr uint32_t kRing = 2048;
+    __shared__ kta::ZsWorkSmall s_w;
     __shared__ uint4 s_win[kZsWin / 16];
     __shared__ uint8_t s_ring[kRing];
+    static_assert(sizeof(kta::ZsWorkSmall) + kZsWin + kRing <= 10240, "sixteen waves per CU");
     zstd_inflate_wave<kRing>(buffer, descs, n_batches, &s_w, s_win, s_ring);
 }
 
@@ -1309,6 +1332,18 @@ int64_t kta_zstd_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint
     if (!kta::zstd_scan(src, n, &bound, &lit)) return -1;
     std::vector<uint8_t> scratch(sizeof(kta::ZsWork) + lit + 64);
     return kta::zstd_inflate(src, n, dst, cap, reinterpret_cast<kta::ZsWork *>(scratch.data()), scratch.data() + sizeof(kta::ZsWork), lit);
+}
+
+int64_t kta_zstd_inflate_host_small(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)
+{
+    if (!src || (!dst && cap)) return -1;
+    uint64_t bound = 0, lit = 0;
+    if (!kta::zstd_scan(src, n, &bound, &lit)) return -1;
+    std::vector<uint8_t> scratch(lit + 64);
+    kta::ZsWorkSmall w;
+    kta::ZsSpill spill;
+    memset(&spill, 0xA5, sizeof(spill));                 // (nothing may be read from it that was not put there)
+    return kta::zstd_inflate_small(src, n, dst, cap, &w, &spill, scratch.data(), lit);
 }
 
 int64_t kta_gzip_inflate_host(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap)

@@ -46,6 +46,7 @@ constexpr uint32_t ZS_BLOCK_MAX = 128u << 10;
 // Per-batch scratch of the decoder (plain memory: global on the device).  FSE entries are
 // symbol | nbits << 8 | base << 16; Huffman entries symbol | nbits << 8.
 struct ZsWork {
+    static constexpr bool kHufShares = false;
     uint32_t ll[1 << 9], of[1 << 8], ml[1 << 9];
     uint32_t wfse[1 << 6];     // FSE table of the Huffman weights
     uint16_t huf[1 << 11];
@@ -55,7 +56,35 @@ struct ZsWork {
     uint8_t weights[256];
     uint8_t ll_log, of_log, ml_log, huf_log;
     uint8_t have_ll, have_of, have_ml, have_huf;
+    KTA_ZSTD_HD uint16_t *huf_table() { return huf; }
+    KTA_ZSTD_HD const uint16_t *huf_table() const { return huf; }
 };
+
+// The same scratch where it is scarce (the wave kernel's LDS: what a wave needs there decides how many waves a CU holds,
+// and the waves are what the kernel's rate goes with).  A block is done with its Huffman table — the literals are all
+// decoded — before it builds or uses its sequence tables, so the 4 KiB table lies over them; what has to outlive that
+// goes through a ZsSpill in plain memory (zs_block): the sequence tables of the block before (a "repeat" mode may name
+// them) around the literals of a Huffman-coded block, the Huffman table for a later block that brings no tree.  A frame
+// of one block — a Kafka batch of the usual size — never spills.
+struct ZsWorkSmall {
+    static constexpr bool kHufShares = true;
+    uint32_t ll[1 << 9], of[1 << 8], ml[1 << 9];      // contiguous: seq_words() of them
+    uint32_t wfse[1 << 6];
+    int16_t norm[64];
+    uint16_t next[64];
+    uint16_t first[64];
+    uint8_t weights[256];
+    uint8_t ll_log, of_log, ml_log, huf_log;
+    uint8_t have_ll, have_of, have_ml, have_huf;
+    KTA_ZSTD_HD uint16_t *huf_table() { return reinterpret_cast<uint16_t *>(ll); }
+    KTA_ZSTD_HD const uint16_t *huf_table() const { return reinterpret_cast<const uint16_t *>(ll); }
+};
+
+struct ZsSpill {
+    uint32_t seq[(1 << 9) + (1 << 8) + (1 << 9)];      // ll, of, ml as they lie in the work struct
+    uint32_t huf[1 << 10];                             // the Huffman table (2^11 entries of 16 bits)
+};
+static_assert(sizeof(ZsSpill::seq) >= sizeof(ZsSpill::huf), "the Huffman table lies inside the sequence tables");
 
 KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
 {
@@ -165,8 +194,8 @@ KTA_ZSTD_HD uint64_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
 
 // ---- FSE ----------------------------------------------------------------------------------------------------
 // Reads a table description (normalized counts) into w.norm; returns the accuracy log, 0 on error.
-template <class S>
-KTA_ZSTD_HD uint32_t zs_read_norm(S &src, ZsFwd &f, ZsWork &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
+template <class W, class S>
+KTA_ZSTD_HD uint32_t zs_read_norm(S &src, ZsFwd &f, W &w, uint32_t max_log, uint32_t max_sym, uint32_t *n_sym)
 {
     const uint32_t log = 5 + zs_fwd(src, f, 4);
     if (f.bad || log > max_log) return 0;
@@ -204,8 +233,8 @@ KTA_ZSTD_HD uint32_t zs_read_norm(S &src, ZsFwd &f, ZsWork &w, uint32_t max_log,
 }
 
 // Spreads w.norm[0 .. n_sym) into the decoding table `t` of 1 << log entries.
-template <class S>
-KTA_ZSTD_HD bool zs_build_fse(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym)
+template <class W, class S>
+KTA_ZSTD_HD bool zs_build_fse(S &src, W &w, uint32_t *t, uint32_t log, uint32_t n_sym)
 {
     const uint32_t size = 1u << log, mask = size - 1u;
     uint32_t high = size;
@@ -239,13 +268,13 @@ KTA_ZSTD_HD bool zs_build_fse(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint
 // A source may bring its own way of building the table — the wave source does (kta_kafka.hip: all 64 lanes at it; the loops
 // above are ~2 500 dependent LDS round trips for three tables of 2^9 cells when every lane of a wave walks them alike) —;
 // every other source takes the loops above, which are the format's own words (RFC 8878 4.1.1).
-template <class S>
-KTA_ZSTD_HD auto zs_build_fse_any(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym, int) -> decltype(src.build_fse(w, t, log, n_sym))
+template <class W, class S>
+KTA_ZSTD_HD auto zs_build_fse_any(S &src, W &w, uint32_t *t, uint32_t log, uint32_t n_sym, int) -> decltype(src.build_fse(w, t, log, n_sym))
 {
     return src.build_fse(w, t, log, n_sym);
 }
-template <class S>
-KTA_ZSTD_HD bool zs_build_fse_any(S &src, ZsWork &w, uint32_t *t, uint32_t log, uint32_t n_sym, long)
+template <class W, class S>
+KTA_ZSTD_HD bool zs_build_fse_any(S &src, W &w, uint32_t *t, uint32_t log, uint32_t n_sym, long)
 {
     return zs_build_fse(src, w, t, log, n_sym);
 }
@@ -253,7 +282,8 @@ KTA_ZSTD_HD bool zs_build_fse_any(S &src, ZsWork &w, uint32_t *t, uint32_t log, 
 KTA_ZSTD_HD void zs_build_rle(uint32_t *t, uint32_t sym) { t[0] = sym; }   // log 0: one state, no bits
 
 // Predefined distributions (RFC 8878 3.1.1.3.2.2.1-3): literal lengths and match lengths accuracy 6, offsets 5.
-KTA_ZSTD_HD void zs_default_norm(ZsWork &w, int which)
+template <class W>
+KTA_ZSTD_HD void zs_default_norm(W &w, int which)
 {
     if (which == 0) {   // literal length codes 0..35
         const int8_t d[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
@@ -269,8 +299,8 @@ KTA_ZSTD_HD void zs_default_norm(ZsWork &w, int which)
 }
 
 // One of the three sequence tables.  mode: 0 predefined, 1 RLE, 2 described, 3 repeat.
-template <class S>
-KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint64_t base, uint64_t n, uint64_t *pos)
+template <class W, class S>
+KTA_ZSTD_HD bool zs_seq_table(W &w, int which, uint32_t mode, S &src, uint64_t base, uint64_t n, uint64_t *pos)
 {
     uint32_t *t = which == 0 ? w.ll : (which == 1 ? w.of : w.ml);
     uint8_t &log = which == 0 ? w.ll_log : (which == 1 ? w.of_log : w.ml_log);
@@ -304,8 +334,8 @@ KTA_ZSTD_HD bool zs_seq_table(ZsWork &w, int which, uint32_t mode, S &src, uint6
 
 // ---- Huffman ------------------------------------------------------------------------------------------------
 // Tree description at p[0 .. n): fills w.huf / w.huf_log; returns the bytes consumed, 0 on error.
-template <class S>
-KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t n)
+template <class W, class S>
+KTA_ZSTD_HD uint64_t zs_read_huffman(W &w, S &src, uint64_t base, uint64_t n)
 {
     if (n < 1) return 0;
     const uint32_t hb = src.byte(base);
@@ -366,11 +396,12 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
             if (src.uni(w.weights[s]) == wt) at += 1u << (wt - 1);
     }
     if (at != (1u << log)) return 0;
+    uint16_t *huf = w.huf_table();
     for (uint32_t s = 0; s < n_w; s++) {
         const uint32_t wt = src.uni(w.weights[s]);
         if (!wt) continue;
         const uint32_t len = 1u << (wt - 1), nb = log + 1 - wt;
-        for (uint32_t i = 0; i < len; i++) w.huf[rank_start[wt] + i] = (uint16_t)(s | (nb << 8));
+        for (uint32_t i = 0; i < len; i++) huf[rank_start[wt] + i] = (uint16_t)(s | (nb << 8));
         rank_start[wt] += len;
     }
     w.huf_log = (uint8_t)log;
@@ -378,16 +409,17 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(ZsWork &w, S &src, uint64_t base, uint64_t 
     return used;
 }
 
-template <class S>
-KTA_ZSTD_HD bool zs_huf_stream(const ZsWork &w, S &src, uint64_t base, uint64_t n, uint8_t *out, uint64_t count)
+template <class W, class S>
+KTA_ZSTD_HD bool zs_huf_stream(const W &w, S &src, uint64_t base, uint64_t n, uint8_t *out, uint64_t count)
 {
     ZsBack b;
     if (!zs_back_init(src, b, base, n)) return false;
     const uint32_t log = w.huf_log, mask = (1u << log) - 1u;
+    const uint16_t *huf = w.huf_table();
     uint32_t state = (uint32_t)zs_back(src, b, log);
     for (uint64_t i = 0; i < count; i++) {
         if (b.off <= -(int64_t)log) return false;    // more symbols wanted than the stream holds
-        const uint32_t e = w.huf[state], nb = e >> 8;
+        const uint32_t e = huf[state], nb = e >> 8;
         out[i] = (uint8_t)e;
         state = ((state << nb) | (uint32_t)zs_back(src, b, nb)) & mask;
     }
@@ -476,10 +508,13 @@ struct ZsOutMem {
         for (; k < len; k++) dst[op + k] = dst[op - dist + k];
         op += len;
     }
+    // a ZsWorkSmall's tables to and from their ZsSpill
+    KTA_ZSTD_HD void spill_words(uint32_t *plain, const uint32_t *work, uint32_t n) { for (uint32_t i = 0; i < n; i++) plain[i] = work[i]; }
+    KTA_ZSTD_HD void unspill_words(uint32_t *work, const uint32_t *plain, uint32_t n) { for (uint32_t i = 0; i < n; i++) work[i] = plain[i]; }
     // the Huffman streams of a literals section (1 or 4; stream i: n[i] bytes at at[i], count[i] symbols, to
     // out + the counts before it): one after the other
-    template <class S>
-    KTA_ZSTD_HD bool huf_streams(const ZsWork &w, S &src, uint32_t streams, const uint64_t at[4], const uint64_t n[4],
+    template <class W, class S>
+    KTA_ZSTD_HD bool huf_streams(const W &w, S &src, uint32_t streams, const uint64_t at[4], const uint64_t n[4],
                                  const uint64_t count[4], uint8_t *out)
     {
         uint64_t done = 0;
@@ -514,9 +549,10 @@ KTA_ZSTD_HD bool zs_put_literals(ZsLits &l, S &src, O &out, uint64_t cnt)
 
 // One compressed block: the bytes [base, base + n) of src, appended through `out`.  `cap`: room of the whole
 // output; `frame_start`: output position where the frame began (offsets may not reach before it).
-template <class S, class O>
-KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, uint64_t cap, uint64_t frame_start,
-                          uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap)
+// `spill`, `last` (the frame's last block): see ZsWorkSmall — a work struct with a table of its own never looks at them.
+template <class W, class S, class O>
+KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint64_t cap, uint64_t frame_start,
+                          uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap, ZsSpill *spill, bool last)
 {
     const uint64_t block_start = out.op;
     uint32_t type, regen, comp, streams;
@@ -534,14 +570,20 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
         lit_rle = (uint8_t)src.byte(base + pos++);
     } else {                                          // Huffman coded (2) / with the previous tree (3)
         if (pos + comp > n || regen > lit_cap) return false;
+        if (type == 3 && !w.have_huf) return false;
+        bool seq_out = false;                         // the sequence tables wait in the spill while the Huffman table is in their place
+        if (W::kHufShares) {
+            if (!spill) return false;                 // (a batch without scratch has no Huffman-coded literals to decode into either)
+            seq_out = (w.have_ll | w.have_of | w.have_ml) != 0;
+            if (seq_out) out.spill_words(spill->seq, w.ll, (uint32_t)(sizeof(spill->seq) / 4));
+            if (type == 3) out.unspill_words(reinterpret_cast<uint32_t *>(w.huf_table()), spill->huf, (uint32_t)(sizeof(spill->huf) / 4));
+        }
         uint64_t q = base + pos, qn = comp;
         if (type == 2) {
             const uint64_t used = zs_read_huffman(w, src, q, qn);
             if (!used) return false;
             q += used;
             qn -= used;
-        } else if (!w.have_huf) {
-            return false;
         }
         uint64_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
         if (streams == 4) {
@@ -564,6 +606,10 @@ KTA_ZSTD_HD bool zs_block(ZsWork &w, S &src, uint64_t base, uint64_t n, O &out, 
             count[3] = regen - 3 * each;
         }
         if (!out.huf_streams(w, src, streams, at, len, count, lit_buf)) return false;
+        if (W::kHufShares) {
+            if (type == 2 && !last) out.spill_words(spill->huf, reinterpret_cast<const uint32_t *>(w.huf_table()), (uint32_t)(sizeof(spill->huf) / 4));
+            if (seq_out) out.unspill_words(w.ll, spill->seq, (uint32_t)(sizeof(spill->seq) / 4));
+        }
         pos += comp;
     }
     // sequences section
@@ -743,8 +789,8 @@ KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64
 
 // Inflates the frames of one batch payload — the bytes [0, n) of src — through `out` (room for cap bytes).
 // `lit`: scratch of at least the size zstd_scan reported.  Returns the bytes produced or -1.
-template <class S, class O>
-KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, ZsWork *w, uint8_t *lit, uint64_t lit_cap)
+template <class W, class S, class O>
+KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, W *w, uint8_t *lit, uint64_t lit_cap, ZsSpill *spill = nullptr)
 {
     uint64_t pos = 0;
     if (n == 0) return -1;
@@ -771,7 +817,7 @@ KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, ZsW
                 pos += 1;
             } else {
                 if (pos + size > n) return -1;
-                if (!zs_block(*w, src, pos, size, out, cap, frame_start, rep, lit, lit_cap)) return -1;
+                if (!zs_block(*w, src, pos, size, out, cap, frame_start, rep, lit, lit_cap, spill, (h & 1) != 0)) return -1;
                 pos += size;
             }
             if (h & 1) break;
@@ -792,6 +838,15 @@ KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, u
     ZsMem s{src};
     ZsOutMem o{dst, 0};
     return zstd_inflate_t(s, n, o, cap, w, lit, lit_cap);
+}
+
+// ... the same with the small work struct and its spill: the host's execution of what the wave kernel runs
+KTA_ZSTD_HD int64_t zstd_inflate_small(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWorkSmall *w, ZsSpill *spill,
+                                       uint8_t *lit, uint64_t lit_cap)
+{
+    ZsMem s{src};
+    ZsOutMem o{dst, 0};
+    return zstd_inflate_t(s, n, o, cap, w, lit, lit_cap, spill);
 }
 
 }  // namespace kta

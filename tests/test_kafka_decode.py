@@ -622,10 +622,17 @@ def test_zstd_inflate_host_against_libzstd():
     cases = _library_cases() + [bytes(rng.integers(0, 16, size=400000, dtype=np.uint8)),
                                 b"".join(bytes([int(x)]) * int(y) for x, y in zip(rng.integers(0, 256, 3000), rng.integers(1, 300, 3000)))]
 
+    spilled = {"treeless": 0, "repeat_after_huffman": 0}
+
     def check(comp, d):
-        out = C2.create_string_buffer(len(d) + 1)
-        assert lib.kta_zstd_inflate_host(comp, len(comp), out, len(d)) == len(d), (len(d), len(comp))
-        assert out.raw[:len(d)] == d
+        # both table layouts: a Huffman table of its own (host, lane kernel) and the one that lies over the sequence
+        # tables and spills what outlives a block (the wave kernel's: kta_zstd.h, ZsWorkSmall)
+        for fn in (lib.kta_zstd_inflate_host, lib.kta_zstd_inflate_host_small):
+            out = C2.create_string_buffer(len(d) + 1)
+            assert fn(comp, len(comp), out, len(d)) == len(d), (len(d), len(comp))
+            assert out.raw[:len(d)] == d
+        for k, v in _zstd_spill_paths(comp).items():
+            spilled[k] += v
 
     for d in cases:
         for level in (-5, 1, 3, 9, 19, 22):
@@ -636,6 +643,9 @@ def test_zstd_inflate_host_against_libzstd():
             o.flush()
             o.write(d[len(d) // 2:])
         check(sink.getvalue().to_pybytes(), d)
+    # the frames above take both ways through the spill: a block without a tree after one with, and a Huffman-coded
+    # block whose sequences repeat the tables of the block before
+    assert spilled["treeless"] > 20 and spilled["repeat_after_huffman"] > 20, spilled
     d = cases[6]
     good = pa.Codec("zstd", compression_level=3).compress(d, asbytes=True)
     check(good + good, d + d)                                  # concatenated frames
@@ -650,8 +660,48 @@ def test_zstd_inflate_host_against_libzstd():
         guard = C2.create_string_buffer(len(d) + 64)
         got = lib.kta_zstd_inflate_host(bytes(bad), len(bad), guard, len(d))
         assert -1 <= got <= len(d) and guard.raw[len(d):] == bytes(64)
+        guard2 = C2.create_string_buffer(len(d) + 64)
+        assert lib.kta_zstd_inflate_host_small(bytes(bad), len(bad), guard2, len(d)) == got      # both layouts: the same verdict
+        assert got < 0 or guard2.raw == guard.raw
         refused += got == -1
     assert refused > 100
+
+
+def _zstd_spill_paths(comp):
+    """Walks the block headers of zstd frames (RFC 8878 3.1.1) and counts the blocks that make a decoder whose Huffman
+    table shares its place with the sequence tables go through its spill: literals coded with the tree of an earlier
+    block, and Huffman-coded literals in a block whose sequences repeat a table of the block before."""
+    n = {"treeless": 0, "repeat_after_huffman": 0}
+    pos = 0
+    while pos + 6 <= len(comp):
+        fhd = comp[pos + 4]
+        fcs, single, did = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+        pos += 5 + (0 if single else 1) + (0, 1, 2, 4)[did] + ((1, 2, 4, 8)[fcs] if (fcs or single) else 0)
+        while True:
+            h = int.from_bytes(comp[pos:pos + 3], "little")
+            pos += 3
+            btype, size = (h >> 1) & 3, h >> 3
+            if btype == 2:
+                b = comp[pos:pos + size]
+                lt, sf = b[0] & 3, (b[0] >> 2) & 3
+                if lt < 2:
+                    regen = b[0] >> 3 if sf in (0, 2) else ((b[0] >> 4) | (b[1] << 4) if sf == 1 else (b[0] >> 4) | (b[1] << 4) | (b[2] << 12))
+                    q = (1, 2, 1, 3)[sf] + (regen if lt == 0 else 1)
+                else:
+                    v = int.from_bytes(b[0:5], "little") >> 4
+                    bits, hdr = ((10, 3), (10, 3), (14, 4), (18, 5))[sf]
+                    q = hdr + ((v >> bits) & ((1 << bits) - 1))
+                    n["treeless"] += lt == 3
+                n_seq = b[q]
+                q += 1 if n_seq < 128 else (2 if n_seq < 255 else 3)
+                if n_seq and lt >= 2:
+                    modes = b[q]
+                    n["repeat_after_huffman"] += 3 in (modes >> 6, (modes >> 4) & 3, (modes >> 2) & 3)
+            pos += 1 if btype == 1 else size
+            if h & 1:
+                break
+        pos += 4 if fhd & 4 else 0
+    return n
 
 
 def _library_cases():
@@ -801,6 +851,12 @@ def test_device_gzip_and_zstd_copy_paths():
               "lz4-indep"]
     blob = b"".join(K.encode_batch(10 * i, recs, 1_600_000_000_000 + i, compression=c) for i, c in enumerate(codecs))
     want, _ = kafka_decode(blob, 1)
+    # the zstd batches (the level 19 one) have blocks without a tree of their own and Huffman-coded blocks that repeat sequence tables: the
+    # wave kernel's Huffman table lies over its sequence tables, and these are the blocks that go through its spill
+    rc, descs, _ = index_host(blob, 1)
+    assert rc == N.KTA_OK
+    paths = [_zstd_spill_paths(blob[d.byte_off + 61:d.byte_off + d.batch_bytes]) for d in descs[:len(codecs)] if d.flags & 32]
+    assert len(paths) == 3 and sum(p["treeless"] for p in paths) > 3 and sum(p["repeat_after_huffman"] for p in paths) > 3, paths
     for variant in (0, 1):
         with kta.HipMetricHandler(2, now=NOW) as h:
             h._check(N.load().kta_kafka_set_variant(h._ctx, variant))
