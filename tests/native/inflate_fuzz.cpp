@@ -40,10 +40,18 @@ int64_t run(const std::string &codec, const std::vector<uint8_t> &in, uint64_t c
         uint64_t bound = 0, lit = 0;
         if (!kta::zstd_scan(src, in.size(), &bound, &lit)) got = -1;
         else {
-            kta::ZsWork *w = (kta::ZsWork *)malloc(sizeof(kta::ZsWork));
             uint8_t *l = (uint8_t *)malloc(lit ? lit : 1);        // exactly what the scan asked for
-            got = kta::zstd_inflate(src, in.size(), dst, cap, w, l, lit);
-            free(w);
+            if (rnd() & 1) {                                      // the wave kernel's table layout: Huffman table over the sequence tables
+                kta::ZsWorkSmall *w = (kta::ZsWorkSmall *)malloc(sizeof(kta::ZsWorkSmall));
+                kta::ZsSpill *sp = (kta::ZsSpill *)malloc(sizeof(kta::ZsSpill));
+                got = kta::zstd_inflate_small(src, in.size(), dst, cap, w, sp, l, lit);
+                free(w);
+                free(sp);
+            } else {
+                kta::ZsWork *w = (kta::ZsWork *)malloc(sizeof(kta::ZsWork));
+                got = kta::zstd_inflate(src, in.size(), dst, cap, w, l, lit);
+                free(w);
+            }
             free(l);
         }
     } else if (codec == "gzip2") {                                // the two-stage form: tokens in an exact-size block too
