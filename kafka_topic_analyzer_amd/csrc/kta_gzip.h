@@ -439,6 +439,10 @@ constexpr uint32_t GZ2_W_DTAB = 848;     // 64
 constexpr uint32_t GZ2_WORK = 912;
 
 KTA_GZIP_HD uint64_t gz_token_bound(uint64_t out) { return out / 3 + out / 255 + 1; }
+// The wave tokenizer (kta_gzip_wave.h) closes the literal run of each of its 64 segments with a token of its own, once per
+// region it decodes (a block, or a 7 KiB window's half of one): room for that many more in a member of `clen` compressed
+// bytes.  (A member of more regions than this — many tiny blocks — is left to the lane tokenizer, which needs none.)
+KTA_GZIP_HD uint64_t gz_closing_tokens(uint64_t clen) { return 64 * (2 + clen / 2048); }
 
 struct GzTokens {
     uint32_t *tok;

@@ -73,6 +73,7 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 }
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>
+#include "kta_gzip_wave.h"     // gzip_tokenize_wave: stage 1 of the gzip inflate, one wave per batch
 
 // Walk one batch.  WRITE = false: only total the key bytes.  Returns false if the records overrun
 // the batch (corrupt / truncated batch).
@@ -206,7 +207,7 @@ constexpr uint32_t kGzTokLanes = 8;
 constexpr uint32_t kLzRing = 16384, kLzChunk = 4096;
 
 template <uint32_t L>
-__global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+__global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches, int only_left)
 {
     __shared__ uint16_t s_work[kta::GZ2_WORK * L];
     __shared__ uint32_t s_win[kta::GZ_WIN / 4 * L];            // the lanes' windows on their streams
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_ka
     const bool has_tokens = d.scratch_end >= scratch + 16;          // (an empty member has none and needs none)
     if (cap && !has_tokens) { descs[b].status = KTA_KB_BAD_FRAMING; return; }
     uint32_t *tok = reinterpret_cast<uint32_t *>(buffer + scratch);
+    if (only_left && has_tokens && tok[0] != kGwNotDone) return;    // kafka_gzip_tokenize_wave has done this one
     uint64_t n_tok = 0;
     kta::GzBitsWin bits;
     bits.win = s_win + threadIdx.x;
@@ -228,6 +230,14 @@ __global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_ka
                                            has_tokens ? (d.scratch_end - scratch - 8) / 4 : 0, &n_tok, s_work + threadIdx.x, L);
     if (got < 0 || (uint64_t)got != cap) descs[b].status = KTA_KB_BAD_FRAMING;   // the trailer told the size
     else if (has_tokens) tok[0] = (uint32_t)n_tok;
+}
+
+// Stage 1 with one WAVE per batch (kta_gzip_wave.h): the block's symbols decoded by 64 lanes from speculative starts that
+// synchronise.  What it leaves (kGwNotDone in the token count) kafka_gzip_tokenize<L> does afterwards.
+__global__ __launch_bounds__(64) KTA_WAVES_PER_EU(4, 8) void kafka_gzip_tokenize_wave(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+{
+    __shared__ GwShared s_gw;
+    gzip_tokenize_wave(s_gw, buffer, descs, n_batches);
 }
 
 // The last kLzRing bytes of one batch's output, mirrored in LDS and moved in chunks (one wave; see above).
@@ -1233,7 +1243,7 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
             }
             uint64_t scratch = 0;
             if (codec == 1 && inflated > 0 && inflated <= (int64_t)kMaxBatchInflate)
-                scratch = 8 + 4 * kta::gz_token_bound((uint64_t)inflated);      // the match tokens of the two-stage inflate
+                scratch = 8 + 4 * (kta::gz_token_bound((uint64_t)inflated) + kta::gz_closing_tokens(total - KTA_KAFKA_BATCH_HEADER));   // the tokens of the two-stage inflate
             if (codec == 4) {
                 uint64_t bound = 0, lit = 0;
                 if (kta::zstd_scan(bytes + pos + KTA_KAFKA_BATCH_HEADER, total - KTA_KAFKA_BATCH_HEADER, &bound, &lit)) {
@@ -1590,8 +1600,14 @@ int kta_kafka_decode_device(kta_ctx *ctx, const uint8_t *blob_device, uint64_t b
             lane_codecs |= KTA_KB_SNAPPY | KTA_KB_LZ4;
         }
         if (any_gzip && st->variant != 1) {   // Huffman decoding one lane per batch, then the copies one wave per batch
+#ifndef KTA_GZIP_LANE_STAGE1
+            hipLaunchKernelGGL(kafka_gzip_tokenize_wave, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, d_descs, n_batches);
+            const int only_left = 1;
+#else
+            const int only_left = 0;
+#endif
             hipLaunchKernelGGL((kafka_gzip_tokenize<kGzTokLanes>), dim3((uint32_t)((n_batches + kGzTokLanes - 1) / kGzTokLanes)),
-                               dim3(kGzTokLanes), 0, s, buf, d_descs, n_batches);
+                               dim3(kGzTokLanes), 0, s, buf, d_descs, n_batches, only_left);
             hipLaunchKernelGGL(kafka_gzip_apply, dim3((uint32_t)n_batches), dim3(64), 0, s, buf, d_descs, n_batches);
         } else if (any_gzip) {
             hipLaunchKernelGGL((kafka_gzip_inflate<kGzipLanes>), dim3((uint32_t)((n_batches + kGzipLanes - 1) / kGzipLanes)),

@@ -45,7 +45,7 @@ struct Dim3 {
     uint32_t x, y, z;
 };
 
-enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3, READLANE = 4 };
+enum Meeting : uint32_t { NONE = 0, BARRIER = 1, ANY = 2, SHFL_XOR = 3, READLANE = 4, BALLOT = 5, SHFL_UP = 6 };
 
 struct Lane {
     ucontext_t ctx;
@@ -102,6 +102,20 @@ template <class T> inline T shfl_xor(T v, int mask, int site)
     T r;
     memcpy(&r, &state().current->out, sizeof(T));
     return r;
+}
+
+// the lanes (of those still running) whose predicate holds
+inline uint64_t ballot(bool pred, int site)
+{
+    park(BALLOT, site, pred ? 1u : 0u, 0);
+    return state().current->out;
+}
+
+// lane - off's value; a lane below `off` (or whose source has finished) keeps its own
+inline uint32_t shfl_up(uint32_t v, uint32_t off, int site)
+{
+    park(SHFL_UP, site, v, off);
+    return (uint32_t)state().current->out;
 }
 
 // v_readlane: every lane takes lane `src`'s value (src is the same for all of them)
@@ -182,6 +196,16 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
                 for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done) { src = s.lanes[l].operand; break; }
                 const Lane &from = s.lanes[src % kLanes];
                 for (uint32_t l = 0; l < kLanes; l++) s.lanes[l].out = from.done ? 0 : from.in;
+            } else if (what == BALLOT) {
+                uint64_t r = 0;
+                for (uint32_t l = 0; l < kLanes; l++) if (!s.lanes[l].done && s.lanes[l].in) r |= 1ull << l;
+                for (uint32_t l = 0; l < kLanes; l++) s.lanes[l].out = r;
+            } else if (what == SHFL_UP) {
+                for (uint32_t l = 0; l < kLanes; l++) {
+                    const uint32_t off = s.lanes[l].operand;
+                    const bool own = l < off || s.lanes[l - off].done;
+                    s.lanes[l].out = own ? s.lanes[l].in : s.lanes[l - off].in;
+                }
             } else if (what == SHFL_XOR) {
                 for (uint32_t l = 0; l < kLanes; l++) {
                     const Lane &from = s.lanes[(l ^ s.lanes[l].operand) % kLanes];
@@ -201,6 +225,9 @@ inline const char *launch(uint32_t grid, int order, uint32_t seed, const std::fu
 #define __any(p) wave_emu::any((p), __LINE__)
 #define __shfl_xor(v, m) wave_emu::shfl_xor((v), (m), __LINE__)
 #define KTA_READLANE(v, l) wave_emu::readlane((uint32_t)(v), (l), __LINE__)
+#define KTA_BALLOT64(p) wave_emu::ballot((p), __LINE__)
+#define KTA_SHFL_UP(v, off) wave_emu::shfl_up((uint32_t)(v), (off), __LINE__)
+#define KTA_UNI(v) ((uint32_t)(v))
 
 // one OS thread: the atomics are plain operations
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
