@@ -44,13 +44,23 @@
 #define KTA_UNI(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #endif
 
-constexpr uint32_t kGwWinBytes = 7168;             // the LDS window on the stream: seven 16-byte units per lane
+#ifndef KTA_GW_WIN
+#define KTA_GW_WIN 7168
+#endif
+#ifndef KTA_GW_LBITS
+#define KTA_GW_LBITS 9
+#endif
+constexpr uint32_t kGwWinBytes = KTA_GW_WIN;       // the LDS window on the stream: seven 16-byte units per lane
 constexpr uint32_t kGwMarginBits = 128;            // a decoder never starts a symbol this close to the window's end
 constexpr uint32_t kGwHeaderBits = 8192;           // a block header (code lengths) is parsed with this much window ahead
-constexpr uint32_t kGwLBits = 9, kGwDBits = 6, kGwCBits = 7;
+constexpr uint32_t kGwLBits = KTA_GW_LBITS, kGwDBits = 6, kGwCBits = 7;
 constexpr uint32_t kGwNotDone = 0xFFFFFFFFu;       // token count word: this batch is the lane kernel's
 constexpr uint32_t kGwMaxStream = 1u << 27;        // longer members: the lane kernel (bit positions stay far below 2^31)
 constexpr uint32_t kGwMinSegBits = 64;
+#ifndef KTA_GW_LITS
+#define KTA_GW_LITS 4
+#endif
+constexpr uint32_t kGwLitsPerRound = KTA_GW_LITS;
 
 struct GwShared {
     uint32_t win[kGwWinBytes / 4 + 8];             // + 8 words: a peek reads the word of its bit and the next
@@ -91,12 +101,17 @@ __device__ __forceinline__ void gw_load_window(GwShared &sh, GwWindow &w, uint32
     __syncthreads();
 }
 
-// the stream's bits from p on: at least 33 of them (p inside the window, kGwMarginBits before its end at most)
-__device__ __forceinline__ uint64_t gw_peek(const GwShared &sh, int32_t wbit0, uint32_t p)
+// the stream's 32 bits from p on (p inside the window, kGwMarginBits before its end at most): a code and its extra bits are
+// at most 28 (a distance code of 15 bits with 13 extra bits)
+__device__ __forceinline__ uint32_t gw_peek(const GwShared &sh, int32_t wbit0, uint32_t p)
 {
     const uint32_t q = (uint32_t)((int32_t)p - wbit0), wd = q >> 5;
-    const uint64_t lo = sh.win[wd], hi = sh.win[wd + 1];
-    return (lo | (hi << 32)) >> (q & 31u);
+    const uint32_t lo = sh.win[wd], hi = sh.win[wd + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, q & 31u);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (q & 31u));
+#endif
 }
 
 __device__ __forceinline__ uint32_t gw_bitrev32(uint32_t v)
@@ -197,21 +212,33 @@ __device__ __forceinline__ GwBuilt gw_build(uint32_t lane, const uint8_t *lens, 
     return r;
 }
 
+// The limit | base words of the code lengths the lookup table does not resolve (PBITS + 1 .. 15), in registers: every lane
+// holds the same ones.
+template <uint32_t PBITS>
+struct GwLong {
+    uint32_t cw[15 - PBITS];
+    __device__ __forceinline__ void load(const uint32_t *code)
+    {
+#pragma unroll
+        for (uint32_t k = PBITS + 1; k <= 15; k++) cw[k - PBITS - 1] = KTA_UNI(code[k]);
+    }
+};
+
 // one symbol of a code through its lookup table; the canonical search over the longer lengths for what the table does not
 // resolve.  v: the stream's bits (>= 15 real or zeros).  Returns the length, 0 if the bits are no code; the symbol -> *sym.
 template <uint32_t PBITS>
-__device__ __forceinline__ uint32_t gw_symbol(uint64_t v, const uint16_t *tab, const uint16_t *syms, uint32_t n_syms, const uint32_t *code,
+__device__ __forceinline__ uint32_t gw_symbol(uint32_t v, const uint16_t *tab, const uint16_t *syms, uint32_t n_syms, const GwLong<PBITS> &lg,
                                               uint32_t *sym)
 {
-    const uint32_t e = tab[(uint32_t)v & ((1u << PBITS) - 1u)];
+    const uint32_t e = tab[v & ((1u << PBITS) - 1u)];
     uint32_t l = e & 15u;
     *sym = e >> 4;
     if (!l) {
-        const uint32_t rev = gw_rev15((uint32_t)v & 0x7FFFu);
+        const uint32_t rev = gw_rev15(v & 0x7FFFu);
         int32_t idx = 0;
 #pragma unroll
         for (uint32_t k = 15; k > PBITS; k--) {
-            const uint32_t cw = code[k];
+            const uint32_t cw = lg.cw[k - PBITS - 1];
             if (rev < (cw & 0xFFFFu)) {
                 l = k;
                 idx = (int32_t)(int16_t)(cw >> 16) + (int32_t)(rev >> (15 - k));
@@ -232,28 +259,41 @@ struct GwSeg {
 
 // Decodes the symbols that begin in [p, limit).  WRITE: literals to dst[op ..], tokens to tok[ti ..] (what the counting
 // decode of the same range announced), matches checked against the output (dist <= op, room up to cap).
+// A round of the loop: up to kGwLitsPerRound literals, then the symbol that is none, if one came up.  (One symbol of either kind
+// per round pays for the match's ~ 50 instructions whenever one of the 64 lanes has one — nearly every round, though few of the
+// symbols are matches; an inner loop that takes literals as long as they come makes the wave wait, round after round, for
+// the lane with the longest run: 1.12 -> 1.84 ms.)
 template <bool WRITE>
 __device__ __forceinline__ GwSeg gw_decode_segment(const GwShared &sh, int32_t wbit0, uint32_t p, uint32_t limit, uint32_t n_lsym,
-                                                   uint32_t n_dsym, uint8_t *dst, uint32_t op, uint32_t cap, uint32_t *tok, uint32_t ti)
+                                                   uint32_t n_dsym, const GwLong<kGwLBits> &llong, const GwLong<kGwDBits> &dlong, uint8_t *dst,
+                                                   uint32_t op, uint32_t cap, uint32_t *tok, uint32_t ti)
 {
     GwSeg r{p, 0, 0, 0};
     const uint32_t op0 = op;
     uint32_t run = 0;
     while (p < limit) {
-        uint64_t v = gw_peek(sh, wbit0, p);
-        uint32_t sym;
-        uint32_t l = gw_symbol<kGwLBits>(v, sh.ltab, sh.lsym, n_lsym, sh.lcode, &sym);
-        if (!l) { r.flags = 2; break; }
-        if (sym < 256) {
-            if (WRITE) {
-                if (op >= cap) { r.flags = 2; break; }
-                dst[op] = (uint8_t)sym;
+        uint32_t v = 0, sym = 0, l = 0;
+        bool lit = true;                               // no symbol that is not a literal waits in (sym, l, v)
+#pragma unroll
+        for (uint32_t j = 0; j < kGwLitsPerRound; j++) {
+            if (lit && p < limit) {
+                v = gw_peek(sh, wbit0, p);
+                l = gw_symbol<kGwLBits>(v, sh.ltab, sh.lsym, n_lsym, llong, &sym);
+                lit = l != 0 && sym < 256;
+                if (WRITE && lit && op >= cap) {
+                    lit = false;
+                    l = 0;
+                }
+                if (lit) {
+                    if (WRITE) dst[op] = (uint8_t)sym;
+                    p += l;
+                    op++;
+                    run++;
+                }
             }
-            p += l;
-            op++;
-            run++;
-            continue;
         }
+        if (lit) continue;
+        if (!l) { r.flags = 2; break; }
         p += l;
         if (sym == 256) { r.flags = 1; break; }
         if (sym > 285) { r.flags = 2; break; }
@@ -268,11 +308,11 @@ __device__ __forceinline__ GwSeg gw_decode_segment(const GwShared &sh, int32_t w
             eb = 0;
             len = 258u;
         }
-        len += (uint32_t)v & ((1u << eb) - 1u);
+        len += v & ((1u << eb) - 1u);
         p += eb;
-        v = gw_peek(sh, wbit0, p);                     // a distance code and its extra bits: <= 28
+        v = gw_peek(sh, wbit0, p);
         uint32_t ds;
-        l = gw_symbol<kGwDBits>(v, sh.dtab, sh.dsym, n_dsym, sh.dcode, &ds);
+        l = gw_symbol<kGwDBits>(v, sh.dtab, sh.dsym, n_dsym, dlong, &ds);
         if (!l || ds > 29) { r.flags = 2; break; }
         v >>= l;
         uint32_t eb2 = 0, dist = 1u + ds;
@@ -280,7 +320,7 @@ __device__ __forceinline__ GwSeg gw_decode_segment(const GwShared &sh, int32_t w
             eb2 = (ds >> 1) - 1u;                      // 1..13 extra bits
             dist = 1u + ((2u + (ds & 1u)) << eb2);
         }
-        dist += (uint32_t)v & ((1u << eb2) - 1u);
+        dist += v & ((1u << eb2) - 1u);
         p += l + eb2;
         const uint32_t esc = run / 255u;
         if (WRITE) {
@@ -337,8 +377,8 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
         const uint32_t wend = (uint32_t)(w.wbit0 + (int32_t)(8 * kGwWinBytes));        // stream bit behind the window
         if (wend < nbits && p + kGwHeaderBits + kGwMarginBits > wend) gw_load_window(sh, w, p);
         if (p + 3 > nbits) return kGwNotDone;
-        uint64_t v = gw_peek(sh, w.wbit0, p);
-        last_block = KTA_UNI((uint32_t)v & 1u);
+        uint32_t v = gw_peek(sh, w.wbit0, p);
+        last_block = KTA_UNI(v & 1u);
         const uint32_t type = KTA_UNI(((uint32_t)v >> 1) & 3u);
         p += 3;
         uint32_t nlen, ndist;
@@ -363,7 +403,7 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
             __syncthreads();
             if (lane < ncode) {
                 const uint32_t order = lane < 3 ? 16u + lane : (lane == 3 ? 0u : ((lane & 1u) ? 8u - ((lane - 3u) >> 1) : 7u + ((lane - 2u) >> 1)));
-                sh.lens[order] = (uint8_t)((uint32_t)gw_peek(sh, w.wbit0, p + 3 * lane) & 7u);
+                sh.lens[order] = (uint8_t)(gw_peek(sh, w.wbit0, p + 3 * lane) & 7u);
             }
             p += 3 * ncode;
             __syncthreads();
@@ -417,6 +457,10 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
             if (type == 2 && (lb.left < 0 || (lb.left > 0 && lb.short01 != nlen))) return kGwNotDone;
             // ---- the block's symbols: region after region of the window ----
             const uint32_t n_lsym = lb.used, n_dsym = db.used;
+            GwLong<kGwLBits> llong;
+            GwLong<kGwDBits> dlong;
+            llong.load(sh.lcode);
+            dlong.load(sh.dcode);
             bool eob = false;
             while (!eob) {
                 uint32_t wend2 = (uint32_t)(w.wbit0 + (int32_t)(8 * kGwWinBytes));
@@ -437,7 +481,7 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
 #endif
                 uint32_t from = b;
                 GwSeg r{b, 0, 0, 0};
-                if (active) r = gw_decode_segment<false>(sh, w.wbit0, from, lim, n_lsym, n_dsym, nullptr, 0, 0, nullptr, 0);
+                if (active) r = gw_decode_segment<false>(sh, w.wbit0, from, lim, n_lsym, n_dsym, llong, dlong, nullptr, 0, 0, nullptr, 0);
                 uint32_t K;                            // the lanes [0, K) are confirmed
                 for (;;) {
                     uint32_t prev_end = KTA_SHFL_UP(r.end, 1);
@@ -453,7 +497,7 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
 #endif
                     if (active && !linked) {
                         from = prev_end;
-                        r = gw_decode_segment<false>(sh, w.wbit0, from, lim, n_lsym, n_dsym, nullptr, 0, 0, nullptr, 0);
+                        r = gw_decode_segment<false>(sh, w.wbit0, from, lim, n_lsym, n_dsym, llong, dlong, nullptr, 0, 0, nullptr, 0);
                     }
                 }
                 K = KTA_UNI(K);
@@ -466,7 +510,7 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
                 const uint32_t my_ti = gw_scan_excl(lane, mine ? r.ntok : 0u, &tot_tok);
                 if (tot_out > cap - op || tot_tok > tok_cap - nt) return kGwNotDone;
                 GwSeg wr{0, 0, 0, 0};
-                if (mine) wr = gw_decode_segment<true>(sh, w.wbit0, from, lim, n_lsym, n_dsym, dst, op + my_op, cap, tok, nt + my_ti);
+                if (mine) wr = gw_decode_segment<true>(sh, w.wbit0, from, lim, n_lsym, n_dsym, llong, dlong, dst, op + my_op, cap, tok, nt + my_ti);
                 if (KTA_BALLOT64(mine && (wr.flags & 2u))) return kGwNotDone;         // a match that reaches before the output's first byte
                 op += tot_out;
                 nt += tot_tok;

@@ -191,20 +191,23 @@ __global__ __launch_bounds__(L) void kafka_gzip_inflate(uint8_t *buffer, kta_kaf
 }
 
 // ---- gzip inflate in two stages (csrc/kta_gzip.h) -----------------------------------------------------
-// Stage 1, kafka_gzip_tokenize: Huffman decoding is bit-serial inside a member, so one LANE per batch, L
-// batches per workgroup; the lookup tables of a lane (1.9 KiB) are in LDS, lane-interleaved.  Literals go
-// straight to their final bytes of the batch's slice, matches become tokens in the batch's scratch (the
-// host index placed it behind the slice: [u32 count, u32 0, tokens]).  Few lanes per wave on purpose: the
-// lanes of a wave sit in different branches (literal / match / table build) most of the time, so a wave
-// costs the sum of its lanes' paths, and the LDS tables bound the batches in flight per CU either way
-// (measured on 16 667 batches of 16 KiB: 8 lanes 4.41 ms, 16 lanes 4.71 ms for inflate + decode).
-// Stage 2, kafka_gzip_apply: one WAVE per batch executes the tokens.  The output is processed in 4 KiB
-// chunks through an LDS ring of the last 16 KiB: a chunk is loaded with its literals in place, the matches
+// Stage 1: Huffman decoding.  kafka_gzip_tokenize_wave (kta_gzip_wave.h; round 6) gives a batch to one WAVE, whose 64 lanes
+// decode a block's symbols from speculative starts that synchronise; what it leaves — stored blocks, streams it finds
+// malformed — kafka_gzip_tokenize<L> does afterwards: one LANE per batch, L batches per workgroup, the lookup tables of a lane
+// (1.9 KiB) in LDS, lane-interleaved.  Literals go straight to their final bytes of the batch's slice, matches become tokens in
+// the batch's scratch (the host index placed it behind the slice: [u32 count, u32 0, tokens]).  The lane kernel has few lanes
+// per wave on purpose: the lanes of a wave sit in different branches (literal / match / table build) most of the time, so a
+// wave costs the sum of its lanes' paths, and the LDS tables bound the batches in flight per CU either way (measured on
+// 16 667 batches of 16 KiB, when it was the only stage 1: 8 lanes 4.41 ms, 16 lanes 4.71 ms for inflate + decode).
+// Stage 2, kafka_gzip_apply: one WAVE per batch executes the tokens.  The output is processed in 2 KiB
+// chunks through an LDS ring of the last 4 KiB: a chunk is loaded with its literals in place, the matches
 // that start in it are copied 64 bytes per step inside LDS (a dependent step costs LDS latency, not a
 // memory round trip), and the chunk is written back in whole 16-byte units.  A match that reaches further
 // back than the ring reads the written-back output (behind a fence, past L1).
 constexpr uint32_t kGzTokLanes = 8;
-constexpr uint32_t kLzRing = 16384, kLzChunk = 4096;
+// (16 KiB / 4 KiB until round 6: ten waves per CU, each waiting on its own chain of LDS round trips — 0.67 ms for 16 667 batches
+// of 16 KiB; 8 KiB / 4 KiB 0.46; 4 KiB / 2 KiB 0.40: more waves, and the matches behind the ring read L2 at little cost)
+constexpr uint32_t kLzRing = 4096, kLzChunk = 2048;
 
 template <uint32_t L>
 __global__ __launch_bounds__(L) void kafka_gzip_tokenize(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches, int only_left)
@@ -251,18 +254,17 @@ struct LzWindow {
     __device__ __forceinline__ uint8_t *ring() const { return reinterpret_cast<uint8_t *>(ring4); }
     __device__ __forceinline__ void load(uint32_t at)           // chunk `at` (literals in place) -> ring
     {
-        static_assert(kLzChunk == 4096, "four 16-byte units per lane");
+        static_assert(kLzChunk % 1024 == 0 && kLzRing >= kLzChunk + 64, "whole 16-byte units per lane; the step before a chunk is in the ring");
         c0 = at;
         const uint32_t last = ((total + 15u) & ~15u) - 16u;      // last 16-byte unit of the slice (total > 0)
-        const uint32_t o0 = at + lane * 16u, o1 = o0 + 1024u, o2 = o0 + 2048u, o3 = o0 + 3072u;
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(dst + (o0 < last ? o0 : last));   // in flight together
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(dst + (o1 < last ? o1 : last));
-        const uint4 v2 = *reinterpret_cast<const uint4 *>(dst + (o2 < last ? o2 : last));
-        const uint4 v3 = *reinterpret_cast<const uint4 *>(dst + (o3 < last ? o3 : last));
-        ring4[(o0 & (kLzRing - 1)) >> 4] = v0;
-        ring4[(o1 & (kLzRing - 1)) >> 4] = v1;
-        ring4[(o2 & (kLzRing - 1)) >> 4] = v2;
-        ring4[(o3 & (kLzRing - 1)) >> 4] = v3;
+        uint4 v[kLzChunk / 1024];
+#pragma unroll
+        for (uint32_t k = 0; k < kLzChunk / 1024; k++) {           // in flight together
+            const uint32_t o = at + lane * 16u + k * 1024u;
+            v[k] = *reinterpret_cast<const uint4 *>(dst + (o < last ? o : last));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kLzChunk / 1024; k++) ring4[((at + lane * 16u + k * 1024u) & (kLzRing - 1)) >> 4] = v[k];
         __syncthreads();
     }
     __device__ __forceinline__ void advance()                   // write the chunk back, take the next one
