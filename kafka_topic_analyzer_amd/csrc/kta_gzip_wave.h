@@ -225,7 +225,9 @@ struct GwLong {
 };
 
 // one symbol of a code through its lookup table; the canonical search over the longer lengths for what the table does not
-// resolve.  v: the stream's bits (>= 15 real or zeros).  Returns the length, 0 if the bits are no code; the symbol -> *sym.
+// resolve.  (One literal in a hundred of the bench's batches has a code of 10 .. 13 bits, so one lane in 64 takes the search in
+// every other round; a second table for those codes — they fill the top of the 15-bit code space, 64 .. 96 entries at a
+// resolution of four strings — instead of the six compare-and-select steps was built and measured: 1.445 -> 1.433 ms, not kept.)  v: the stream's bits (>= 15 real or zeros).  Returns the length, 0 if the bits are no code; the symbol -> *sym.
 template <uint32_t PBITS>
 __device__ __forceinline__ uint32_t gw_symbol(uint32_t v, const uint16_t *tab, const uint16_t *syms, uint32_t n_syms, const GwLong<PBITS> &lg,
                                               uint32_t *sym)
@@ -409,39 +411,60 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
             __syncthreads();
             const GwBuilt cb = gw_build<kGwCBits, 7, 1>(lane, sh.lens, 19, sh.dsym, sh.ctab, nullptr);
             if (cb.left != 0) return kGwNotDone;      // (the lane kernel refuses an incomplete code-length code too)
-            // the code lengths, one after the other (run lengths refer to the one before): every lane alike
+            // The code lengths: a sequence of symbols of the code-length code (a length; "repeat the one before 3-6 times";
+            // "3-10 zeros"; "11-138 zeros"), each where the one before ends — walked by every lane alike that was ~ 150 rounds
+            // of two dependent LDS round trips, a quarter of the kernel's time.  So 64 bits at a time: lane j decodes the symbol
+            // that would begin at bit p + j, the chain of the real ones (0, then where each ends) is followed with readlanes,
+            // a prefix sum over the chain's lanes gives every symbol its place among the lengths, and "the one before" is
+            // the value of the nearest chain lane below that carries one.
             uint32_t i = 0, prev = 0;
             bool bad = false;
-            while (i < nlen + ndist) {
+            const uint32_t need = nlen + ndist;
+            uint8_t *vals = reinterpret_cast<uint8_t *>(sh.dsym);      // (the code-length code's symbols are done with)
+            while (i < need) {
                 if (p > nbits) { bad = true; break; }
-                v = gw_peek(sh, w.wbit0, p);
-                const uint32_t e = KTA_UNI(sh.ctab[(uint32_t)v & 127u]);
-                const uint32_t l = e & 15u, sym = e >> 4;
-                if (!l) { bad = true; break; }
-                p += l;
-                v >>= l;
-                if (sym < 16) {
-                    sh.lens[i++] = (uint8_t)sym;
-                    prev = sym;
-                    continue;
+                const uint32_t vj = gw_peek(sh, w.wbit0, p + lane);
+                const uint32_t e = sh.ctab[vj & 127u];
+                const uint32_t l = e & 15u, sym = e >> 4, x = vj >> l;
+                uint32_t adv = 0, cnt = 0;                 // bits the symbol takes (0: no symbol), lengths it stands for
+                if (l) {
+                    if (sym < 16) { adv = l; cnt = 1; }
+                    else if (sym == 16) { adv = l + 2; cnt = 3 + (x & 3u); }
+                    else if (sym == 17) { adv = l + 3; cnt = 3 + (x & 7u); }
+                    else { adv = l + 7; cnt = 11 + (x & 127u); }
                 }
-                uint32_t rep, fill = 0;
-                if (sym == 16) {
-                    if (i == 0) { bad = true; break; }
-                    fill = prev;
-                    rep = 3 + KTA_UNI((uint32_t)v & 3u);
-                    p += 2;
-                } else if (sym == 17) {
-                    rep = 3 + KTA_UNI((uint32_t)v & 7u);
-                    p += 3;
-                } else {
-                    rep = 11 + KTA_UNI((uint32_t)v & 127u);
-                    p += 7;
+                uint64_t chain = 0;
+                for (uint32_t j = 0; j < 64;) {
+                    chain |= 1ull << j;
+                    const uint32_t a = KTA_READLANE(adv, j);
+                    if (!a) break;                         // (an error if this symbol is one of those wanted: below)
+                    j += a;
                 }
-                if (i + rep > nlen + ndist) { bad = true; break; }
-                for (uint32_t k = 0; k < rep; k++) sh.lens[i + k] = (uint8_t)fill;
-                i += rep;
-                prev = fill;
+                const bool on = ((chain >> lane) & 1ull) != 0;
+                uint32_t total;
+                const uint32_t excl = gw_scan_excl(lane, on ? cnt : 0u, &total);
+                const uint32_t remaining = need - i;
+                const bool used = on && excl < remaining;
+                const bool err = used && (adv == 0 || cnt > remaining - excl || (sym == 16 && i + excl == 0));
+                if (KTA_BALLOT64(err)) { bad = true; break; }
+                // the nearest used lane at or below this one that carries a value (is no "repeat"): its number + 1, 0 if none
+                uint32_t src = used && sym != 16 ? lane + 1 : 0u;
+#pragma unroll
+                for (uint32_t off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = KTA_SHFL_UP(src, off);
+                    if (lane >= off && up > src) src = up;
+                }
+                __syncthreads();
+                vals[lane] = (uint8_t)(sym < 16 ? sym : 0u);
+                __syncthreads();
+                const uint32_t val = src ? (uint32_t)vals[src - 1] : prev;
+                if (used)
+                    for (uint32_t k = 0; k < cnt; k++) sh.lens[i + excl + k] = (uint8_t)val;
+                const uint64_t um = KTA_BALLOT64(used);    // (lane 0 at least: it is on the chain, and a length is wanted)
+                const uint32_t jl = 63u - (uint32_t)__builtin_clzll(um);
+                p += jl + KTA_READLANE(adv, jl);
+                i += KTA_READLANE(excl + cnt, jl);
+                prev = KTA_READLANE(val, jl);
             }
             if (bad || p > nbits) return kGwNotDone;
             __syncthreads();
