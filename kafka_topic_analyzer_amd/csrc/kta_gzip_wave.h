@@ -25,8 +25,8 @@
 // The compressed bytes come through an LDS window (7 KiB: the usual batch whole; a longer member in several windows), so do
 // the code tables, which all lanes share — one batch per wave — and build together (gw_build: ballots rank the symbols of
 // every code length, a lane fills its entries of the lookup table by decoding their index).  Everything a member may
-// hold that this kernel does not do itself — stored blocks, members of 128 MiB and more, a token area too small for the
-// extra closing tokens — and every stream it finds malformed is LEFT to the lane kernel, which runs afterwards over the
+// hold that this kernel does not do itself — members of 128 MiB and more, a token area too small for the extra closing
+// tokens — and every stream it finds malformed is LEFT to the lane kernel, which runs afterwards over the
 // batches marked kGwNotDone and gives the verdict: a batch this kernel finishes is one the lane kernel would have accepted
 // with the same bytes (the tests hold both against zlib and against each other on damaged streams).
 #pragma once
@@ -44,23 +44,16 @@
 #define KTA_UNI(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #endif
 
-#ifndef KTA_GW_WIN
-#define KTA_GW_WIN 7168
-#endif
-#ifndef KTA_GW_LBITS
-#define KTA_GW_LBITS 9
-#endif
-constexpr uint32_t kGwWinBytes = KTA_GW_WIN;       // the LDS window on the stream: seven 16-byte units per lane
+constexpr uint32_t kGwWinBytes = 7168;             // the LDS window on the stream: seven 16-byte units per lane
 constexpr uint32_t kGwMarginBits = 128;            // a decoder never starts a symbol this close to the window's end
 constexpr uint32_t kGwHeaderBits = 8192;           // a block header (code lengths) is parsed with this much window ahead
-constexpr uint32_t kGwLBits = KTA_GW_LBITS, kGwDBits = 6, kGwCBits = 7;
+// index bits of the lookup tables (literal/length, distance, code-length code).  (10 bits for the literal/length code — 1 KiB
+// more table, paid with a 6 KiB window, which the bench's 5-6.4 KB batches then need twice — measured slower: 1.92 -> 1.97 ms.)
+constexpr uint32_t kGwLBits = 9, kGwDBits = 6, kGwCBits = 7;
 constexpr uint32_t kGwNotDone = 0xFFFFFFFFu;       // token count word: this batch is the lane kernel's
 constexpr uint32_t kGwMaxStream = 1u << 27;        // longer members: the lane kernel (bit positions stay far below 2^31)
 constexpr uint32_t kGwMinSegBits = 64;
-#ifndef KTA_GW_LITS
-#define KTA_GW_LITS 4
-#endif
-constexpr uint32_t kGwLitsPerRound = KTA_GW_LITS;
+constexpr uint32_t kGwLitsPerRound = 4;            // (1: 1.63 ms, 2: 1.51, 4: 1.445, 8: 1.46 for 16 667 batches of 16 KiB, inflate + decode)
 
 struct GwShared {
     uint32_t win[kGwWinBytes / 4 + 8];             // + 8 words: a peek reads the word of its bit and the next
@@ -383,7 +376,7 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
         last_block = KTA_UNI(v & 1u);
         const uint32_t type = KTA_UNI(((uint32_t)v >> 1) & 3u);
         p += 3;
-        uint32_t nlen, ndist;
+        uint32_t nlen = 0, ndist = 0;
         if (type == 1) {                               // fixed codes (RFC 1951 3.2.6)
             nlen = 288;
             ndist = 30;
@@ -469,10 +462,24 @@ __device__ __forceinline__ uint32_t gw_tokenize_member(GwShared &sh, const uint8
             if (bad || p > nbits) return kGwNotDone;
             __syncthreads();
             if (sh.lens[256] == 0) return kGwNotDone; // no end-of-block code
+        } else if (type == 0) {                        // stored: LEN, ~LEN at the next byte boundary, then LEN bytes — literals
+            const uint32_t at = (p + 7u) & ~7u;
+            if (at + 32 > nbits) return kGwNotDone;
+            v = gw_peek(sh, w.wbit0, at);
+            const uint32_t len = KTA_UNI(v & 0xFFFFu), nlen16 = KTA_UNI(v >> 16);
+            const uint32_t esc = len / 255u, rest = len - esc * 255u, ntk = esc + (rest ? 1u : 0u);
+            if ((len ^ 0xFFFFu) != nlen16 || at + 32 + 8 * len > nbits || len > cap - op || ntk > tok_cap - nt) return kGwNotDone;
+            const uint8_t *from = buffer + w.g0 + ((at + 32) >> 3);
+            for (uint32_t k = lane; k < len; k += 64) dst[op + k] = from[k];
+            for (uint32_t k = lane; k < esc; k += 64) tok[nt + k] = 255u;
+            if (rest && lane == 0) tok[nt + esc] = rest;
+            op += len;
+            nt += ntk;
+            p = at + 32 + 8 * len;
         } else {
-            return kGwNotDone;                         // stored blocks (and the invalid type): the lane kernel's
+            return kGwNotDone;                         // the invalid type: the lane kernel says so
         }
-        {
+        if (type != 0) {
             // an incomplete code is legal only as a single 1-bit code (kta_gzip.h: gzip_tokenize)
             const GwBuilt db = gw_build<kGwDBits, 15, 1>(lane, sh.lens + nlen, ndist, sh.dsym, sh.dtab, sh.dcode);
             if (type == 2 && (db.left < 0 || (db.left > 0 && db.short01 != ndist))) return kGwNotDone;

@@ -107,10 +107,11 @@ def test_members_of_several_blocks_and_windows(emu):
     several times the 7 KiB window."""
     c = _cases()
     d = c["text"]
-    # Z_FULL_FLUSH / Z_SYNC_FLUSH end with an empty STORED block: not this kernel's
-    for flush in (zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH):
-        comp = gz(d[:20000], 6, flush_at=[5000], flush=flush)
-        assert run(emu, comp, 20000)[0] == LEFT
+    # Z_FULL_FLUSH / Z_SYNC_FLUSH end with an empty STORED block
+    for k, flush in enumerate((zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH)):
+        comp = gz(d, 6, flush_at=range(700, len(d), 9001), flush=flush)
+        r, out = run(emu, comp, len(d), shift=3 + k, order=ORDERS[k])
+        assert r >= 0 and out == d
     # Z_BLOCK closes the block without one
     for order in ORDERS:
         comp = gz(d, 6, flush_at=range(300, len(d), 4099), flush=zlib.Z_BLOCK)
@@ -124,12 +125,18 @@ def test_members_of_several_blocks_and_windows(emu):
 
 
 def test_what_the_wave_leaves_to_the_lane_kernel(emu):
-    """Stored blocks, a token area without room for the closing tokens, an output slice of the wrong size: left, not
-    mis-decoded — and nothing written behind the output."""
+    """A token area without room for the closing tokens, an output slice of the wrong size, a damaged stored block: left, not
+    mis-decoded — and nothing written behind the output.  (Stored blocks themselves — incompressible values, level 0, several
+    of 64 KiB in a row, between coded blocks — are this kernel's.)"""
     rng = np.random.default_rng(5)
-    noise = bytes(rng.integers(0, 256, 5000, dtype=np.uint8))
-    assert run(emu, gz(noise, 6), len(noise))[0] == LEFT             # incompressible: zlib stores it
-    assert run(emu, gz(noise, 0), len(noise))[0] == LEFT
+    noise = bytes(rng.integers(0, 256, 200000, dtype=np.uint8))
+    for k, (d, level) in enumerate([(noise[:5000], 6), (noise[:5000], 0), (noise, 0), (noise[:70000] + b"abc" * 9000 + noise[:3000], 6), (b"", 6)]):
+        comp = gz(d, level)
+        r, out = run(emu, comp, len(d), shift=k * 3, order=ORDERS[k % 3])
+        assert r >= 0 and out == d, k
+    comp = bytearray(gz(noise[:5000], 0))
+    comp[10 + 3] ^= 1                                                # LEN and ~LEN disagree
+    assert run(emu, bytes(comp), 5000)[0] == LEFT
     d = _cases()["text16k"]
     comp = gz(d, 6)
     r, out = run(emu, comp, len(d))
