@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KTA_ABI_VERSION 6   /* 6: kta_replay_messages, kta_handle_message_stats; the table state takes the fused pass; kta_kafka_set_variant takes 0, 1, 2, 10, 11 only (the other geometries went in round 5); 5: kta_set_fuse, kta_alive_pass_info; 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
+#define KTA_ABI_VERSION 6   /* 6: kta_replay_messages, kta_handle_message_stats, kta_zstd_inflate_host_small (kta_kafka.h); the table state takes the fused pass; kta_kafka_set_variant takes 0, 1, 2, 10, 11 only (the other geometries went in round 5); 5: kta_set_fuse, kta_alive_pass_info; 4: KTA_FLAG_ALIVE_TABLE, the default -c state is the bit set (submission order); 3: kta_comm_* / kta_exchange*, kta_result_vector is a snapshot; 2: kta_kafka_batch_desc.scratch_end */
 
 /* status codes */
 #define KTA_OK 0

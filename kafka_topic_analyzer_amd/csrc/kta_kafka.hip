@@ -257,14 +257,12 @@ struct LzWindow {
         static_assert(kLzChunk % 1024 == 0 && kLzRing >= kLzChunk + 64, "whole 16-byte units per lane; the step before a chunk is in the ring");
         c0 = at;
         const uint32_t last = ((total + 15u) & ~15u) - 16u;      // last 16-byte unit of the slice (total > 0)
-        uint4 v[kLzChunk / 1024];
-#pragma unroll
-        for (uint32_t k = 0; k < kLzChunk / 1024; k++) {           // in flight together
-            const uint32_t o = at + lane * 16u + k * 1024u;
-            v[k] = *reinterpret_cast<const uint4 *>(dst + (o < last ? o : last));
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kLzChunk / 1024; k++) ring4[((at + lane * 16u + k * 1024u) & (kLzRing - 1)) >> 4] = v[k];
+        static_assert(kLzChunk == 2048, "two 16-byte units per lane");
+        const uint32_t o0 = at + lane * 16u, o1 = o0 + 1024u;
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(dst + (o0 < last ? o0 : last));   // in flight together
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(dst + (o1 < last ? o1 : last));
+        ring4[(o0 & (kLzRing - 1)) >> 4] = v0;
+        ring4[(o1 & (kLzRing - 1)) >> 4] = v1;
         __syncthreads();
     }
     __device__ __forceinline__ void advance()                   // write the chunk back, take the next one
@@ -286,39 +284,27 @@ struct LzWindow {
             uint32_t n = c0 + kLzChunk - op;
             n = n < len ? n : len;
             const bool in_ring = op - dist + kLzRing >= c0 + kLzChunk;   // the whole source is in the ring
-            if (n > 64 && dist >= 64 && in_ring) {
-                // up to four steps whose sources are all final already (the copy does not reach into itself
-                // within them): their reads go out together, one LDS round trip instead of four
-                uint32_t m = n < 256 ? n : 256u;
-                m = dist < m ? dist : m;
-                uint8_t v[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t i = lane + 64 * k;
-                    v[k] = i < m ? ring()[(op - dist + i) & (kLzRing - 1)] : (uint8_t)0;
+            // The n bytes of the match in this chunk at once, 64 per step with no step waiting for another: byte i is the byte
+            // i mod dist of the `dist` bytes before op, and those are final.  (Until round 6 a step copied from what the step
+            // before had written — a chain of LDS round trips per match — behind ~ 45 scalar instructions of loop control, and
+            // the kernel was bound by the scalar unit's issue rate: 12 K scalar instructions per batch.)
+            const bool periodic = dist < n;
+            const float inv = periodic ? __frcp_rn((float)dist) * 0.99999976f : 0.0f;   // (a hair below 1 / dist: the quotient is never too big)
+            if (!in_ring) __threadfence_block();       // further back than the ring: written back already (kLzRing >= chunk + 64) —
+                                                       // the wave's own earlier stores have reached L2: a wait, no cache maintenance
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint32_t m = i;
+                if (periodic) {
+                    m = i - (uint32_t)((float)i * inv) * dist;
+                    m = m >= dist ? m - dist : m;
                 }
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t i = lane + 64 * k;
-                    if (i < m) ring()[(op + i) & (kLzRing - 1)] = v[k];
+                if (i < n) {
+                    const uint32_t s = op - dist + m;
+                    const uint8_t v = in_ring ? ring()[s & (kLzRing - 1)] : __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ring()[(op + i) & (kLzRing - 1)] = v;
                 }
-                op += m;
-                len -= m;
-                continue;
             }
-            n = n < 64 ? n : 64;
-            // byte i of the step: source index repeats with period `dist` when the copy overlaps itself
-            const uint32_t s = op - dist + (dist >= 64 ? lane : lane % dist);
-            uint8_t v = 0;
-            if (in_ring) {
-                if (lane < n) v = ring()[s & (kLzRing - 1)];
-            } else {                                               // further back: written back already (kLzRing >= chunk + 64)
-                // (workgroup scope: the wave's own earlier stores have reached L2 — a wait, no cache maintenance; the
-                // agent-scope fence that stood here until round 6 also wrote the L2 back and invalidated it, per far match)
-                __threadfence_block();
-                if (lane < n) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane < n) ring()[(op + lane) & (kLzRing - 1)] = v;
             op += n;
             len -= n;
         }

@@ -500,9 +500,10 @@ def test_host_index_sizes_compressed_batches():
             if d.flags & 32:   # zstd: the decoder's tables and literals follow the slice
                 assert d.scratch_end > ((d.payload_end + 63) & ~63) + 10000
                 run += (d.scratch_end - ((d.payload_end + 63) & ~63) + 63) & ~63
-            elif d.flags & 16:  # gzip: the match tokens of the two-stage inflate (count + out/3 + out/255 + 1 words)
-                out = d.payload_end - d.payload_off
-                assert d.scratch_end == ((d.payload_end + 63) & ~63) + 8 + 4 * (out // 3 + out // 255 + 1)
+            elif d.flags & 16:  # gzip: the tokens of the two-stage inflate (count + out/3 + out/255 + 1 words, + the closing
+                out = d.payload_end - d.payload_off     # tokens of the wave tokenizer's segments: kta_gzip.h, gz_closing_tokens)
+                clen = d.batch_bytes - 61
+                assert d.scratch_end == ((d.payload_end + 63) & ~63) + 8 + 4 * (out // 3 + out // 255 + 1 + 64 * (2 + clen // 2048))
                 run += (d.scratch_end - ((d.payload_end + 63) & ~63) + 63) & ~63
             else:
                 assert d.scratch_end == d.payload_end
