@@ -272,7 +272,8 @@ __device__ __forceinline__ GwSeg gw_decode_segment(const GwShared &sh, int32_t w
 #pragma unroll
         for (uint32_t j = 0; j < kGwLitsPerRound; j++) {
             if (lit && p < limit) {
-                v = gw_peek(sh, wbit0, p);
+                // (a peek brings 32 bits and a code is at most 15: every second literal finds its bits behind the one before)
+                v = (j & 1u) ? v >> l : gw_peek(sh, wbit0, p);
                 l = gw_symbol<kGwLBits>(v, sh.ltab, sh.lsym, n_lsym, llong, &sym);
                 lit = l != 0 && sym < 256;
                 if (WRITE && lit && op >= cap) {
@@ -292,7 +293,7 @@ __device__ __forceinline__ GwSeg gw_decode_segment(const GwShared &sh, int32_t w
         p += l;
         if (sym == 256) { r.flags = 1; break; }
         if (sym > 285) { r.flags = 2; break; }
-        v >>= l;
+        v = gw_peek(sh, wbit0, p);                     // the length's extra bits (<= 5)
         const uint32_t k = sym - 257u;                 // 0..28
         uint32_t eb = 0, len = 3u + k;                 // 257..264: 3..10
         if (k >= 8) {
