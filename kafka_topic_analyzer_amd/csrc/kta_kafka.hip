@@ -498,6 +498,15 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         if (lo >= hi) return 0;
         const uint64_t a0 = src0 + base + (uint64_t)lo, a1 = src0 + base + (uint64_t)hi - 1;
         if (a0 - wabs >= kZsWin || a1 - wabs >= kZsWin) fetch(a0, (uint32_t)(hi - lo));
+        if (hi - lo == 8) {
+            // all eight bytes inside the slice (every container of a sequence's fields but the stream's first): three aligned
+            // words and two funnel shifts, one LDS round trip — the byte-by-byte form below is eight of them behind 64-bit
+            // compares, ~ 150 instructions per container, and a sequence takes one or two
+            const uint32_t o = (uint32_t)(a0 - wabs), wd = o >> 2, sh = (o & 3u) * 8u;
+            const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win4);
+            const uint32_t x0 = w32[wd], x1 = w32[wd + 1], x2 = w32[wd + 2 < kZsWin / 4 ? wd + 2 : kZsWin / 4 - 1];   // (x2 counts only if sh > 0: then wd + 2 is inside)
+            return (uint64_t)uni(__builtin_amdgcn_alignbit(x1, x0, sh)) | ((uint64_t)uni(__builtin_amdgcn_alignbit(x2, x1, sh)) << 32);
+        }
         const uint8_t *w = reinterpret_cast<const uint8_t *>(win4) + (src0 + base - wabs);   // (may wrap: indexed with k below)
         uint64_t c = 0;
 #pragma unroll

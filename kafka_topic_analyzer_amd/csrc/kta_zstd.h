@@ -192,6 +192,27 @@ KTA_ZSTD_HD uint64_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
     return (b.cont >> (uint32_t)(at - b.lo)) & ((1ull << nb) - 1ull);
 }
 
+// The same reader for a caller that reads several fields in a row (a sequence: up to 31 + 16 + 16 extra bits, then up to
+// 9 + 9 + 8 state bits): zs_back_fill loads the container so that the unread bits end in its top byte — 57 of them at least
+// are then in it (zeros below the stream's first byte) —, zs_back_take hands out the next nb without looking: the caller
+// counts, and fills again before the 57 run out.  (zs_back's own checks — is the field inside the container, 64-bit
+// compares and all — were ~ 25 scalar instructions per field, six fields per sequence; the wave kernel is bound by the
+// scalar unit's issue rate.)
+template <class S>
+KTA_ZSTD_HD void zs_back_fill(S &src, ZsBack &b)
+{
+    const int64_t byte_lo = ((b.off + 7) >> 3) - 8;
+    b.cont = src.le64(b.base, b.n, byte_lo);
+    b.lo = byte_lo * 8;
+    b.loaded = true;
+}
+
+KTA_ZSTD_HD uint32_t zs_back_take(ZsBack &b, uint32_t nb)   // nb <= 31; at most 57 bits between two fills
+{
+    b.off -= (int64_t)nb;
+    return (uint32_t)(b.cont >> ((uint32_t)(b.off - b.lo) & 63u)) & ((1u << nb) - 1u);   // (& 63: nb = 0 right after a fill)
+}
+
 // ---- FSE ----------------------------------------------------------------------------------------------------
 // Reads a table description (normalized counts) into w.norm; returns the accuracy log, 0 on error.
 template <class W, class S>
@@ -636,39 +657,33 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint6
         if (pos >= n) return false;
         ZsBack b;
         if (!zs_back_init(src, b, base + pos, n - pos)) return false;
-        uint32_t sl = (uint32_t)zs_back(src, b, w.ll_log), so = (uint32_t)zs_back(src, b, w.of_log), sm = (uint32_t)zs_back(src, b, w.ml_log);
+        // Match length and literal length codes: baseline | extra bits << 24 (RFC 8878 3.1.1.3.2.1.1).  Match lengths: codes
+        // 0..31 are 3 + code, then baselines 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, ... with 1, 1, 1, 1, 2, 2, 3, 3,
+        // 4, 4, 5, 7, 8, ..., 16 extra bits; literal lengths: 0..15 are the code, then 16, 18, 20, 22, 24, 28, 32, 40, 48, 64,
+        // 128, ..., 65536 with 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, ..., 16.  (Tables, not the closed forms: on the device a
+        // scalar load each instead of ~ 30 scalar compare-and-select instructions.)
+        static constexpr uint32_t kMl[53] = {0x3, 0x4, 0x5, 0x6, 0x7, 0x8, 0x9, 0xA, 0xB, 0xC, 0xD, 0xE, 0xF, 0x10, 0x11, 0x12, 0x13, 0x14, 0x15, 0x16, 0x17, 0x18, 0x19, 0x1A, 0x1B, 0x1C, 0x1D, 0x1E, 0x1F, 0x20, 0x21, 0x22, 0x1000023, 0x1000025, 0x1000027, 0x1000029, 0x200002B, 0x200002F, 0x3000033, 0x300003B, 0x4000043, 0x4000053, 0x5000063, 0x7000083, 0x8000103, 0x9000203, 0xA000403, 0xB000803, 0xC001003, 0xD002003, 0xE004003, 0xF008003, 0x10010003};
+        static constexpr uint32_t kLl[36] = {0x0, 0x1, 0x2, 0x3, 0x4, 0x5, 0x6, 0x7, 0x8, 0x9, 0xA, 0xB, 0xC, 0xD, 0xE, 0xF, 0x1000010, 0x1000012, 0x1000014, 0x1000016, 0x2000018, 0x200001C, 0x3000020, 0x3000028, 0x4000030, 0x6000040, 0x7000080, 0x8000100, 0x9000200, 0xA000400, 0xB000800, 0xC001000, 0xD002000, 0xE004000, 0xF008000, 0x10010000};
+        zs_back_fill(src, b);
+        uint32_t sl = zs_back_take(b, w.ll_log), so = zs_back_take(b, w.of_log), sm = zs_back_take(b, w.ml_log);    // <= 26 bits
         if (b.off < 0) return false;
         for (uint32_t i = 0; i < n_seq; i++) {
             const uint32_t el = src.uni(w.ll[sl]), eo = src.uni(w.of[so]), em = src.uni(w.ml[sm]);
             const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
-            if (oc > 31) return false;
-            const uint64_t ov = (1ull << oc) + zs_back(src, b, oc);
-            // match length: codes 0..31 are 3 + code; then baselines with 1,1,1,1,2,2,3,3,4,4,5,7,8,...,16 extra bits
-            uint32_t ml_base, ml_bits;
-            if (mc < 32) { ml_base = mc + 3; ml_bits = 0; }
-            else {
-                if (mc > 52) return false;
-                const uint32_t j = mc - 32;           // 0..20
-                // extra bits 1,1,1,1,2,2,3,3,4,4,5,7,8,...,16; baselines 35,37,39,41,43,47,51,59,67,83,99,131,259,...
-                ml_bits = j < 4 ? 1u : (j < 10 ? (j >> 1) : (j == 10 ? 5u : j - 4u));
-                ml_base = j < 4 ? 35u + 2u * j : (j < 6 ? 43u + 4u * (j - 4) : (j < 8 ? 51u + 8u * (j - 6) : (j < 10 ? 67u + 16u * (j - 8)
-                        : (j == 10 ? 99u : (1u << (j - 4u)) + 3u))));
-            }
-            const uint64_t mlen = ml_base + zs_back(src, b, ml_bits);
-            uint32_t ll_base, ll_bits;
-            if (lc < 16) { ll_base = lc; ll_bits = 0; }
-            else {
-                if (lc > 35) return false;
-                const uint32_t j = lc - 16;           // 0..19
-                // extra bits 1,1,1,1,2,2,3,3,4,6,7,...,16; baselines 16,18,20,22,24,28,32,40,48,64,128,...,65536
-                ll_bits = j < 4 ? 1u : (j < 8 ? (j >> 1) : (j == 8 ? 4u : j - 3u));
-                ll_base = j < 4 ? 16u + 2u * j : (j < 6 ? 24u + 4u * (j - 4) : (j < 8 ? 32u + 8u * (j - 6) : (j == 8 ? 48u : 1u << (j - 3u))));
-            }
-            const uint64_t llen = ll_base + zs_back(src, b, ll_bits);
+            if (oc > 31 || mc > 52 || lc > 35) return false;
+            const uint32_t mt = kMl[mc], lt = kLl[lc];
+            const uint32_t ml_bits = mt >> 24, ll_bits = lt >> 24;
+            // the sequence's fields: offset (<= 31 bits), match length (<= 16), literal length (<= 16), then the three states
+            // (<= 9 + 9 + 8); a fill is good for 57
+            zs_back_fill(src, b);
+            const uint64_t ov = (1ull << oc) + zs_back_take(b, oc);
+            const uint32_t mlen = (mt & 0xFFFFFFu) + zs_back_take(b, ml_bits);
+            if (oc + ml_bits + ll_bits + 26 > 57) zs_back_fill(src, b);
+            const uint32_t llen = (lt & 0xFFFFFFu) + zs_back_take(b, ll_bits);
             if (i + 1 < n_seq) {                      // state updates: literal length, match length, offset
-                sl = (el >> 16) + (uint32_t)zs_back(src, b, (el >> 8) & 0xFF);
-                sm = (em >> 16) + (uint32_t)zs_back(src, b, (em >> 8) & 0xFF);
-                so = (eo >> 16) + (uint32_t)zs_back(src, b, (eo >> 8) & 0xFF);
+                sl = (el >> 16) + zs_back_take(b, (el >> 8) & 0xFF);
+                sm = (em >> 16) + zs_back_take(b, (em >> 8) & 0xFF);
+                so = (eo >> 16) + zs_back_take(b, (eo >> 8) & 0xFF);
             }
             if (b.off < 0) return false;
             uint64_t offset;
