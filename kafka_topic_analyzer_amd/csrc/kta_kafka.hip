@@ -683,10 +683,14 @@ __global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, k
 // ---- Snappy inflate, wave-cooperative: one wave per compressed batch -------------------------------
 // Elements are inherently sequential, but each one moves up to 64 bytes: the wave parses the tag
 // uniformly (compressed stream staged in an LDS window, so a tag costs LDS latency, not an L2 round
-// trip) and executes every literal / copy with all 64 lanes.  The last 16 KiB of output are mirrored in
+// trip) and executes every literal / copy with all 64 lanes.  The last 2 KiB of output are mirrored in
 // an LDS ring: a copy whose offset reaches further back reads the global output instead (after a fence).
-constexpr uint32_t kSnapWin = 4096;
-constexpr uint32_t kSnapRing = 16384;
+// (Rounds 2-5: a 4 KiB window and a 16 KiB ring — 20 KiB of LDS, eight waves per CU, each waiting on its own chain of round
+// trips: Snappy 1.59 ms, LZ4 1.27 ms for 16 667 batches of 16 KiB.  Round 6, after the zstd and gzip kernels had shown what the
+// occupancy is worth and how little the copies behind the ring cost: 4 KiB / 4 KiB 0.94 / 0.82 ms, 4 / 2 0.83 / 0.74,
+// 2 KiB / 2 KiB — 32 waves per CU, all a CU holds — 0.79 / 0.70 ms, 2 / 1 0.82 / 0.72.)
+constexpr uint32_t kSnapWin = 2048;
+constexpr uint32_t kSnapRing = 2048;
 
 __global__ __launch_bounds__(64) void kafka_snappy_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs,
                                                                  uint64_t n_batches)
