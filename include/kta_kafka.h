@@ -173,7 +173,9 @@ int kta_kafka_encode_synth_host(const struct kta_synth_spec *spec, uint64_t firs
 /* As above with a codec: 0 = none, 2 = Snappy (bare block), 3 = LZ4 (one frame of linked 64 KiB blocks),
  * both from a small greedy compressor; values are then filled with a 24-byte periodic pseudo-random
  * pattern so that the stream has real copies.  0x100 = uncompressed batches with that same value
- * pattern (what a caller compresses with another codec, e.g. bench.py with zlib for gzip). */
+ * pattern (what a caller compresses with another codec, e.g. bench.py with zlib for gzip).  | 0x200: the
+ * values are words, numbers and punctuation instead (skewed bytes and many short copies, as JSON
+ * payloads have them: Huffman-coded literals in zstd, long code tables in gzip). */
 int kta_kafka_encode_synth_host_ex(const struct kta_synth_spec *spec, uint64_t first, uint64_t n,
                                    uint32_t records_per_batch, int codec, uint8_t *out, uint64_t cap,
                                    uint64_t *len);

@@ -3,6 +3,7 @@
 // them, for benchmarks, fixtures and topic files; plus the host CRC-32C.  Nothing here is on the
 // measured path: the consumer side (index, inflate, CRC check, decode) is csrc/kta_kafka.hip.
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -166,6 +167,7 @@ extern "C" int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64
                                    int codec, uint8_t *out, uint64_t cap, uint64_t *len)
 {
     const bool patterned = codec != 0;   // 0x100: uncompressed, but with the value pattern of the compressed forms
+    const bool text = (codec & 0x200) != 0;   // 0x200: values of words and punctuation (skewed bytes, many short copies) instead
     codec &= 0xFF;
     if (!spec || !len || records_per_batch == 0 || (codec != 0 && codec != 2 && codec != 3)) return KTA_ERR_INVALID;
     std::vector<uint8_t> packed;
@@ -205,7 +207,27 @@ extern "C" int kta_kafka_encode_synth_host_ex(const kta_synth_spec *spec, uint64
                 q += klb;
             }
             memcpy(q, vh, vhn);                             // value bytes + the 0 headersCount are already zero
-            if (patterned && vlb) {                         // a periodic pattern: compressible, but with real copies
+            if (text && vlb) {                              // words from a small vocabulary, numbers, JSON-like punctuation
+                static const char *const words[32] = {"user", "action", "click", "view", "purchase", "session", "timestamp", "amount",
+                                                      "currency", "EUR", "USD", "status", "ok", "error", "retry", "region", "eu-west",
+                                                      "us-east", "device", "mobile", "desktop", "browser", "version", "payload", "items",
+                                                      "price", "quantity", "id", "name", "true", "false", "null"};
+                uint64_t h = kta_mix64(first + b0 + j);
+                size_t x = 0;
+                while (x < vlb) {
+                    h = kta_mix64(h);
+                    const char *w = words[h & 31];
+                    if (((h >> 5) & 7) == 0) {              // a number now and then
+                        char num[24];
+                        const int nn = snprintf(num, sizeof num, "%u", (unsigned)((h >> 8) % 100000));
+                        for (int c = 0; c < nn && x < vlb; c++) q[vhn + x++] = (uint8_t)num[c];
+                    } else {
+                        for (; *w && x < vlb; w++) q[vhn + x++] = (uint8_t)*w;
+                    }
+                    static const char seps[8] = {'"', ':', ',', ' ', '{', '}', '"', '_'};
+                    if (x < vlb) q[vhn + x++] = (uint8_t)seps[(h >> 24) & 7];
+                }
+            } else if (patterned && vlb) {                  // a periodic pattern: compressible, but with real copies
                 const uint64_t seed = kta_mix64(first + b0 + j);
                 for (size_t x = 0; x < vlb; x++) q[vhn + x] = (uint8_t)(kta_mix64(seed + (x % 24)) >> 7);
             }

@@ -74,6 +74,7 @@ int decode_variant_for(int forced, uint64_t n_batches, uint64_t blob_len)
 
 #include "kta_decode_coop.h"   // Reader, read_varlong, pin, kafka_decode_coop<G, W, R>
 #include "kta_gzip_wave.h"     // gzip_tokenize_wave: stage 1 of the gzip inflate, one wave per batch
+#include "kta_zstd_huf_wave.h" // zh_streams: the Huffman-coded literals of a zstd block, by the whole wave
 
 // Walk one batch.  WRITE = false: only total the key bytes.  Returns false if the records overrun
 // the batch (corrupt / truncated batch).
@@ -616,23 +617,17 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
         for (uint32_t i = lane; i < n; i += 64) work[i] = plain[i];
         __syncthreads();
     }
-    // the Huffman streams of a literals section, one lane each, straight from memory (a lane on its own cannot
-    // use the wave's window); the decoded literals are read back by all lanes (lit_buf)
+    // the Huffman streams of a literals section: all 64 lanes on one stream at a time, through the source's LDS window (which
+    // the sequences' reader does not need yet; kta_zstd_huf_wave.h); the decoded literals are read back by all lanes (lit_buf)
     template <class W, class S>
     __device__ __forceinline__ bool huf_streams(const W &w, S &src, uint32_t streams, const uint64_t at[4],
                                                 const uint64_t n[4], const uint64_t count[4], uint8_t *out)
     {
-        const uint64_t my_at = lane == 0 ? at[0] : (lane == 1 ? at[1] : (lane == 2 ? at[2] : at[3]));
-        const uint64_t my_n = lane == 0 ? n[0] : (lane == 1 ? n[1] : (lane == 2 ? n[2] : n[3]));
-        const uint64_t my_count = lane == 0 ? count[0] : (lane == 1 ? count[1] : (lane == 2 ? count[2] : count[3]));
-        const uint64_t my_out = lane == 0 ? 0 : (lane == 1 ? count[0] : (lane == 2 ? count[0] + count[1] : count[0] + count[1] + count[2]));
-        bool ok = true;
-        if (lane < streams) {
-            kta::ZsMem m{src.memory()};
-            ok = kta::zs_huf_stream(w, m, my_at, my_n, out + my_out, my_count);
-        }
+        const bool ok = zh_streams(reinterpret_cast<uint32_t *>(src.win4), src.buffer, src.src0, streams, at, n, count, w.huf_table(),
+                                   w.huf_log, out, lane);
+        src.wabs = kZsNoWindow;                            // (the window holds a stream's bytes now)
         __threadfence_block();                             // (the lanes' literals are read back by the wave's other lanes, past L1)
-        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+        return ok;
     }
 };
 

@@ -26,6 +26,8 @@ ap.add_argument("--records", type=int, default=1_000_000)
 ap.add_argument("--rpb", type=int, default=60)
 ap.add_argument("--codecs", default="gzip,zstd")
 ap.add_argument("--variants", default="0,1")
+ap.add_argument("--values", default="pattern", choices=["pattern", "text"],
+                help="value bytes: the 24-byte periodic pattern of bench.py, or words / numbers / punctuation (JSON-like)")
 args = ap.parse_args()
 lib = N.load()
 spec, _ = kta.synth_preset("c4")
@@ -35,7 +37,7 @@ ref = kta.synth_fill_host(spec, 0, min(nc, 1 << 16))
 h = kta.HipMetricHandler(256)
 for name in args.codecs.split(","):
     codec = ids[name]
-    enc = codec if codec in (2, 3) else 0x100
+    enc = (codec if codec in (2, 3) else 0x100) | (0x200 if args.values == "text" else 0)
     ln = C.c_uint64()
     lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc, None, 0, C.byref(ln))
     cbuf = np.zeros(ln.value + 128, np.uint8)
@@ -67,7 +69,7 @@ for name in args.codecs.split(","):
         h._check(lib.kta_kafka_decode_device(h._ctx, blob.partition, ln.value, descs, st.n_batches, nc, C.byref(out), None, C.byref(bad)))
         cols = h.download_batch(out, len(ref["partition"]))
         ok = bad.value == 0 and all(np.array_equal(cols[k], ref[k]) for k in ("key_len", "val_len", "ts_ms"))
-        print(json.dumps({"codec": name, "variant": variant, "batches": int(st.n_batches),
+        print(json.dumps({"codec": name, "values": args.values, "variant": variant, "batches": int(st.n_batches),
                           "compressed_bytes": int(ln.value), "inflate_area": int(st.inflate_bytes), "ms": round(best * 1e3, 3),
                           "compressed_GBps": round(ln.value / best / 1e9, 2), "ok": bool(ok), "bad_batches": int(bad.value)}), flush=True)
     h._check(lib.kta_kafka_set_variant(h._ctx, 0))
