@@ -537,72 +537,87 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
         dst[op + i] = v;
         ring[(op + i) & (kZsRing - 1)] = v;
     }
+    // (The copies count in 32 bits from pointers formed once per call: a batch of JSON-like values runs ~ 1 400 sequences of a
+    // few bytes each through these, at 16 waves per CU the kernel is bound by the instructions it issues, and 64-bit index
+    // arithmetic per byte-lane was a third of them.)
+    template <bool PAST_L1>
+    __device__ __forceinline__ void lit_from(const uint8_t *p, uint64_t cnt64)
+    {
+        uint8_t *d = dst + op;
+        const uint32_t cnt = (uint32_t)cnt64, ro = (uint32_t)op;        // (a block's literals: <= 128 KiB)
+        if (cnt <= 64) {                                               // the usual run: one step
+            if (lane < cnt) {
+                const uint8_t v = PAST_L1 ? __hip_atomic_load(p + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[lane];
+                d[lane] = v;
+                ring[(ro + lane) & (kZsRing - 1)] = v;
+            }
+        } else {
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 256) {               // four loads in flight per lane
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + lane + 64 * k;
+                    v[k] = i < cnt ? (PAST_L1 ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i]) : (uint8_t)0;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + lane + 64 * k;
+                    if (i < cnt) {
+                        d[i] = v[k];
+                        ring[(ro + i) & (kZsRing - 1)] = v[k];
+                    }
+                }
+            }
+        }
+        op += cnt64;
+    }
     template <class S>
-    __device__ __forceinline__ void lit_src(S &src, uint64_t at, uint64_t cnt)
-    {
-        const uint8_t *p = src.memory() + at;
-        for (uint64_t i0 = 0; i0 < cnt; i0 += 256) {                 // four loads in flight per lane
-            uint8_t v[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t i = i0 + lane + 64 * k;
-                v[k] = i < cnt ? p[i] : (uint8_t)0;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t i = i0 + lane + 64 * k;
-                if (i < cnt) put(i, v[k]);
-            }
-        }
-        op += cnt;
-    }
-    __device__ __forceinline__ void lit_buf(const uint8_t *lit, uint64_t cnt)   // written by lanes of this wave (huf_streams): past L1
-    {
-        for (uint64_t i0 = 0; i0 < cnt; i0 += 256) {
-            uint8_t v[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t i = i0 + lane + 64 * k;
-                v[k] = i < cnt ? __hip_atomic_load(lit + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t i = i0 + lane + 64 * k;
-                if (i < cnt) put(i, v[k]);
-            }
-        }
-        op += cnt;
-    }
+    __device__ __forceinline__ void lit_src(S &src, uint64_t at, uint64_t cnt) { lit_from<false>(src.memory() + at, cnt); }
+    // (the Huffman streams' literals were written by lanes of this wave: read past L1)
+    __device__ __forceinline__ void lit_buf(const uint8_t *lit, uint64_t cnt) { lit_from<true>(lit, cnt); }
     __device__ __forceinline__ void lit_rle(uint8_t v, uint64_t cnt)
     {
         for (uint64_t i = lane; i < cnt; i += 64) put(i, v);
         op += cnt;
     }
-    __device__ __forceinline__ void match(uint64_t dist, uint64_t len)
+    __device__ __forceinline__ void match(uint64_t dist64, uint64_t len64)
     {
-        for (uint64_t i0 = 0; i0 < len; i0 += 64) {
-            const uint64_t i = i0 + lane;
-            // dist >= 64: this step's sources were written before it; dist < 64: the period just before this step
-            // (not the one before the whole match: a match longer than the ring has overwritten that one)
-            const uint64_t s = dist >= 64 ? op - dist + i : op + i0 - dist + (lane % (uint32_t)dist);
-            uint8_t v = 0;
-            if (dist <= kZsRing) {
-                if (i < len) v = ring[s & (kZsRing - 1)];
-            } else {
-                // The bytes behind the ring were stored at least kZsRing / 64 = 128 store instructions ago (a store moves at most
-                // 64 bytes), and a wave's memory operations complete in order: once all but its last 63 are done, those stores
-                // have reached L2, where the load — agent scope: past L1 — finds them.  No fence: the workgroup-scope fence
-                // waits for EVERY earlier store, the literals and matches just written, a memory round trip per far match
-                // (and rounds 2-5's agent-scope fence wrote the L2 back on top of it).
-                static_assert(kZsRing >= 1024, "what lies behind the ring is at least 16 stores old");
+        uint8_t *d = dst + op;
+        const uint32_t len = (uint32_t)len64, ro = (uint32_t)op;       // (a match: <= 128 KiB; the ring is indexed modulo its size)
+        if (dist64 <= kZsRing) {
+            const uint32_t dist = (uint32_t)dist64, ph = dist < 64 ? lane % dist : lane;
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                // dist >= 64: this step's sources were written before it; dist < 64: the period just before this step
+                // (not the one before the whole match: a match longer than the ring has overwritten that one)
+                const uint32_t s = ro + i0 - dist + ph;
+                if (i < len) {
+                    const uint8_t v = ring[s & (kZsRing - 1)];
+                    d[i] = v;
+                    ring[(ro + i) & (kZsRing - 1)] = v;
+                }
+            }
+        } else {
+            // The bytes behind the ring were stored at least kZsRing / 64 store instructions ago (a store moves at most 64
+            // bytes), and a wave's memory operations complete in order: once all but its last few are done, those stores
+            // have reached L2, where the load — agent scope: past L1 — finds them.  No fence: the workgroup-scope fence
+            // waits for EVERY earlier store, the literals and matches just written, a memory round trip per far match
+            // (and rounds 2-5's agent-scope fence wrote the L2 back on top of it).
+            static_assert(kZsRing >= 1024, "what lies behind the ring is at least 16 stores old");
+            const uint8_t *from = d - dist64;
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                const uint32_t i = i0 + lane;
                 if (kZsRing >= 64 * 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
                 else if (kZsRing >= 32 * 64) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < len) {
+                    const uint8_t v = __hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    d[i] = v;
+                    ring[(ro + i) & (kZsRing - 1)] = v;
+                }
             }
-            if (i < len) put(i, v);
         }
-        op += len;
+        op += len64;
     }
     // The tables of the work struct (LDS) to and from the batch's spill (global): every lane moves the same words both ways,
     // so what it reads back is what it wrote itself.  (Rare: a frame of several blocks; kta_zstd.h, ZsWorkSmall.)
