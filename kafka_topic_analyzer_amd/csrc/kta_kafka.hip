@@ -410,7 +410,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         win4[lane + 64] = v1;
         __syncthreads();
     }
-    __device__ __forceinline__ uint32_t byte(uint64_t at)          // `at` is the same in every lane
+    __device__ __forceinline__ uint32_t byte(uint32_t at)          // `at` is the same in every lane
     {
         const uint64_t abs = src0 + at;
         if (abs - wabs >= kZsWin) fetch(abs, 1);   // (unsigned: also abs < wabs and the empty window)
@@ -493,11 +493,11 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         return true;
     }
     // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; outside the slice: zeros
-    __device__ __forceinline__ uint64_t le64(uint64_t base, uint64_t n, int64_t first)
+    __device__ __forceinline__ uint64_t le64(uint32_t base, uint32_t n, int32_t first)
     {
-        const int64_t lo = first < 0 ? 0 : first, hi = first + 8 < (int64_t)n ? first + 8 : (int64_t)n;
+        const int32_t lo = first < 0 ? 0 : first, hi = first + 8 < (int32_t)n ? first + 8 : (int32_t)n;
         if (lo >= hi) return 0;
-        const uint64_t a0 = src0 + base + (uint64_t)lo, a1 = src0 + base + (uint64_t)hi - 1;
+        const uint64_t a0 = src0 + base + (uint32_t)lo, a1 = src0 + base + (uint32_t)hi - 1;
         if (a0 - wabs >= kZsWin || a1 - wabs >= kZsWin) fetch(a0, (uint32_t)(hi - lo));
         if (hi - lo == 8) {
             // all eight bytes inside the slice (every container of a sequence's fields but the stream's first): three aligned
@@ -512,7 +512,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         uint64_t c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int64_t k = first + i;
+            const int32_t k = first + i;
             if (k >= lo && k < hi) c |= (uint64_t)w[k] << (8 * i);
         }
         return (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
@@ -522,7 +522,7 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
 template <uint32_t kZsRing>
 struct ZsOutWave {                 // output sink: 64 bytes per step, the last kZsRing bytes mirrored in LDS
     uint8_t *dst;
-    uint64_t op;
+    uint32_t op;                   // (a batch inflates to less than 2 GiB: the index caps it at 512 MiB)
     uint8_t *ring;
     uint32_t lane;
     // (Round 6 measured the kernel without its literal copies (- 0.43 of 2.59 ms) and without its match copies (- 1.03), then
@@ -532,7 +532,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     // What a batch costs is its ~ 50 k instructions at the ~ 11 cycles each that two waves per SIMD leave exposed; the
     // copies are a third of them.  More waves — under 128 registers and 10 KiB of LDS a wave — was the way: kafka_zstd_inflate_coop.)
 
-    __device__ __forceinline__ void put(uint64_t i, uint8_t v)
+    __device__ __forceinline__ void put(uint32_t i, uint8_t v)
     {
         dst[op + i] = v;
         ring[(op + i) & (kZsRing - 1)] = v;
@@ -541,10 +541,10 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     // few bytes each through these, at 16 waves per CU the kernel is bound by the instructions it issues, and 64-bit index
     // arithmetic per byte-lane was a third of them.)
     template <bool PAST_L1>
-    __device__ __forceinline__ void lit_from(const uint8_t *p, uint64_t cnt64)
+    __device__ __forceinline__ void lit_from(const uint8_t *p, uint32_t cnt)
     {
         uint8_t *d = dst + op;
-        const uint32_t cnt = (uint32_t)cnt64, ro = (uint32_t)op;        // (a block's literals: <= 128 KiB)
+        const uint32_t ro = op;
         if (cnt <= 64) {                                               // the usual run: one step
             if (lane < cnt) {
                 const uint8_t v = PAST_L1 ? __hip_atomic_load(p + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[lane];
@@ -569,23 +569,23 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
                 }
             }
         }
-        op += cnt64;
-    }
-    template <class S>
-    __device__ __forceinline__ void lit_src(S &src, uint64_t at, uint64_t cnt) { lit_from<false>(src.memory() + at, cnt); }
-    // (the Huffman streams' literals were written by lanes of this wave: read past L1)
-    __device__ __forceinline__ void lit_buf(const uint8_t *lit, uint64_t cnt) { lit_from<true>(lit, cnt); }
-    __device__ __forceinline__ void lit_rle(uint8_t v, uint64_t cnt)
-    {
-        for (uint64_t i = lane; i < cnt; i += 64) put(i, v);
         op += cnt;
     }
-    __device__ __forceinline__ void match(uint64_t dist64, uint64_t len64)
+    template <class S>
+    __device__ __forceinline__ void lit_src(S &src, uint32_t at, uint32_t cnt) { lit_from<false>(src.memory() + at, cnt); }
+    // (the Huffman streams' literals were written by lanes of this wave: read past L1)
+    __device__ __forceinline__ void lit_buf(const uint8_t *lit, uint32_t cnt) { lit_from<true>(lit, cnt); }
+    __device__ __forceinline__ void lit_rle(uint8_t v, uint32_t cnt)
+    {
+        for (uint32_t i = lane; i < cnt; i += 64) put(i, v);
+        op += cnt;
+    }
+    __device__ __forceinline__ void match(uint32_t dist, uint32_t len)
     {
         uint8_t *d = dst + op;
-        const uint32_t len = (uint32_t)len64, ro = (uint32_t)op;       // (a match: <= 128 KiB; the ring is indexed modulo its size)
-        if (dist64 <= kZsRing) {
-            const uint32_t dist = (uint32_t)dist64, ph = dist < 64 ? lane % dist : lane;
+        const uint32_t ro = op;                                        // (the ring is indexed modulo its size)
+        if (dist <= kZsRing) {
+            const uint32_t ph = dist < 64 ? lane % dist : lane;
             for (uint32_t i0 = 0; i0 < len; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 // dist >= 64: this step's sources were written before it; dist < 64: the period just before this step
@@ -604,7 +604,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
             // waits for EVERY earlier store, the literals and matches just written, a memory round trip per far match
             // (and rounds 2-5's agent-scope fence wrote the L2 back on top of it).
             static_assert(kZsRing >= 1024, "what lies behind the ring is at least 16 stores old");
-            const uint8_t *from = d - dist64;
+            const uint8_t *from = d - dist;
             for (uint32_t i0 = 0; i0 < len; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 if (kZsRing >= 64 * 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
@@ -617,7 +617,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
                 }
             }
         }
-        op += len64;
+        op += len;
     }
     // The tables of the work struct (LDS) to and from the batch's spill (global): every lane moves the same words both ways,
     // so what it reads back is what it wrote itself.  (Rare: a frame of several blocks; kta_zstd.h, ZsWorkSmall.)
@@ -635,8 +635,8 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     // the Huffman streams of a literals section: all 64 lanes on one stream at a time, through the source's LDS window (which
     // the sequences' reader does not need yet; kta_zstd_huf_wave.h); the decoded literals are read back by all lanes (lit_buf)
     template <class W, class S>
-    __device__ __forceinline__ bool huf_streams(const W &w, S &src, uint32_t streams, const uint64_t at[4],
-                                                const uint64_t n[4], const uint64_t count[4], uint8_t *out)
+    __device__ __forceinline__ bool huf_streams(const W &w, S &src, uint32_t streams, const uint32_t at[4],
+                                                const uint32_t n[4], const uint32_t count[4], uint8_t *out)
     {
         const bool ok = zh_streams(reinterpret_cast<uint32_t *>(src.win4), src.buffer, src.src0, streams, at, n, count, w.huf_table(),
                                    w.huf_log, out, lane);
@@ -663,7 +663,12 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
     const uint64_t lit_cap = d.scratch_end > scratch ? d.scratch_end - scratch : 0;
     ZsWaveSrc src{buffer, src0, src0 + n, s_win, kZsNoWindow, lane};
     ZsOutWave<kZsRing> out{buffer + d.payload_off, 0, s_ring, lane};
-    const int64_t got = kta::zstd_inflate_t(src, n, out, cap, s_w, buffer + scratch, lit_cap,
+    if (n >= (1ull << 31) || cap >= (1ull << 31)) {        // (the decoder's positions are 32 bits wide; the index caps a batch at 512 MiB)
+        if (lane == 0) descs[b].status = KTA_KB_BAD_FRAMING;
+        return;
+    }
+    const int64_t got = kta::zstd_inflate_t(src, (uint32_t)n, out, (uint32_t)cap, s_w, buffer + scratch,
+                                             (uint32_t)(lit_cap < (1ull << 31) ? lit_cap : (1ull << 31) - 1),
                                              d.scratch_end >= scratch ? reinterpret_cast<kta::ZsSpill *>(buffer + spill) : nullptr);
     if (lane == 0) {
         if (got < 0) descs[b].status = KTA_KB_BAD_FRAMING;
@@ -671,7 +676,7 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
     }
 }
 
-__global__ __launch_bounds__(64) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
+__global__ __launch_bounds__(64) KTA_WAVES_PER_EU(4, 8) void kafka_zstd_inflate_coop(uint8_t *buffer, kta_kafka_batch_desc *descs, uint64_t n_batches)
 {
     // The wave is bound by latencies, so what the kernel delivers goes with the waves a CU holds, and those go with the LDS a
     // wave takes (160 KiB a CU, handed out in 1280-byte pieces) until the registers bind at four waves per SIMD (120 VGPRs):

@@ -94,17 +94,17 @@ KTA_ZSTD_HD uint32_t zs_highbit(uint32_t v)   // floor(log2(v)), v > 0
 // ---- byte source: plain memory ------------------------------------------------------------------------------
 struct ZsMem {
     const uint8_t *p;
-    KTA_ZSTD_HD uint32_t byte(uint64_t at) { return p[at]; }
+    KTA_ZSTD_HD uint32_t byte(uint32_t at) { return p[at]; }
     // a value every lane of a wave source holds alike (read from an LDS table, say): a wave source moves it to the
     // scalar unit, which keeps the uniform parsing out of the vector registers; nothing to do here
     KTA_ZSTD_HD uint32_t uni(uint32_t x) { return x; }
     // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; bytes outside the slice are zero
-    KTA_ZSTD_HD uint64_t le64(uint64_t base, uint64_t n, int64_t first)
+    KTA_ZSTD_HD uint64_t le64(uint32_t base, uint32_t n, int32_t first)
     {
         uint64_t c = 0;
         for (int i = 0; i < 8; i++) {
-            const int64_t k = first + i;
-            if (k >= 0 && (uint64_t)k < n) c |= (uint64_t)p[base + (uint64_t)k] << (8 * i);
+            const int32_t k = first + i;
+            if (k >= 0 && (uint32_t)k < n) c |= (uint64_t)p[base + (uint32_t)k] << (8 * i);
         }
         return c;
     }
@@ -113,15 +113,15 @@ struct ZsMem {
 
 // ---- forward (LSB first) bit reader: FSE table descriptions --------------------------------------------
 struct ZsFwd {
-    uint64_t base, n;   // the bytes [base, base + n) of the source
-    uint64_t bit;       // next bit
+    uint32_t base, n;   // the bytes [base, base + n) of the source
+    uint32_t bit;       // next bit
     bool bad;
     uint64_t cont;      // the stream bits [lo, lo + 64), lo a multiple of 8 (zeros past the end): one load per 6+ bytes
-    uint64_t lo;
+    uint32_t lo;
     bool loaded;
 };
 
-KTA_ZSTD_HD ZsFwd zs_fwd_init(uint64_t base, uint64_t n)
+KTA_ZSTD_HD ZsFwd zs_fwd_init(uint32_t base, uint32_t n)
 {
     ZsFwd f;
     f.base = base;
@@ -141,7 +141,7 @@ KTA_ZSTD_HD uint32_t zs_fwd(S &src, ZsFwd &f, uint32_t nb)   // nb <= 16
     if (f.bit + nb > 8 * f.n) { f.bad = true; return 0; }
     if (!f.loaded || f.bit < f.lo || f.bit + nb > f.lo + 64) {
         f.lo = f.bit & ~7ull;
-        f.cont = src.le64(f.base, f.n, (int64_t)(f.lo >> 3));
+        f.cont = src.le64(f.base, f.n, (int32_t)(f.lo >> 3));
         f.loaded = true;
     }
     const uint32_t v = (uint32_t)(f.cont >> (uint32_t)(f.bit - f.lo)) & ((1u << nb) - 1u);
@@ -154,22 +154,22 @@ KTA_ZSTD_HD uint32_t zs_fwd(S &src, ZsFwd &f, uint32_t nb)   // nb <= 16
 // are zeros); it is reloaded, eight bytes at once, when a read leaves it — about once per sequence or per
 // eight Huffman symbols instead of once per field.
 struct ZsBack {
-    uint64_t base, n;
-    int64_t off;        // bits [0, off) are unread; may go negative (zeros)
+    uint32_t base, n;
+    int32_t off;        // bits [0, off) are unread; may go negative (zeros)
     uint64_t cont;
-    int64_t lo;         // bit index of the container's bit 0; off + 1 .. : nothing loaded
+    int32_t lo;         // bit index of the container's bit 0; off + 1 .. : nothing loaded
     bool loaded;
 };
 
 template <class S>
-KTA_ZSTD_HD bool zs_back_init(S &src, ZsBack &b, uint64_t base, uint64_t n)
+KTA_ZSTD_HD bool zs_back_init(S &src, ZsBack &b, uint32_t base, uint32_t n)
 {
     if (n == 0) return false;
     const uint32_t last = src.byte(base + n - 1);
     if (last == 0) return false;
     b.base = base;
     b.n = n;
-    b.off = (int64_t)(8 * (n - 1)) + (int64_t)zs_highbit(last);
+    b.off = (int32_t)(8 * (n - 1)) + (int32_t)zs_highbit(last);
     b.cont = 0;
     b.lo = 0;
     b.loaded = false;
@@ -177,14 +177,14 @@ KTA_ZSTD_HD bool zs_back_init(S &src, ZsBack &b, uint64_t base, uint64_t n)
 }
 
 template <class S>
-KTA_ZSTD_HD uint64_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
+KTA_ZSTD_HD uint32_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
 {
-    b.off -= (int64_t)nb;
+    b.off -= (int32_t)nb;
     if (nb == 0) return 0;
-    const int64_t at = b.off;                        // the bits [at, at + nb)
-    if (!b.loaded || at < b.lo || at + (int64_t)nb > b.lo + 64) {
+    const int32_t at = b.off;                        // the bits [at, at + nb)
+    if (!b.loaded || at < b.lo || at + (int32_t)nb > b.lo + 64) {
         // the container ends at the byte boundary at or above at + nb: reads go downwards from here
-        const int64_t byte_hi = (at + (int64_t)nb + 7) >> 3, byte_lo = byte_hi - 8;
+        const int32_t byte_hi = (at + (int32_t)nb + 7) >> 3, byte_lo = byte_hi - 8;
         b.cont = src.le64(b.base, b.n, byte_lo);
         b.lo = byte_lo * 8;
         b.loaded = true;
@@ -201,7 +201,7 @@ KTA_ZSTD_HD uint64_t zs_back(S &src, ZsBack &b, uint32_t nb)   // nb <= 32
 template <class S>
 KTA_ZSTD_HD void zs_back_fill(S &src, ZsBack &b)
 {
-    const int64_t byte_lo = ((b.off + 7) >> 3) - 8;
+    const int32_t byte_lo = ((b.off + 7) >> 3) - 8;
     b.cont = src.le64(b.base, b.n, byte_lo);
     b.lo = byte_lo * 8;
     b.loaded = true;
@@ -209,7 +209,7 @@ KTA_ZSTD_HD void zs_back_fill(S &src, ZsBack &b)
 
 KTA_ZSTD_HD uint32_t zs_back_take(ZsBack &b, uint32_t nb)   // nb <= 31; at most 57 bits between two fills
 {
-    b.off -= (int64_t)nb;
+    b.off -= (int32_t)nb;
     return (uint32_t)(b.cont >> ((uint32_t)(b.off - b.lo) & 63u)) & ((1u << nb) - 1u);   // (& 63: nb = 0 right after a fill)
 }
 
@@ -321,7 +321,7 @@ KTA_ZSTD_HD void zs_default_norm(W &w, int which)
 
 // One of the three sequence tables.  mode: 0 predefined, 1 RLE, 2 described, 3 repeat.
 template <class W, class S>
-KTA_ZSTD_HD bool zs_seq_table(W &w, int which, uint32_t mode, S &src, uint64_t base, uint64_t n, uint64_t *pos)
+KTA_ZSTD_HD bool zs_seq_table(W &w, int which, uint32_t mode, S &src, uint32_t base, uint32_t n, uint32_t *pos)
 {
     uint32_t *t = which == 0 ? w.ll : (which == 1 ? w.of : w.ml);
     uint8_t &log = which == 0 ? w.ll_log : (which == 1 ? w.of_log : w.ml_log);
@@ -356,12 +356,12 @@ KTA_ZSTD_HD bool zs_seq_table(W &w, int which, uint32_t mode, S &src, uint64_t b
 // ---- Huffman ------------------------------------------------------------------------------------------------
 // Tree description at p[0 .. n): fills w.huf / w.huf_log; returns the bytes consumed, 0 on error.
 template <class W, class S>
-KTA_ZSTD_HD uint64_t zs_read_huffman(W &w, S &src, uint64_t base, uint64_t n)
+KTA_ZSTD_HD uint32_t zs_read_huffman(W &w, S &src, uint32_t base, uint32_t n)
 {
     if (n < 1) return 0;
     const uint32_t hb = src.byte(base);
     uint32_t n_w = 0;
-    uint64_t used;
+    uint32_t used;
     if (hb >= 128) {                                  // direct: 4 bits per weight
         n_w = hb - 127;
         used = 1 + (n_w + 1) / 2;
@@ -377,7 +377,7 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(W &w, S &src, uint64_t base, uint64_t n)
         uint32_t n_sym = 0;
         const uint32_t log = zs_read_norm(src, f, w, 6, 12, &n_sym);   // weights 0..12 (max code length 11 + 1)
         if (!log || !zs_build_fse_any(src, w, w.wfse, log, n_sym, 0)) return 0;
-        const uint64_t at = f.bit >> 3;
+        const uint32_t at = f.bit >> 3;
         if (at >= hb) return 0;
         ZsBack b;
         if (!zs_back_init(src, b, base + 1 + at, hb - at)) return 0;
@@ -431,32 +431,32 @@ KTA_ZSTD_HD uint64_t zs_read_huffman(W &w, S &src, uint64_t base, uint64_t n)
 }
 
 template <class W, class S>
-KTA_ZSTD_HD bool zs_huf_stream(const W &w, S &src, uint64_t base, uint64_t n, uint8_t *out, uint64_t count)
+KTA_ZSTD_HD bool zs_huf_stream(const W &w, S &src, uint32_t base, uint32_t n, uint8_t *out, uint32_t count)
 {
     ZsBack b;
     if (!zs_back_init(src, b, base, n)) return false;
     const uint32_t log = w.huf_log, mask = (1u << log) - 1u;
     const uint16_t *huf = w.huf_table();
     uint32_t state = (uint32_t)zs_back(src, b, log);
-    for (uint64_t i = 0; i < count; i++) {
-        if (b.off <= -(int64_t)log) return false;    // more symbols wanted than the stream holds
+    for (uint32_t i = 0; i < count; i++) {
+        if (b.off <= -(int32_t)log) return false;    // more symbols wanted than the stream holds
         const uint32_t e = huf[state], nb = e >> 8;
         out[i] = (uint8_t)e;
         state = ((state << nb) | (uint32_t)zs_back(src, b, nb)) & mask;
     }
-    return b.off == -(int64_t)log;                    // every bit consumed, none invented
+    return b.off == -(int32_t)log;                    // every bit consumed, none invented
 }
 
 // ---- literals and sequences ------------------------------------------------------------------------------
 struct ZsLit {
     const uint8_t *p;   // raw / decoded literals (nullptr for RLE)
-    uint64_t n;
+    uint32_t n;
     uint8_t rle;
 };
 
 // Parses the literals section header at p: type, regenerated and compressed sizes, header bytes (0 = error).
 template <class S>
-KTA_ZSTD_HD uint32_t zs_lit_header(S &src, uint64_t base, uint64_t n, uint32_t *type, uint32_t *regen, uint32_t *comp,
+KTA_ZSTD_HD uint32_t zs_lit_header(S &src, uint32_t base, uint32_t n, uint32_t *type, uint32_t *regen, uint32_t *comp,
                                    uint32_t *streams)
 {
     if (n < 1) return 0;
@@ -499,27 +499,27 @@ KTA_ZSTD_HD uint32_t zs_lit_header(S &src, uint64_t base, uint64_t n, uint32_t *
 // The callers have checked every bound (room in dst, literals left, offsets inside the frame); a sink moves bytes.
 struct ZsOutMem {
     uint8_t *dst;
-    uint64_t op;
+    uint32_t op;
 
     template <class S>
-    KTA_ZSTD_HD void lit_src(S &src, uint64_t at, uint64_t cnt)      // literals that sit in the compressed bytes
+    KTA_ZSTD_HD void lit_src(S &src, uint32_t at, uint32_t cnt)      // literals that sit in the compressed bytes
     {
-        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = (uint8_t)src.byte(at + k);
+        for (uint32_t k = 0; k < cnt; k++) dst[op + k] = (uint8_t)src.byte(at + k);
         op += cnt;
     }
-    KTA_ZSTD_HD void lit_buf(const uint8_t *lit, uint64_t cnt)         // Huffman-decoded literals
+    KTA_ZSTD_HD void lit_buf(const uint8_t *lit, uint32_t cnt)         // Huffman-decoded literals
     {
-        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = lit[k];
+        for (uint32_t k = 0; k < cnt; k++) dst[op + k] = lit[k];
         op += cnt;
     }
-    KTA_ZSTD_HD void lit_rle(uint8_t v, uint64_t cnt)
+    KTA_ZSTD_HD void lit_rle(uint8_t v, uint32_t cnt)
     {
-        for (uint64_t k = 0; k < cnt; k++) dst[op + k] = v;
+        for (uint32_t k = 0; k < cnt; k++) dst[op + k] = v;
         op += cnt;
     }
-    KTA_ZSTD_HD void match(uint64_t dist, uint64_t len)                // may overlap itself
+    KTA_ZSTD_HD void match(uint32_t dist, uint32_t len)                // may overlap itself
     {
-        uint64_t k = 0;
+        uint32_t k = 0;
         if (dist >= 8)
             for (; k + 8 <= len; k += 8) {
                 uint64_t v;
@@ -535,10 +535,10 @@ struct ZsOutMem {
     // the Huffman streams of a literals section (1 or 4; stream i: n[i] bytes at at[i], count[i] symbols, to
     // out + the counts before it): one after the other
     template <class W, class S>
-    KTA_ZSTD_HD bool huf_streams(const W &w, S &src, uint32_t streams, const uint64_t at[4], const uint64_t n[4],
-                                 const uint64_t count[4], uint8_t *out)
+    KTA_ZSTD_HD bool huf_streams(const W &w, S &src, uint32_t streams, const uint32_t at[4], const uint32_t n[4],
+                                 const uint32_t count[4], uint8_t *out)
     {
-        uint64_t done = 0;
+        uint32_t done = 0;
         for (uint32_t i = 0; i < streams; i++) {
             if (!zs_huf_stream(w, src, at[i], n[i], out + done, count[i])) return false;
             done += count[i];
@@ -550,17 +550,17 @@ struct ZsOutMem {
 // The literals of a block being handed out to its sequences.
 struct ZsLits {
     uint32_t type, regen;
-    uint64_t at;            // literals handed out so far
-    uint64_t src_at;        // raw: where they start in the source
+    uint32_t at;            // literals handed out so far
+    uint32_t src_at;        // raw: where they start in the source
     uint8_t rle;
     uint8_t *buf;           // Huffman coded: decoded here
-    uint64_t block_start, cap;
+    uint32_t block_start, cap;
 };
 
 template <class S, class O>
-KTA_ZSTD_HD bool zs_put_literals(ZsLits &l, S &src, O &out, uint64_t cnt)
+KTA_ZSTD_HD bool zs_put_literals(ZsLits &l, S &src, O &out, uint32_t cnt)
 {
-    if (cnt > (uint64_t)l.regen - l.at || out.op + cnt > l.cap || out.op + cnt - l.block_start > ZS_BLOCK_MAX) return false;
+    if (cnt > (uint32_t)l.regen - l.at || out.op + cnt > l.cap || out.op + cnt - l.block_start > ZS_BLOCK_MAX) return false;
     if (l.type == 0) out.lit_src(src, l.src_at + l.at, cnt);
     else if (l.type == 1) out.lit_rle(l.rle, cnt);
     else out.lit_buf(l.buf + l.at, cnt);
@@ -572,15 +572,15 @@ KTA_ZSTD_HD bool zs_put_literals(ZsLits &l, S &src, O &out, uint64_t cnt)
 // output; `frame_start`: output position where the frame began (offsets may not reach before it).
 // `spill`, `last` (the frame's last block): see ZsWorkSmall — a work struct with a table of its own never looks at them.
 template <class W, class S, class O>
-KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint64_t cap, uint64_t frame_start,
-                          uint64_t rep[3], uint8_t *lit_buf, uint64_t lit_cap, ZsSpill *spill, bool last)
+KTA_ZSTD_HD bool zs_block(W &w, S &src, uint32_t base, uint32_t n, O &out, uint32_t cap, uint32_t frame_start,
+                          uint32_t rep[3], uint8_t *lit_buf, uint32_t lit_cap, ZsSpill *spill, bool last)
 {
-    const uint64_t block_start = out.op;
+    const uint32_t block_start = out.op;
     uint32_t type, regen, comp, streams;
     const uint32_t hdr = zs_lit_header(src, base, n, &type, &regen, &comp, &streams);
     if (!hdr || regen > ZS_BLOCK_MAX) return false;
-    uint64_t pos = hdr;
-    uint64_t lit_src_at = 0;                          // type 0: where the raw literals start in src
+    uint32_t pos = hdr;
+    uint32_t lit_src_at = 0;                          // type 0: where the raw literals start in src
     uint8_t lit_rle = 0;
     if (type == 0) {                                  // raw: used in place
         if (pos + regen > n) return false;
@@ -599,21 +599,21 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint6
             if (seq_out) out.spill_words(spill->seq, w.ll, (uint32_t)(sizeof(spill->seq) / 4));
             if (type == 3) out.unspill_words(reinterpret_cast<uint32_t *>(w.huf_table()), spill->huf, (uint32_t)(sizeof(spill->huf) / 4));
         }
-        uint64_t q = base + pos, qn = comp;
+        uint32_t q = base + pos, qn = comp;
         if (type == 2) {
-            const uint64_t used = zs_read_huffman(w, src, q, qn);
+            const uint32_t used = zs_read_huffman(w, src, q, qn);
             if (!used) return false;
             q += used;
             qn -= used;
         }
-        uint64_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
+        uint32_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
         if (streams == 4) {
             if (qn < 6) return false;
-            const uint64_t s1 = (uint64_t)src.byte(q) | ((uint64_t)src.byte(q + 1) << 8);
-            const uint64_t s2 = (uint64_t)src.byte(q + 2) | ((uint64_t)src.byte(q + 3) << 8);
-            const uint64_t s3 = (uint64_t)src.byte(q + 4) | ((uint64_t)src.byte(q + 5) << 8);
+            const uint32_t s1 = (uint32_t)src.byte(q) | ((uint32_t)src.byte(q + 1) << 8);
+            const uint32_t s2 = (uint32_t)src.byte(q + 2) | ((uint32_t)src.byte(q + 3) << 8);
+            const uint32_t s3 = (uint32_t)src.byte(q + 4) | ((uint32_t)src.byte(q + 5) << 8);
             if (6 + s1 + s2 + s3 > qn) return false;
-            const uint64_t each = ((uint64_t)regen + 3) / 4;
+            const uint32_t each = ((uint32_t)regen + 3) / 4;
             if (3 * each > regen) return false;
             at[0] = q + 6;
             at[1] = at[0] + s1;
@@ -676,7 +676,7 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint6
             // the sequence's fields: offset (<= 31 bits), match length (<= 16), literal length (<= 16), then the three states
             // (<= 9 + 9 + 8); a fill is good for 57
             zs_back_fill(src, b);
-            const uint64_t ov = (1ull << oc) + zs_back_take(b, oc);
+            const uint32_t ov = (1u << oc) + zs_back_take(b, oc);
             const uint32_t mlen = (mt & 0xFFFFFFu) + zs_back_take(b, ml_bits);
             if (oc + ml_bits + ll_bits + 26 > 57) zs_back_fill(src, b);
             const uint32_t llen = (lt & 0xFFFFFFu) + zs_back_take(b, ll_bits);
@@ -686,7 +686,7 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint6
                 so = (eo >> 16) + zs_back_take(b, (eo >> 8) & 0xFF);
             }
             if (b.off < 0) return false;
-            uint64_t offset;
+            uint32_t offset;
             if (ov > 3) {
                 offset = ov - 3;
                 rep[2] = rep[1];
@@ -711,25 +711,25 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint64_t base, uint64_t n, O &out, uint6
     } else if (pos != n) {
         return false;
     }
-    return zs_put_literals(lits, src, out, (uint64_t)regen - lits.at);    // the literals after the last sequence
+    return zs_put_literals(lits, src, out, (uint32_t)regen - lits.at);    // the literals after the last sequence
 }
 
 struct ZsFrame {
-    uint64_t header;       // bytes of magic + frame header
+    uint32_t header;       // bytes of magic + frame header
     uint64_t window;       // window size (content size for single-segment frames)
     uint64_t content;      // frame content size, ~0 if absent
     bool checksum;
 };
 
 template <class S>
-KTA_ZSTD_HD bool zs_frame_header(S &src, uint64_t base, uint64_t n, ZsFrame *f)
+KTA_ZSTD_HD bool zs_frame_header(S &src, uint32_t base, uint32_t n, ZsFrame *f)
 {
     if (n < 6 || src.byte(base) != 0x28 || src.byte(base + 1) != 0xB5 || src.byte(base + 2) != 0x2F || src.byte(base + 3) != 0xFD)
         return false;
     const uint32_t fhd = src.byte(base + 4), fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
     if (fhd & 0x08) return false;                     // reserved bit
     if (did) return false;                            // dictionaries are not supported
-    uint64_t pos = 5;
+    uint32_t pos = 5;
     f->window = 0;
     if (!single) {
         if (pos >= n) return false;
@@ -759,7 +759,7 @@ KTA_ZSTD_HD bool zs_frame_header(S &src, uint64_t base, uint64_t n, ZsFrame *f)
 KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64_t *lit)
 {
     uint64_t pos = 0, total = 0, max_lit = 0;
-    if (n == 0) return false;
+    if (n == 0 || n >= (1ull << 31)) return false;     // (the decoder's positions are 32 bits wide)
     ZsMem src{p};
     while (pos < n) {
         ZsFrame f;
@@ -805,16 +805,16 @@ KTA_ZSTD_HD bool zstd_scan(const uint8_t *p, uint64_t n, uint64_t *bound, uint64
 // Inflates the frames of one batch payload — the bytes [0, n) of src — through `out` (room for cap bytes).
 // `lit`: scratch of at least the size zstd_scan reported.  Returns the bytes produced or -1.
 template <class W, class S, class O>
-KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, W *w, uint8_t *lit, uint64_t lit_cap, ZsSpill *spill = nullptr)
+KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint32_t n, O &out, uint32_t cap, W *w, uint8_t *lit, uint32_t lit_cap, ZsSpill *spill = nullptr)
 {
-    uint64_t pos = 0;
+    uint32_t pos = 0;
     if (n == 0) return -1;
     while (pos < n) {
         ZsFrame f;
         if (!zs_frame_header(src, pos, n - pos, &f)) return -1;
         pos += f.header;
-        const uint64_t frame_start = out.op;
-        uint64_t rep[3] = {1, 4, 8};
+        const uint32_t frame_start = out.op;
+        uint32_t rep[3] = {1, 4, 8};
         w->have_ll = w->have_of = w->have_ml = w->have_huf = 0;
         while (true) {
             if (pos + 3 > n) return -1;
@@ -850,18 +850,20 @@ KTA_ZSTD_HD int64_t zstd_inflate_t(S &src, uint64_t n, O &out, uint64_t cap, W *
 KTA_ZSTD_HD int64_t zstd_inflate(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWork *w, uint8_t *lit,
                                  uint64_t lit_cap)
 {
+    if (n >= (1ull << 31) || cap >= (1ull << 31)) return -1;
     ZsMem s{src};
     ZsOutMem o{dst, 0};
-    return zstd_inflate_t(s, n, o, cap, w, lit, lit_cap);
+    return zstd_inflate_t(s, (uint32_t)n, o, (uint32_t)cap, w, lit, (uint32_t)(lit_cap < (1ull << 31) ? lit_cap : (1ull << 31) - 1));
 }
 
 // ... the same with the small work struct and its spill: the host's execution of what the wave kernel runs
 KTA_ZSTD_HD int64_t zstd_inflate_small(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, ZsWorkSmall *w, ZsSpill *spill,
                                        uint8_t *lit, uint64_t lit_cap)
 {
+    if (n >= (1ull << 31) || cap >= (1ull << 31)) return -1;
     ZsMem s{src};
     ZsOutMem o{dst, 0};
-    return zstd_inflate_t(s, n, o, cap, w, lit, lit_cap, spill);
+    return zstd_inflate_t(s, (uint32_t)n, o, (uint32_t)cap, w, lit, (uint32_t)(lit_cap < (1ull << 31) ? lit_cap : (1ull << 31) - 1), spill);
 }
 
 }  // namespace kta

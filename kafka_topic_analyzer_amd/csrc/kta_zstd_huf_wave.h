@@ -136,12 +136,12 @@ __device__ __forceinline__ bool zh_stream(uint32_t *win, const uint8_t *buffer, 
 
 // The streams of one literals section (1 or 4): stream i is the n[i] bytes at buffer[src0 + at[i] ..) and holds count[i] symbols;
 // the literals -> out[0 .. count[0] + ... ).  Every lane of the wave calls this with the same arguments.
-__device__ __forceinline__ bool zh_streams(uint32_t *win, const uint8_t *buffer, uint64_t src0, uint32_t streams, const uint64_t at[4],
-                                           const uint64_t n[4], const uint64_t count[4], const uint16_t *huf, uint32_t log, uint8_t *out,
+__device__ __forceinline__ bool zh_streams(uint32_t *win, const uint8_t *buffer, uint64_t src0, uint32_t streams, const uint32_t at[4],
+                                           const uint32_t n[4], const uint32_t count[4], const uint16_t *huf, uint32_t log, uint8_t *out,
                                            uint32_t lane)
 {
     const uint64_t lo_bound = src0 & ~15ull;
-    uint64_t done = 0;
+    uint32_t done = 0;
     bool ok = true;
     for (uint32_t s = 0; s < streams && ok; s++) {
         if (n[s] > (1u << 27) || count[s] > (1u << 27)) return false;

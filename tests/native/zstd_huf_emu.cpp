@@ -35,19 +35,19 @@ int64_t kta_emu_zstd_huf(const uint8_t *sec, uint64_t n, uint32_t shift, uint8_t
     do {
         if (!hdr || type != 2 || hdr + comp > n) break;
         if (regen > cap) { rc = -4; break; }
-        uint64_t q = hdr, qn = comp;
-        const uint64_t used = kta::zs_read_huffman(w, src, q, qn);
+        uint32_t q = hdr, qn = comp;
+        const uint32_t used = kta::zs_read_huffman(w, src, q, qn);
         if (!used) break;
         q += used;
         qn -= used;
-        uint64_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
+        uint32_t at[4] = {q, 0, 0, 0}, len[4] = {qn, 0, 0, 0}, count[4] = {regen, 0, 0, 0};
         if (streams == 4) {                               // (kta_zstd.h: zs_block)
             if (qn < 6) break;
-            const uint64_t s1 = (uint64_t)src.byte(q) | ((uint64_t)src.byte(q + 1) << 8);
-            const uint64_t s2 = (uint64_t)src.byte(q + 2) | ((uint64_t)src.byte(q + 3) << 8);
-            const uint64_t s3 = (uint64_t)src.byte(q + 4) | ((uint64_t)src.byte(q + 5) << 8);
+            const uint32_t s1 = src.byte(q) | (src.byte(q + 1) << 8);
+            const uint32_t s2 = src.byte(q + 2) | (src.byte(q + 3) << 8);
+            const uint32_t s3 = src.byte(q + 4) | (src.byte(q + 5) << 8);
             if (6 + s1 + s2 + s3 > qn) break;
-            const uint64_t each = ((uint64_t)regen + 3) / 4;
+            const uint32_t each = (regen + 3) / 4;
             if (3 * each > regen) break;
             at[0] = q + 6; at[1] = at[0] + s1; at[2] = at[1] + s2; at[3] = at[2] + s3;
             len[0] = s1; len[1] = s2; len[2] = s3; len[3] = qn - 6 - s1 - s2 - s3;
