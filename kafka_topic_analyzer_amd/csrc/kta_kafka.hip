@@ -380,41 +380,45 @@ __global__ __launch_bounds__(kGzipLanes) void kafka_zstd_inflate(uint8_t *buffer
 // The policy methods are force-inlined: a call would pass `this` through memory, and the LDS address
 // spaces of the window, the ring and the tables would be lost (flat accesses, private-memory traffic).
 constexpr uint32_t kZsWin = 2048;                  // (1 KiB — a thirteenth wave per CU — measured the same: round 6)
-constexpr uint64_t kZsNoWindow = 1ull << 62;       // (x - kZsNoWindow is huge for every buffer offset x: "not in the window")
+constexpr int32_t kZsNoWindowRel = INT32_MIN / 2;  // (at - kZsNoWindowRel is huge for every position `at` of a batch: "not in the window")
 
-struct ZsWaveSrc {                 // byte source: the batch payload behind an LDS window (absolute buffer offsets)
+struct ZsWaveSrc {                 // byte source: the batch payload behind an LDS window
     const uint8_t *buffer;
-    uint64_t src0, src_end;        // the payload is buffer[src0 .. src_end)
+    uint64_t src0;                 // the payload is buffer[src0 .. src0 + n)
+    uint32_t n;
     uint4 *win4;
-    uint64_t wabs;                 // absolute offset of the window's first byte (16-byte aligned); kZsNoWindow: empty
+    int32_t wlo;                   // the window's first byte, relative to src0 (>= -15: it begins on a 16-byte boundary of the
+                                   // buffer); kZsNoWindowRel: empty.  (Relative and 32 bits wide: "is it in the window" is two
+                                   // scalar instructions, not the eight of a 64-bit compare of buffer offsets, and a sequence asks twice.)
     uint32_t lane;
 
     __device__ __forceinline__ const uint8_t *memory() const { return buffer + src0; }
     __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-    __device__ __forceinline__ void fetch(uint64_t abs, uint32_t need)   // make [abs, abs + need) readable through the window
+    __device__ __forceinline__ bool inside(uint32_t at) const { return (uint32_t)((int32_t)at - wlo) < kZsWin; }
+    __device__ __forceinline__ void fetch(uint32_t at, uint32_t need)   // make [at, at + need) readable through the window
     {
         __syncthreads();
-        const uint64_t lo = src0 & ~15ull;
-        uint64_t base = abs & ~15ull;
-        if (wabs != kZsNoWindow && abs < wabs) {       // reading backwards (bit streams): the window ends just above
-            const uint64_t end = (abs + need + 15) & ~15ull;
-            base = end >= kZsWin + lo ? end - kZsWin : lo;
+        const int32_t mis = (int32_t)((uint32_t)src0 & 15u);            // src0 - mis is a 16-byte boundary
+        int32_t base = (int32_t)((at + (uint32_t)mis) & ~15u) - mis;
+        if (wlo != kZsNoWindowRel && (int32_t)at < wlo) {               // reading backwards (bit streams): the window ends just above
+            const int32_t end = (int32_t)((at + need + (uint32_t)mis + 15u) & ~15u) - mis;
+            base = end - (int32_t)kZsWin >= -mis ? end - (int32_t)kZsWin : -mis;
         }
-        wabs = base;
-        const uint64_t last = ((src_end + 15) & ~15ull) - 16;          // last readable block of the batch
-        const uint4 *blocks = reinterpret_cast<const uint4 *>(buffer);
-        static_assert(kZsWin == 2048, "two 16-byte blocks per lane");
-        const uint64_t a0 = wabs + lane * 16, a1 = a0 + 1024;
-        const uint4 v0 = blocks[(a0 < last ? a0 : last) >> 4], v1 = blocks[(a1 < last ? a1 : last) >> 4];   // in flight together
+        wlo = base;
+        const int32_t last = (int32_t)((n + (uint32_t)mis + 15u) & ~15u) - 16 - mis;     // last readable unit of the batch
+        static_assert(kZsWin == 2048, "two 16-byte units per lane");
+        const int32_t a0 = wlo + (int32_t)lane * 16, a1 = a0 + 1024;
+        const uint8_t *m = buffer + src0;
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(m + (a0 < last ? a0 : last));    // in flight together
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(m + (a1 < last ? a1 : last));
         win4[lane] = v0;
         win4[lane + 64] = v1;
         __syncthreads();
     }
     __device__ __forceinline__ uint32_t byte(uint32_t at)          // `at` is the same in every lane
     {
-        const uint64_t abs = src0 + at;
-        if (abs - wabs >= kZsWin) fetch(abs, 1);   // (unsigned: also abs < wabs and the empty window)
-        return uni(reinterpret_cast<const uint8_t *>(win4)[abs - wabs]);
+        if (!inside(at)) fetch(at, 1);
+        return uni(reinterpret_cast<const uint8_t *>(win4)[(int32_t)at - wlo]);
     }
     // The FSE decoding table of w.norm[0 .. n_sym) (kta_zstd.h: zs_build_fse, RFC 8878 4.1.1) with all 64 lanes: the spec's
     // loops — spread the symbols over the cells with a stride, then walk the cells in order handing every symbol its states —
@@ -492,23 +496,23 @@ struct ZsWaveSrc {                 // byte source: the batch payload behind an L
         }
         return true;
     }
-    // the eight bytes [first, first + 8) of the slice [base, base + n), little endian; outside the slice: zeros
-    __device__ __forceinline__ uint64_t le64(uint32_t base, uint32_t n, int32_t first)
+    // the eight bytes [first, first + 8) of the slice [base, base + len), little endian; outside the slice: zeros
+    __device__ __forceinline__ uint64_t le64(uint32_t base, uint32_t len, int32_t first)
     {
-        const int32_t lo = first < 0 ? 0 : first, hi = first + 8 < (int32_t)n ? first + 8 : (int32_t)n;
+        const int32_t lo = first < 0 ? 0 : first, hi = first + 8 < (int32_t)len ? first + 8 : (int32_t)len;
         if (lo >= hi) return 0;
-        const uint64_t a0 = src0 + base + (uint32_t)lo, a1 = src0 + base + (uint32_t)hi - 1;
-        if (a0 - wabs >= kZsWin || a1 - wabs >= kZsWin) fetch(a0, (uint32_t)(hi - lo));
+        const uint32_t a0 = base + (uint32_t)lo, a1 = base + (uint32_t)hi - 1;
+        if (!inside(a0) || !inside(a1)) fetch(a0, (uint32_t)(hi - lo));
         if (hi - lo == 8) {
             // all eight bytes inside the slice (every container of a sequence's fields but the stream's first): three aligned
-            // words and two funnel shifts, one LDS round trip — the byte-by-byte form below is eight of them behind 64-bit
+            // words and two funnel shifts, one LDS round trip — the byte-by-byte form below is eight of them behind
             // compares, ~ 150 instructions per container, and a sequence takes one or two
-            const uint32_t o = (uint32_t)(a0 - wabs), wd = o >> 2, sh = (o & 3u) * 8u;
+            const uint32_t o = (uint32_t)((int32_t)a0 - wlo), wd = o >> 2, sh = (o & 3u) * 8u;
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win4);
             const uint32_t x0 = w32[wd], x1 = w32[wd + 1], x2 = w32[wd + 2 < kZsWin / 4 ? wd + 2 : kZsWin / 4 - 1];   // (x2 counts only if sh > 0: then wd + 2 is inside)
             return (uint64_t)uni(__builtin_amdgcn_alignbit(x1, x0, sh)) | ((uint64_t)uni(__builtin_amdgcn_alignbit(x2, x1, sh)) << 32);
         }
-        const uint8_t *w = reinterpret_cast<const uint8_t *>(win4) + (src0 + base - wabs);   // (may wrap: indexed with k below)
+        const uint8_t *w = reinterpret_cast<const uint8_t *>(win4) + ((int32_t)base - wlo);   // (may lie before the window: indexed with k below)
         uint64_t c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -640,7 +644,7 @@ struct ZsOutWave {                 // output sink: 64 bytes per step, the last k
     {
         const bool ok = zh_streams(reinterpret_cast<uint32_t *>(src.win4), src.buffer, src.src0, streams, at, n, count, w.huf_table(),
                                    w.huf_log, out, lane);
-        src.wabs = kZsNoWindow;                            // (the window holds a stream's bytes now)
+        src.wlo = kZsNoWindowRel;                          // (the window holds a stream's bytes now)
         __threadfence_block();                             // (the lanes' literals are read back by the wave's other lanes, past L1)
         return ok;
     }
@@ -661,7 +665,7 @@ __device__ __forceinline__ void zstd_inflate_wave(uint8_t *buffer, kta_kafka_bat
     const uint64_t scratch = spill + kZstdWorkBytes;                             // the literals of a Huffman-coded section
     static_assert(sizeof(kta::ZsSpill) <= kZstdWorkBytes, "the spill lies in the lane kernel's table space");
     const uint64_t lit_cap = d.scratch_end > scratch ? d.scratch_end - scratch : 0;
-    ZsWaveSrc src{buffer, src0, src0 + n, s_win, kZsNoWindow, lane};
+    ZsWaveSrc src{buffer, src0, (uint32_t)n, s_win, kZsNoWindowRel, lane};
     ZsOutWave<kZsRing> out{buffer + d.payload_off, 0, s_ring, lane};
     if (n >= (1ull << 31) || cap >= (1ull << 31)) {        // (the decoder's positions are 32 bits wide; the index caps a batch at 512 MiB)
         if (lane == 0) descs[b].status = KTA_KB_BAD_FRAMING;
