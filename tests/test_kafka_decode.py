@@ -3,6 +3,7 @@ header index against record sets built by the independent encoder (expected outp
 and against a committed byte-level fixture.  GPU: the device decode and the end-to-end
 `kta_kafka_consume` against the oracle."""
 import ctypes as C
+import sys
 import functools
 import json
 import os
@@ -872,6 +873,53 @@ def test_device_gzip_and_zstd_copy_paths():
                     assert kb[o:o + 3] == key, (variant, codecs[b], key)
                     at = kb.find(value[:64], o + 3, o + 3 + 8 + 64)    # the value follows its varint length
                     assert at > 0 and kb[at:at + len(value)] == value, (variant, codecs[b], key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("values", ["pattern", "text"])
+def test_device_inflates_the_generators_batches_of_every_codec(values):
+    """The synthetic encoder's batches (bench.py's source) in every codec, with its two value laws — the 24-byte periodic
+    pattern of the bench (raw literals and ~ 100 long matches per batch) and words / numbers / punctuation (Huffman-coded
+    literals in zstd, ~ 1 500 short matches per batch: the regime where the inflate kernels copy in rounds) —: the decoded
+    columns equal the generator's, and every inflated payload is, byte for byte, the uncompressed batch's."""
+    pytest.importorskip("pyarrow")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    lib = N.load()
+    spec, _ = kta.synth_preset("c4")
+    nc, rpb = 9000, 60
+    flag = 0x200 if values == "text" else 0
+
+    def encode(enc):
+        ln = C.c_uint64()
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc | flag, None, 0, C.byref(ln))
+        buf = np.zeros(ln.value + 128, np.uint8)
+        lib.kta_kafka_encode_synth_host_ex(C.byref(spec), 0, nc, rpb, enc | flag, buf.ctypes.data, ln.value, C.byref(ln))
+        return buf[:ln.value].tobytes()
+
+    plain = encode(0x100)
+    payloads = []
+    pos = 0
+    while pos + 61 <= len(plain):
+        total = 12 + int.from_bytes(plain[pos + 8:pos + 12], "big")
+        payloads.append(plain[pos + 61:pos + total])
+        pos += total
+    ref = kta.synth_fill_host(spec, 0, nc)
+    for codec in (1, 2, 3, 4):
+        blob = encode(codec) if codec in (2, 3) else bench._recompress_batches(lib, plain, codec)
+        assert len(blob) < len(plain)
+        for variant in (0, 1):
+            with kta.HipMetricHandler(2, now=NOW) as h:
+                h._check(lib.kta_kafka_set_variant(h._ctx, variant))
+                cols, st, bad = _decode_on_device(h, blob, 1, True)
+                assert bad == 0 and st.n_records == nc
+                for k in ("key_len", "val_len", "ts_ms"):
+                    assert np.array_equal(cols[k], ref[k]), (codec, variant, k)
+                rc, descs, _ = index_host(blob, 1)
+                whole = cols["key_bytes"]
+                for b, want in enumerate(payloads):         # a batch's slice of the inflate area begins at payload_off
+                    at = descs[b].payload_off
+                    assert whole[at:at + len(want)].tobytes() == want, (codec, variant, b)
 
 
 @pytest.mark.gpu
