@@ -674,11 +674,12 @@ KTA_ZSTD_HD bool zs_block(W &w, S &src, uint32_t base, uint32_t n, O &out, uint3
             const uint32_t mt = kMl[mc], lt = kLl[lc];
             const uint32_t ml_bits = mt >> 24, ll_bits = lt >> 24;
             // the sequence's fields: offset (<= 31 bits), match length (<= 16), literal length (<= 16), then the three states
-            // (<= 9 + 9 + 8); a fill is good for 57
-            zs_back_fill(src, b);
+            // (<= 9 + 9 + 8); a fill is good for 57, and what the sequence before left of its container (b.off - b.lo bits)
+            // often serves this one too
+            if (b.off - b.lo < (int32_t)(oc + ml_bits)) zs_back_fill(src, b);
             const uint32_t ov = (1u << oc) + zs_back_take(b, oc);
             const uint32_t mlen = (mt & 0xFFFFFFu) + zs_back_take(b, ml_bits);
-            if (oc + ml_bits + ll_bits + 26 > 57) zs_back_fill(src, b);
+            if (b.off - b.lo < (int32_t)(ll_bits + 26)) zs_back_fill(src, b);
             const uint32_t llen = (lt & 0xFFFFFFu) + zs_back_take(b, ll_bits);
             if (i + 1 < n_seq) {                      // state updates: literal length, match length, offset
                 sl = (el >> 16) + zs_back_take(b, (el >> 8) & 0xFF);
