@@ -9,9 +9,6 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_${TAG}
 RAW=/tmp/prof_${TAG}
 mkdir -p $OUT $RAW
-cd $ROOT
-timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-tail -c 600 $OUT/bench_n1.err
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $RAW/stats -o r -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hostfed --no-alive-extras > $OUT/bench_stats_run.json 2> $OUT/stats.err
 python $ROOT/tools/summarize_rocprof.py stats $(find $RAW/stats -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1
@@ -19,6 +16,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace -d $RAW/pmc_$c -o r -- python $ROOT/bench.py --steps 5 --warmup 1 --preroll 5 --no-cpu-baseline --no-hostfed --no-alive-extras > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python $ROOT/tools/summarize_rocprof.py pmc $(find $RAW/pmc_* -name '*.db') > $OUT/pmc_hbm.txt 2>&1
+# the default bench line LAST, with roofline.traffic replayed from THESE counter passes (the same file is regenerated from
+# pmc_hbm.txt in the repo afterwards: tools/make_traffic.py records the sources' hashes, which are the same there)
+cd $ROOT
+python tools/make_traffic.py $OUT/pmc_hbm.txt > profiles/traffic.json 2> $OUT/make_traffic.err
+timeout 500 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+tail -c 600 $OUT/bench_n1.err
 # the multi-GPU modes with ONE rank and the collectives forced (a 1-GPU box): config 5 (both handlers + the whole
 # exchange) and config 4 as stated (strong scaling); "forced_collectives": true, not headline numbers
 cd $ROOT
