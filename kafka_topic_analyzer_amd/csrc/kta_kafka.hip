@@ -1265,6 +1265,12 @@ int kta_kafka_index_host(const uint8_t *bytes, uint64_t len, int32_t partition, 
         if (batch_length < KTA_KAFKA_BATCH_HEADER - 12) break;           // not a v2 batch header: stop
         const uint64_t total = 12ull + (uint64_t)batch_length;
         if (pos + total > len) break;                                     // partial batch at the end of a fetch
+        // (the walk is a chain of cache misses, one header per batch, 5-6 KB apart: the next header is asked for while this
+        // batch is looked at, and the one after it where batches of this size would put it, and the trailer gzip / zstd read)
+        __builtin_prefetch(bytes + pos + total);
+        __builtin_prefetch(bytes + pos + total + 60);
+        if (pos + 2 * total + 64 <= len) __builtin_prefetch(bytes + pos + 2 * total);
+        __builtin_prefetch(bytes + pos + total - 8);
         const uint8_t magic = bytes[pos + 16];
         if (magic != 2) {
             stats->n_old_magic++;
