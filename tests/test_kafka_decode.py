@@ -923,7 +923,8 @@ def test_device_inflates_the_generators_batches_of_every_codec(values):
 
 
 @pytest.mark.gpu
-def test_device_inflate_verdicts_on_mutated_gzip_and_zstd_streams():
+@pytest.mark.parametrize("seed", [314, 2718, 1618])
+def test_device_inflate_verdicts_on_mutated_gzip_and_zstd_streams(seed):
     """The wave / lane executions of the gzip and zstd decoders against the host execution of the same text, on
     damaged streams: a batch whose stream the host function refuses must come back flagged (all of its records
     partition -1), undamaged batches must decode as before, and nothing may fault or hang — for both kernel
@@ -931,7 +932,7 @@ def test_device_inflate_verdicts_on_mutated_gzip_and_zstd_streams():
     pytest.importorskip("pyarrow")
     import ctypes as C2
     lib = N.load()
-    rng = np.random.default_rng(314)
+    rng = np.random.default_rng(seed)
     text = b"".join(b"user-%05d|%s|balance=%d;" % (i % 513, b"x" * (i % 37), i * 7919 % 100003) for i in range(2500))
     noise = bytes(rng.integers(0, 256, size=6000, dtype=np.uint8))
     recs = [(0, b"k0", text[:20000]), (1, b"k1", noise), (2, b"k2", text[20000:50000] + noise[:900]), (3, None, b"\0" * 9000)]
