@@ -32,9 +32,9 @@ p48=k('kta_alive_partition48<10, true, false>'); p48f=k('kta_alive_partition48<1
 fold=k('kta_fold_partials'); rng=k('kta_alive_apply<10, true, true>'); fb=k('kta_alive_fallback')
 B=7.046430720e9; B2=10.06632960e9; T=9.05969664e9; T2=12.07959552e9
 txt=f'''Round 6 (final kernels; `r06_*` from ONE gpurun call, `tools/profile_round.sh r06`, on the final tree — the round's last change of a profiled
-kernel was the zstd kernel's container fills; the recipe runs the kernel-stats process first, then the two counter passes, then — with the
+kernel file was the host index's prefetches (the zstd kernel's container fills before that); the recipe runs the kernel-stats process first, then the two counter passes, then — with the
 traffic of THOSE passes in `traffic.json` — the default `python bench.py` (`r06_bench_n1.json`), then the two forced lines.  The same recipe ran
-six times earlier in the round, on other boxes, after the table state's rewrite, the slot-range passes and the inflate kernels' steps: their
+seven times earlier in the round, on other boxes, after the table state's rewrite, the slot-range passes and the inflate kernels' steps: their
 numbers are quoted as "other boxes").
 `kta_metrics_scan<0,true,false>` on 2^30 records: {scan:.1f} us per launch under rocprofv3 (174 launches) vs {st['roofline']['kernel_ms']*1e3:.1f} us from the HIP events of the
 same process (`r06_bench_stats_run.json`) => {20*2**30/st['roofline']['kernel_ms']/1e9:.2f} TB/s = {st['roofline']['frac']:.3f}; the default run of the call (`r06_bench_n1.json`) {n1['roofline']['kernel_ms']*1e3:.1f} us => {n1['roofline']['frac']:.3f}
@@ -76,7 +76,7 @@ wave instead of 20, 32 waves per CU instead of 8 — {comp['snappy']['compressed
 bench line): gzip 2.73 ms = 56 GB/s (tokenizer 1.49 + apply 1.14), zstd 10.7 ms = 14.3, Snappy 3.59 ms = 53, LZ4 5.06 ms = 36.
 PCIe-inclusive: `raw_log_e2e` {e2e['metrics']['raw_log_GBps']:.1f} / {e2e['count_alive_keys']['raw_log_GBps']:.1f} GB/s of raw log (the round's boxes: 49-53; an untimed leg first: the order of the timed ones
 decides nothing any more); `raw_log_e2e.compressed`, GB/s of compressed log: Snappy {e2e['compressed']['snappy']['raw_log_GBps']:.1f}, gzip {e2e['compressed']['gzip']['raw_log_GBps']:.1f}, zstd {e2e['compressed']['zstd']['raw_log_GBps']:.1f}, LZ4 {e2e['compressed']['lz4']['raw_log_GBps']:.1f}
-(other boxes: 42.8-47.5 / 40.5-41.2 / 40.4-43.5 / 36.3-38.3); `host_fed` {n1['host_fed']['metrics']['GBps_over_pcie']:.1f} GB/s; `boundary_per_message` {bpm['c4']['value']/1e6:.0f} M messages/s ({bpm['c4']['ns_per_message']:.1f} ns
+(other boxes: 42.8-47.5 / 40.5-46.2 / 40.4-44.6 / 36.3-39.4); `host_fed` {n1['host_fed']['metrics']['GBps_over_pcie']:.1f} GB/s; `boundary_per_message` {bpm['c4']['value']/1e6:.0f} M messages/s ({bpm['c4']['ns_per_message']:.1f} ns
 each; config 4's records; other boxes 274-296 M) and {bpm['c3_alive_keys']['value']/1e6:.0f} M/s with `-c` and 16-byte keys ({bpm['c3_alive_keys']['ns_per_message']:.1f} ns) on one host thread.
 `r06_bench_c5_forced.json`: {c5f['ms_per_step']:.1f} ms per step on one rank (100 M distinct keys on ONE GPU in the table state — the direct path carries most of
 the batch; the exchange re-sends every entry the rank ever wrote); `r06_bench_c4_strong_forced.json`: {c4f['ms_per_step']:.2f} ms per step.
