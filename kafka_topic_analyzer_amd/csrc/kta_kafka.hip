@@ -890,21 +890,27 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
     if (b >= n_batches) return;
     const kta_kafka_batch_desc d = descs[b];
     if (!(d.flags & KTA_KB_LZ4) || d.status) return;
-    const uint64_t src0 = d.byte_off + KTA_KAFKA_BATCH_HEADER, src_end = d.byte_off + d.batch_bytes;
+    // Positions are relative to the batch's first payload byte and 32 bits wide, and what the wave parses — tokens, lengths,
+    // offsets — is moved to scalar registers as it is read (every lane reads the same byte): until round 6 the sequence loop
+    // computed in 64-bit VECTOR arithmetic on values all lanes held alike and branched through the exec mask, and at the 32
+    // waves per CU the kernel has now it is bound by the instructions it issues.
+    const uint8_t *src = buffer + d.byte_off + KTA_KAFKA_BATCH_HEADER;
+    const uint32_t src_len = (uint32_t)d.batch_bytes - KTA_KAFKA_BATCH_HEADER;
     uint8_t *dst = buffer + d.payload_off;
-    const uint64_t cap = d.payload_end - d.payload_off;               // a bound: blocks x block maximum size
-    const uint4 *blocks = reinterpret_cast<const uint4 *>(buffer);
-    uint64_t wbase = ~0ull;
-    auto fetch = [&](uint64_t at, uint32_t need) {
-        if (wbase != ~0ull && at >= wbase && at + need <= wbase + kSnapWin) return;
+    const uint64_t cap64 = d.payload_end - d.payload_off;             // a bound: blocks x block maximum size
+    const uint32_t cap = cap64 < 0x7FFFFFFFull ? (uint32_t)cap64 : 0x7FFFFFFFu;
+    const int32_t mis = (int32_t)((d.byte_off + KTA_KAFKA_BATCH_HEADER) & 15ull);    // src - mis is a 16-byte boundary
+    const int32_t last = (int32_t)((src_len + (uint32_t)mis + 15u) & ~15u) - 16 - mis;   // last readable unit of the batch
+    int32_t wbase = INT32_MIN / 2;                                    // the window's first byte (relative; >= -15)
+    auto fetch = [&](uint32_t at, uint32_t need) {
+        if ((uint32_t)((int32_t)at - wbase) < kSnapWin && (uint32_t)((int32_t)(at + need) - wbase) <= kSnapWin) return;
         __syncthreads();
-        wbase = at & ~15ull;
-        const uint64_t last = ((src_end + 15) & ~15ull) - 16;          // last readable block of the batch
+        wbase = (int32_t)((at + (uint32_t)mis) & ~15u) - mis;
         uint4 stage[kSnapWin / 1024];                                  // loads in flight together, then LDS
 #pragma unroll
         for (uint32_t u = 0; u < kSnapWin / 1024; u++) {
-            const uint64_t a = wbase + lane * 16 + u * 1024;
-            stage[u] = blocks[(a < last ? a : last) >> 4];
+            const int32_t a = wbase + (int32_t)(lane * 16 + u * 1024);
+            stage[u] = *reinterpret_cast<const uint4 *>(src + (a < last ? a : last));
         }
 #pragma unroll
         for (uint32_t u = 0; u < kSnapWin / 1024; u++) pin(stage[u]);
@@ -912,64 +918,78 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
         for (uint32_t u = 0; u < kSnapWin / 1024; u++) s_in[lane + 64 * u] = stage[u];
         __syncthreads();
     };
-    auto in_byte = [&](uint64_t at) -> uint32_t { return win[at - wbase]; };
+    auto in_byte = [&](uint32_t at) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[(int32_t)at - wbase]); };
+    // `n` bytes from p (memory) to the output at op
+    auto copy_in = [&](const uint8_t *p, uint32_t op, uint32_t n) {
+        uint8_t *o = dst + op;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint8_t v = p[i];
+            o[i] = v;
+            s_ring[(op + i) & (kSnapRing - 1)] = v;
+        }
+    };
     // copy `len` bytes of earlier output, `off` back, to the current position (64 bytes per step)
-    auto copy_match = [&](uint64_t op, uint64_t off, uint64_t len) {
-        for (uint64_t i0 = 0; i0 < len; i0 += 64) {
-            const uint64_t i = i0 + lane;
-            uint8_t v = 0;
-            // off >= 64: this step's sources were written before it; off < 64: the period just before this step
+    auto copy_match = [&](uint32_t op, uint32_t off, uint32_t len) {
+        uint8_t *o = dst + op;
+        if (off <= kSnapRing) {
+            // off >= 64: a step's sources were written before it; off < 64: the period just before the step
             // (not the one before the whole match: a match longer than the ring has overwritten that one)
-            const uint64_t s = off >= 64 ? op - off + i : op + i0 - off + (lane % (uint32_t)off);
-            if (off <= kSnapRing) {
-                if (i < len) v = s_ring[s & (kSnapRing - 1)];
-            } else {
-                __threadfence_block();
-                if (i < len) v = __hip_atomic_load(dst + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ph = off < 64 ? lane % off : lane;
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                if (i < len) {
+                    const uint8_t v = s_ring[(op + i0 - off + ph) & (kSnapRing - 1)];
+                    o[i] = v;
+                    s_ring[(op + i) & (kSnapRing - 1)] = v;
+                }
             }
-            if (i < len) {
-                dst[op + i] = v;
-                s_ring[(op + i) & (kSnapRing - 1)] = v;
+        } else {
+            const uint8_t *from = o - off;
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                __threadfence_block();
+                if (i < len) {
+                    const uint8_t v = __hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    o[i] = v;
+                    s_ring[(op + i) & (kSnapRing - 1)] = v;
+                }
             }
         }
     };
 
-    uint64_t op = 0;
-    bool bad = src_end - src0 < 7;
-    uint64_t pos = src0, block_max = 0;
+    uint32_t op = 0;
+    bool bad = src_len < 7 || src_len >= 0x7FFFFFF0u;
+    uint32_t pos = 0, block_max = 0;
     bool block_checksum = false;
     if (!bad) {
         fetch(pos, 16);
         bad = !(in_byte(pos) == 0x04 && in_byte(pos + 1) == 0x22 && in_byte(pos + 2) == 0x4D && in_byte(pos + 3) == 0x18);
         const uint32_t flg = in_byte(pos + 4), bd = in_byte(pos + 5), bs = (bd >> 4) & 7u;
         bad = bad || (flg >> 6) != 1u || bs < 4;
-        block_max = 1ull << (8 + 2 * bs);
+        block_max = 1u << (8 + 2 * bs);
         block_checksum = (flg & 0x10u) != 0;
         pos += 6 + ((flg & 0x08u) ? 8 : 0) + ((flg & 0x01u) ? 4 : 0) + 1;
     }
     while (!bad) {                                                    // one iteration per block
-        if (pos + 4 > src_end) { bad = true; break; }
+        if (pos + 4 > src_len) { bad = true; break; }
         fetch(pos, 4);
         const uint32_t w = in_byte(pos) | (in_byte(pos + 1) << 8) | (in_byte(pos + 2) << 16) | (in_byte(pos + 3) << 24);
         pos += 4;
         if (w == 0) break;                                            // end mark
-        const uint64_t sz = w & 0x7FFFFFFFu, bend = pos + sz;
-        if (sz > block_max || bend > src_end) { bad = true; break; }
+        const uint32_t sz = w & 0x7FFFFFFFu;
+        if (sz > block_max || sz > src_len - pos) { bad = true; break; }
+        const uint32_t bend = pos + sz;
         if (w & 0x80000000u) {                                        // stored block
-            if (op + sz > cap) { bad = true; break; }
-            for (uint64_t i = lane; i < sz; i += 64) {
-                const uint8_t v = buffer[pos + i];
-                dst[op + i] = v;
-                s_ring[(op + i) & (kSnapRing - 1)] = v;
-            }
+            if (sz > cap - op) { bad = true; break; }
+            copy_in(src + pos, op, sz);
             op += sz;
         } else {
-            uint64_t ip = pos;
+            uint32_t ip = pos;
             while (ip < bend) {                                       // one iteration per sequence
                 fetch(ip, 8);
                 const uint32_t token = in_byte(ip);
                 ip++;
-                uint64_t lit = token >> 4;
+                uint32_t lit = token >> 4;
                 if (lit == 15) {
                     uint32_t byte;
                     do {
@@ -981,20 +1001,16 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
                     } while (byte == 255);
                     if (bad) break;
                 }
-                if (ip + lit > bend || op + lit > cap) { bad = true; break; }
-                for (uint64_t i = lane; i < lit; i += 64) {           // literals straight from the compressed stream
-                    const uint8_t v = buffer[ip + i];
-                    dst[op + i] = v;
-                    s_ring[(op + i) & (kSnapRing - 1)] = v;
-                }
+                if (lit > bend - ip || lit > cap - op) { bad = true; break; }
+                copy_in(src + ip, op, lit);                           // literals straight from the compressed stream
                 ip += lit;
                 op += lit;
                 if (ip == bend) break;                                // the last sequence has no match
                 if (ip + 2 > bend) { bad = true; break; }
                 fetch(ip, 8);
-                const uint64_t off = (uint64_t)in_byte(ip) | ((uint64_t)in_byte(ip + 1) << 8);
+                const uint32_t off = in_byte(ip) | (in_byte(ip + 1) << 8);
                 ip += 2;
-                uint64_t ml = token & 15u;
+                uint32_t ml = token & 15u;
                 if (ml == 15) {
                     uint32_t byte;
                     do {
@@ -1007,7 +1023,7 @@ __global__ __launch_bounds__(64) void kafka_lz4_inflate_coop(uint8_t *buffer, kt
                     if (bad) break;
                 }
                 ml += 4;
-                if (off == 0 || off > op || op + ml > cap) { bad = true; break; }
+                if (off == 0 || off > op || ml > cap - op) { bad = true; break; }
                 copy_match(op, off, ml);
                 op += ml;
             }
