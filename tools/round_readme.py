@@ -32,9 +32,9 @@ p48=k('kta_alive_partition48<10, true, false>'); p48f=k('kta_alive_partition48<1
 fold=k('kta_fold_partials'); rng=k('kta_alive_apply<10, true, true>'); fb=k('kta_alive_fallback')
 B=7.046430720e9; B2=10.06632960e9; T=9.05969664e9; T2=12.07959552e9
 txt=f'''Round 6 (final kernels; `r06_*` from ONE gpurun call, `tools/profile_round.sh r06`, on the final tree — the round's last change of a profiled
-kernel file was the host index's prefetches (the zstd kernel's container fills before that); the recipe runs the kernel-stats process first, then the two counter passes, then — with the
+kernel was the LZ4 kernel's scalar parse; the recipe runs the kernel-stats process first, then the two counter passes, then — with the
 traffic of THOSE passes in `traffic.json` — the default `python bench.py` (`r06_bench_n1.json`), then the two forced lines.  The same recipe ran
-seven times earlier in the round, on other boxes, after the table state's rewrite, the slot-range passes and the inflate kernels' steps: their
+eight times earlier in the round, on other boxes, after the table state's rewrite, the slot-range passes and the inflate kernels' steps: their
 numbers are quoted as "other boxes").
 `kta_metrics_scan<0,true,false>` on 2^30 records: {scan:.1f} us per launch under rocprofv3 (174 launches) vs {st['roofline']['kernel_ms']*1e3:.1f} us from the HIP events of the
 same process (`r06_bench_stats_run.json`) => {20*2**30/st['roofline']['kernel_ms']/1e9:.2f} TB/s = {st['roofline']['frac']:.3f}; the default run of the call (`r06_bench_n1.json`) {n1['roofline']['kernel_ms']*1e3:.1f} us => {n1['roofline']['frac']:.3f}
@@ -72,8 +72,8 @@ us (637.2: a 4 KiB ring, a match at a time, 64 tokens at a time); inflate + deco
 `kafka_zstd_inflate_coop` {k('kafka_zstd_inflate_coop'):.1f} us (rounds 2-5: 2.80-2.85 ms — the FSE tables built by all 64 lanes, cheaper waits, 16 instead of 8 waves per
 CU, a sequence's fields from containers that serve two sequences, positions in 32 bits, the Huffman literals by the whole wave); inflate + decode
 {comp['zstd']['ms']:.2f} ms = {comp['zstd']['compressed_GBps']:.0f} GB/s (32.8); `kafka_snappy_inflate_coop` {k('kafka_snappy_inflate_coop'):.1f} us (1480.4) and `kafka_lz4_inflate_coop` {k('kafka_lz4_inflate_coop'):.1f} us (1134.9): 4 KiB of LDS a
-wave instead of 20, 32 waves per CU instead of 8 — {comp['snappy']['compressed_GBps']:.0f} and {comp['lz4']['compressed_GBps']:.0f} GB/s (65, 77)**.  JSON-like values (`tools/bench_inflate.py --values text`, not in the
-bench line): gzip 2.73 ms = 56 GB/s (tokenizer 1.49 + apply 1.14), zstd 10.7 ms = 14.3, Snappy 3.59 ms = 53, LZ4 5.06 ms = 36.
+wave instead of 20, 32 waves per CU instead of 8, and LZ4's parse in scalar registers with 32-bit positions — {comp['snappy']['compressed_GBps']:.0f} and {comp['lz4']['compressed_GBps']:.0f} GB/s (65, 77)**.  JSON-like values (`tools/bench_inflate.py --values text`, not in the
+bench line): gzip 2.73 ms = 56 GB/s (tokenizer 1.49 + apply 1.14), zstd 10.7 ms = 14.3, Snappy 3.59 ms = 53, LZ4 3.6 ms = 50.
 PCIe-inclusive: `raw_log_e2e` {e2e['metrics']['raw_log_GBps']:.1f} / {e2e['count_alive_keys']['raw_log_GBps']:.1f} GB/s of raw log (the round's boxes: 49-53; an untimed leg first: the order of the timed ones
 decides nothing any more); `raw_log_e2e.compressed`, GB/s of compressed log: Snappy {e2e['compressed']['snappy']['raw_log_GBps']:.1f}, gzip {e2e['compressed']['gzip']['raw_log_GBps']:.1f}, zstd {e2e['compressed']['zstd']['raw_log_GBps']:.1f}, LZ4 {e2e['compressed']['lz4']['raw_log_GBps']:.1f}
 (other boxes: 42.8-47.5 / 40.5-46.2 / 40.4-44.6 / 36.3-39.4); `host_fed` {n1['host_fed']['metrics']['GBps_over_pcie']:.1f} GB/s; `boundary_per_message` {bpm['c4']['value']/1e6:.0f} M messages/s ({bpm['c4']['ns_per_message']:.1f} ns
