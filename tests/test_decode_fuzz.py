@@ -61,7 +61,7 @@ def test_decode_kernel_is_memory_safe_on_damaged_record_sets(fuzzer):
                            K.encode_batch(40, recs, 10**12, raw_records=raw) + K.encode_batch(50, filler, 2000)))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:detect_stack_use_after_return=0",
                UBSAN_OPTIONS="print_stacktrace=1")
-    rounds = int(os.environ.get("KTA_FUZZ_ROUNDS", "60"))      # mutations per seed (150 took 150 s of the CPU suite's 420)
+    rounds = int(os.environ.get("KTA_FUZZ_ROUNDS", "40"))      # mutations per seed (150 took 150 s of the CPU suite's 420)
     r = subprocess.run([exe, str(rounds), *seeds], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     ok, reported = (int(x.split("=")[1]) for x in r.stdout.split()[1:3])
