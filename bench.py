@@ -743,7 +743,9 @@ def raw_log_e2e_report(kta, device, n_records=4_000_000, passes=4):
             cbuf[:len(z)] = np.frombuffer(z, np.uint8)
             cl.value = len(z)
         leg(cbuf, cl.value, False, 1, name)                       # (the codec's kernels loaded, the inflate area allocated)
-        out["compressed"][name] = leg(cbuf, cl.value, False, passes, name)
+        # (a compressed blob is a third of an uncompressed one: three times the passes for a timed stretch of the same length —
+        # with 12 blobs, 25 ms, the pipeline's fill and drain were a tenth of the row: tools/e2e_probe.py)
+        out["compressed"][name] = leg(cbuf, cl.value, False, 3 * passes, name)
     return out
 
 

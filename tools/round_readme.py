@@ -76,7 +76,7 @@ wave instead of 20, 32 waves per CU instead of 8, and LZ4's parse in scalar regi
 bench line): gzip 2.73 ms = 56 GB/s (tokenizer 1.49 + apply 1.14), zstd 10.7 ms = 14.3, Snappy 3.59 ms = 53, LZ4 3.6 ms = 50.
 PCIe-inclusive: `raw_log_e2e` {e2e['metrics']['raw_log_GBps']:.1f} / {e2e['count_alive_keys']['raw_log_GBps']:.1f} GB/s of raw log (the round's boxes: 49-53; an untimed leg first: the order of the timed ones
 decides nothing any more); `raw_log_e2e.compressed`, GB/s of compressed log: Snappy {e2e['compressed']['snappy']['raw_log_GBps']:.1f}, gzip {e2e['compressed']['gzip']['raw_log_GBps']:.1f}, zstd {e2e['compressed']['zstd']['raw_log_GBps']:.1f}, LZ4 {e2e['compressed']['lz4']['raw_log_GBps']:.1f}
-(other boxes: 42.8-47.5 / 40.5-46.2 / 40.4-44.6 / 36.3-39.4); `host_fed` {n1['host_fed']['metrics']['GBps_over_pcie']:.1f} GB/s; `boundary_per_message` {bpm['c4']['value']/1e6:.0f} M messages/s ({bpm['c4']['ns_per_message']:.1f} ns
+(36 blobs per codec; with the 12 of the round's earlier lines, 25 ms, the pipeline's fill and drain were a tenth of the row: 42.8-47.5 / 40.5-46.2 / 40.4-44.6 / 36.3-39.4); `host_fed` {n1['host_fed']['metrics']['GBps_over_pcie']:.1f} GB/s; `boundary_per_message` {bpm['c4']['value']/1e6:.0f} M messages/s ({bpm['c4']['ns_per_message']:.1f} ns
 each; config 4's records; other boxes 274-296 M) and {bpm['c3_alive_keys']['value']/1e6:.0f} M/s with `-c` and 16-byte keys ({bpm['c3_alive_keys']['ns_per_message']:.1f} ns) on one host thread.
 `r06_bench_c5_forced.json`: {c5f['ms_per_step']:.1f} ms per step on one rank (100 M distinct keys on ONE GPU in the table state — the direct path carries most of
 the batch; the exchange re-sends every entry the rank ever wrote); `r06_bench_c4_strong_forced.json`: {c4f['ms_per_step']:.2f} ms per step.
