@@ -26,6 +26,7 @@ namespace kta {
 struct Lz4Frame {
     uint64_t first_block; // offset of the first block header
     uint64_t block_max;   // block maximum size
+    uint64_t content;     // content size if the frame states it, else ~0
     bool block_checksum;
 };
 
@@ -39,6 +40,11 @@ KTA_LZ4_HD bool lz4_frame_header(const uint8_t *p, uint64_t n, Lz4Frame *f)
     f->block_max = 1ull << (8 + 2 * bs); // 4 -> 64 KiB ... 7 -> 4 MiB
     f->block_checksum = (flg & 0x10u) != 0;
     f->first_block = 6 + ((flg & 0x08u) ? 8 : 0) + ((flg & 0x01u) ? 4 : 0) + 1; // + HC
+    f->content = ~0ull;
+    if ((flg & 0x08u) && n >= 14) {
+        f->content = 0;
+        for (int i = 0; i < 8; i++) f->content |= (uint64_t)p[6 + i] << (8 * i);
+    }
     return f->first_block <= n;
 }
 
@@ -60,7 +66,9 @@ KTA_LZ4_HD int64_t lz4_inflate_bound(const uint8_t *p, uint64_t n)
         bound += (w & 0x80000000u) ? sz : (grown < f.block_max ? grown : f.block_max);
         pos += sz + (f.block_checksum ? 4 : 0);
     }
-    return (int64_t)bound;
+    // a frame that states its content size (librdkafka's do) gets a slice of that size: one that inflates to more is refused
+    // where it crosses it, as one that crosses the blocks' bound is
+    return (int64_t)(f.content < bound ? f.content : bound);
 }
 
 // Inflate one block into dst[op .. cap); `dst` holds the earlier blocks' output (linked blocks).
